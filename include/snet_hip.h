@@ -1,0 +1,166 @@
+/*
+ * snet_hip.h -- C ABI of libsnet_hip.so, the MI355X (gfx950) force-engine kernels
+ * for SevenNet's per-MD-step energy/force path.
+ *
+ * Boundary rules
+ *   - extern "C", plain pointers and sizes only (no torch / ATen types);
+ *   - every pointer argument is a DEVICE pointer unless the name ends in _host;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the legacy default stream); the caller owns all buffers;
+ *   - return value: 0 = ok, nonzero = error, message via snet_last_error()
+ *     (thread-local).  Style follows the reference's only existing C ABI,
+ *     sevenn/pair_e3gnn/pair_d3_for_ase.cu:2034-2082 (opaque handle + int rc).
+ *   - all floating point is fp32 (the reference is fp32-only:
+ *     sevenn/main/sevenn.py:138-139), indices are int32.
+ *
+ * Feature layout: node features are `ir_mul` (for each irrep block, a
+ * [2l+1][mul] slab; blocks concatenated) inside the engine.  The reference's
+ * boundary layout `mul_ir` ([mul][2l+1]) is converted with snet_permute_cols().
+ *
+ * Each entry point cites the reference code it replaces.
+ */
+#ifndef SNET_HIP_H
+#define SNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNET_ABI_VERSION 1
+
+/* ---- housekeeping ------------------------------------------------------- */
+int snet_abi_version(void);
+const char *snet_last_error(void);
+/* number of compiled tensor-product shapes; tag i (12 hex chars) */
+int snet_conv_num_shapes(void);
+const char *snet_conv_shape_tag(int i);
+
+/* ---- a1: edge embedding -------------------------------------------------
+ * replaces EdgeEmbedding.forward, sevenn/nn/edge_embedding.py:207-217
+ * (BesselBasis :101-103, PolynomialCutoff :125-132, XPLORCutoff :150-160,
+ *  SphericalEncoding :164-185 = e3nn SphericalHarmonics 'component').       */
+typedef struct snet_edge_params {
+  float cutoff;        /* rc */
+  int32_t n_basis;     /* <= 16 */
+  int32_t cutoff_kind; /* 0 poly_cut, 1 XPLOR */
+  int32_t poly_p;      /* poly_cut p value */
+  float cutoff_on;     /* XPLOR r_on */
+  int32_t lmax;        /* <= 3 */
+  int32_t normalize;   /* SH on unit vector (1) or raw vector (0, <0.10 checkpoints) */
+} snet_edge_params;
+
+/* edge_vec[E,3] -> emb[E,n_basis], sh[E,(lmax+1)^2]; coeffs_host[n_basis] = Bessel c_n (HOST) */
+int snet_edge_embed_fwd(const snet_edge_params *p_host, const float *coeffs_host, const float *edge_vec,
+                        int64_t n_edges, float *emb, float *sh, void *stream);
+/* g_vec[E,3] = d/d edge_vec of <g_emb,emb> + <g_sh,sh>  (replaces autograd through a1) */
+int snet_edge_embed_bwd(const snet_edge_params *p_host, const float *coeffs_host, const float *edge_vec,
+                        int64_t n_edges, const float *g_emb, const float *g_sh, float *g_vec, void *stream);
+
+/* ---- a3/a4/a2.1: dense channel mixing on MFMA (fp32 in / fp32 acc) --------
+ * One call = one per-irrep block of e3nn o3.Linear (sevenn/nn/linear.py:94-100),
+ * one species slice of the FCTP self-connection (self_connection.py:11-67), or
+ * one layer of the radial FullyConnectedNet (convolution.py:93-95,121).
+ *   C[node(n), m, :] (+)= A[node(n), m, :] @ B          n < n_nodes, m < d
+ *   A row address = A + node*a_node_stride + a_off + m*K      (K contiguous)
+ *   C row address = C + node*c_node_stride + c_off + m*N
+ *   node(n) = row_idx ? row_idx[n] : n        (species-grouped rows for FCTP)
+ * B is [K,N] row-major with the e3nn path normalisation already folded in.   */
+int snet_gemm(const float *A, const float *B, float *C, int64_t n_nodes, int32_t d, int32_t K, int32_t N,
+              int64_t a_node_stride, int64_t a_off, int64_t c_node_stride, int64_t c_off,
+              const int32_t *row_idx, int32_t accumulate, void *stream);
+
+/* a = act(z)*cst  /  g_z = g_a * cst * act'(z)   (act: 0 silu, 1 tanh);
+ * radial-MLP hidden activations, normalize2mom constant `cst` */
+int snet_act_fwd(const float *z, float *a, int64_t n, int32_t act, float cst, void *stream);
+int snet_act_bwd(const float *z, const float *g_a, float *g_z, int64_t n, int32_t act, float cst, void *stream);
+
+/* ---- a2.2-a2.5: fused gather -> uvu tensor product -> segmented reduce ----
+ * replaces IrrepsConvolution.forward lines 131-135 / the `convolution_cls`
+ * plug-in call of IrrepsScatterGatterFusedConvolution (convolution.py:270-278):
+ *   out[i] = scale * sum_{e: dst(e)=i} TP_uvu(x[src(e)], sh[e]; w[e])
+ * Edges must be sorted by destination (CSR row_ptr over the n_dst owned
+ * nodes); x has n_src >= n_dst rows (ghost rows are gather sources only,
+ * convolution.py:125-138).  A plan is a compiled specialisation looked up by
+ * its shape tag (sevennet_amd.model_spec.ConvSpec.tag).                      */
+typedef struct snet_conv_plan snet_conv_plan;
+int snet_conv_plan_create(const char *tag, snet_conv_plan **plan);
+void snet_conv_plan_destroy(snet_conv_plan *plan);
+int snet_conv_plan_dims(const snet_conv_plan *plan, int32_t *dx, int32_t *dout, int32_t *nsh, int32_t *wn);
+
+int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
+                  const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, float *out,
+                  void *stream);
+/* per-edge gradients: g_w[E,wn] (overwritten) and g_sh[E,nsh] (ACCUMULATED, so
+ * one buffer collects all layers) given g_out[n_dst,dout]                    */
+int snet_conv_bwd_edge(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
+                       const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
+                       const float *g_out, float *g_w, float *g_sh, void *stream);
+/* source-node gradient g_x[n_src,dx] (overwritten) via the source-sorted edge
+ * permutation: col_ptr[n_src+1], eperm[E] (edge ids grouped by source), dst[E].
+ * Deterministic replacement of the scatter-add autograd performs for x[src]. */
+int snet_conv_bwd_node(const snet_conv_plan *plan, const float *sh, const float *w, const int32_t *col_ptr,
+                       const int32_t *eperm, const int32_t *dst, int64_t n_src, float scale,
+                       const float *g_out, float *g_x, void *stream);
+
+/* ---- a5: equivariant gate ------------------------------------------------
+ * replaces EquivariantGate.forward, sevenn/nn/equivariant_gate.py:57-59     */
+typedef struct snet_gate_seg {
+  int32_t kind;     /* 0: scalars -> act(s)*cst ; 1: gated[m,u] * (act(gate[u])*cst) */
+  int32_t in_off;   /* offset in the gate input row */
+  int32_t out_off;  /* offset in the output row */
+  int32_t mul;
+  int32_t l;
+  int32_t gate_off; /* kind 1: offset of this segment's gate scalars in the input row */
+  int32_t act;      /* 0 silu, 1 tanh */
+  float cst;        /* normalize2mom constant of act */
+} snet_gate_seg;
+#define SNET_MAX_GATE_SEGS 16
+int snet_gate_fwd(const float *y, float *out, int64_t n_nodes, int32_t dim_in, int32_t dim_out,
+                  const snet_gate_seg *segs_host, int32_t n_segs, void *stream);
+int snet_gate_bwd(const float *y, const float *g_out, float *g_y, int64_t n_nodes, int32_t dim_in,
+                  int32_t dim_out, const snet_gate_seg *segs_host, int32_t n_segs, void *stream);
+
+/* ---- a6: species embedding (one-hot @ W == table lookup) ------------------
+ * replaces OnehotEmbedding + first IrrepsLinear, node_embedding.py:44-53,
+ * model_build.py:505-521.  out[n,:] = table[types[n],:]                     */
+int snet_embed_rows(const float *table, const int32_t *types, float *out, int64_t n_nodes, int32_t dim,
+                    void *stream);
+
+/* ---- a4.1 and friends: y += x ; column permutation (layout conversion) --- */
+int snet_add_inplace(float *y, const float *x, int64_t n, void *stream);
+int snet_permute_cols(const float *x, const int32_t *col_idx, float *out, int64_t n_rows, int32_t dim,
+                      void *stream); /* out[r,c] = x[r,col_idx[c]] */
+
+/* ---- a7/a8: per-species rescale + total energy ---------------------------
+ * replaces (SpeciesWise)Rescale.forward scale.py:53-56,155-162 and AtomReduce
+ * linear.py:127-141.  e_atom[n] = e[n]*scale[t]+shift[t] (n_scale==1: global);
+ * *energy (device double) = sum over the first n_nodes rows (deterministic).  */
+int snet_rescale_reduce(const float *e_scaled, const int32_t *types, const float *scale, const float *shift,
+                        int32_t n_scale, int64_t n_nodes, float *e_atom, double *energy, void *stream);
+
+/* ---- a9/a11: forces and virial from dE/d edge_vec --------------------------
+ * replaces ForceStressOutputFromEdge.forward force_output.py:189-228 and the
+ * host loops of pair_e3gnn.cpp:210-270.  Over n_nodes rows (locals + ghosts):
+ *   F[i]   = sum_{e: center(e)=i} g[e] - sum_{e: neighbor(e)=i} g[e]
+ *   vir[i] = -sum_{e: neighbor(e)=i} (rx gx, ry gy, rz gz, rx gy, ry gz, rz gx)
+ * in-edges via row_ptr (edges sorted by center), out-edges via col_ptr/eperm.
+ * virial_atom may be NULL; virial_total[6] (device double) may be NULL.       */
+int snet_edge_force(const float *g_vec, const float *edge_vec, const int32_t *row_ptr, const int32_t *col_ptr,
+                    const int32_t *eperm, int64_t n_nodes, int64_t n_edges, float *forces, float *virial_atom,
+                    double *virial_total, void *stream);
+
+/* ---- a12: halo pack / unpack ---------------------------------------------
+ * replaces PairE3GNNParallel::pack_forward_comm_gnn / unpack_reverse_comm_gnn,
+ * pair_e3gnn_parallel.cpp:747-911 (index_select / scatter / scatter-add).
+ *   gather:      out[i,:]      = x[idx[i],:]
+ *   scatter_add: y[idx[i],:]  += x[i,:]       (idx unique within one call)   */
+int snet_gather_rows(const float *x, const int32_t *idx, float *out, int64_t n_idx, int32_t dim, void *stream);
+int snet_scatter_add_rows(const float *x, const int32_t *idx, float *y, int64_t n_idx, int32_t dim,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNET_HIP_H */

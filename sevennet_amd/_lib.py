@@ -1,0 +1,102 @@
+"""ctypes binding of libsnet_hip.so (the C ABI declared in include/snet_hip.h).
+
+The HIP library is the product: there is no CPU or PyTorch fallback.  If the
+shared object is missing this module raises immediately (build it with
+`python -m sevennet_amd.build`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsnet_hip.so')
+
+c_f32p = C.c_void_p   # device float*
+c_i32p = C.c_void_p   # device int32*
+c_f64p = C.c_void_p
+c_stream = C.c_void_p
+
+
+class EdgeParams(C.Structure):
+    _fields_ = [('cutoff', C.c_float), ('n_basis', C.c_int32), ('cutoff_kind', C.c_int32),
+                ('poly_p', C.c_int32), ('cutoff_on', C.c_float), ('lmax', C.c_int32),
+                ('normalize', C.c_int32)]
+
+
+class GateSeg(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('in_off', C.c_int32), ('out_off', C.c_int32), ('mul', C.c_int32),
+                ('l', C.c_int32), ('gate_off', C.c_int32), ('act', C.c_int32), ('cst', C.c_float)]
+
+
+# name -> (restype, argtypes); mirrors include/snet_hip.h one to one
+SIGNATURES = {
+    'snet_abi_version': (C.c_int, []),
+    'snet_last_error': (C.c_char_p, []),
+    'snet_conv_num_shapes': (C.c_int, []),
+    'snet_conv_shape_tag': (C.c_char_p, [C.c_int]),
+    'snet_edge_embed_fwd': (C.c_int, [C.POINTER(EdgeParams), C.POINTER(C.c_float), c_f32p, C.c_int64, c_f32p,
+                                      c_f32p, c_stream]),
+    'snet_edge_embed_bwd': (C.c_int, [C.POINTER(EdgeParams), C.POINTER(C.c_float), c_f32p, C.c_int64, c_f32p,
+                                      c_f32p, c_f32p, c_stream]),
+    'snet_gemm': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                            C.c_int64, C.c_int64, C.c_int64, c_i32p, C.c_int32, c_stream]),
+    'snet_act_fwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_stream]),
+    'snet_act_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_stream]),
+    'snet_conv_plan_create': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    'snet_conv_plan_destroy': (None, [C.c_void_p]),
+    'snet_conv_plan_dims': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'snet_conv_fwd': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_float,
+                                c_f32p, c_stream]),
+    'snet_conv_bwd_edge': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_float,
+                                     c_f32p, c_f32p, c_f32p, c_stream]),
+    'snet_conv_bwd_node': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_float,
+                                     c_f32p, c_f32p, c_stream]),
+    'snet_gate_fwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(GateSeg), C.c_int32,
+                                c_stream]),
+    'snet_gate_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(GateSeg),
+                                C.c_int32, c_stream]),
+    'snet_embed_rows': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
+    'snet_add_inplace': (C.c_int, [c_f32p, c_f32p, C.c_int64, c_stream]),
+    'snet_permute_cols': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
+    'snet_rescale_reduce': (C.c_int, [c_f32p, c_i32p, c_f32p, c_f32p, C.c_int32, C.c_int64, c_f32p, c_f64p,
+                                      c_stream]),
+    'snet_edge_force': (C.c_int, [c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_int64, c_f32p, c_f32p,
+                                  c_f64p, c_stream]),
+    'snet_gather_rows': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
+    'snet_scatter_add_rows': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libsnet_hip.so and type every entry point.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} not found: the HIP force engine has not been built '
+            '(run `python -m sevennet_amd.build`); there is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.snet_abi_version() != 1:
+        raise RuntimeError('libsnet_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = load().snet_last_error()
+        raise RuntimeError(f'{what} failed (rc={rc}): {msg.decode() if msg else "?"}')
+
+
+def compiled_conv_tags():
+    lib = load()
+    return [lib.snet_conv_shape_tag(i).decode() for i in range(lib.snet_conv_num_shapes())]

@@ -1,0 +1,112 @@
+"""Ahead-of-time build of libsnet_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+
+    python -m sevennet_amd.build [-j N] [--force]
+
+Generates the spherical-harmonics header and one .hip per tensor-product shape
+(codegen.py), compiles every translation unit with
+`hipcc --offload-arch=gfx950 -O3` and links `sevennet_amd/libsnet_hip.so`
+in-tree (so it travels with the repo snapshot to the GPU box).
+"""
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+from . import codegen
+from .shapes import aot_conv_specs
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+GEN = os.path.join(CSRC, 'generated')
+OBJ = os.path.join(CSRC, 'build')
+INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
+LIB = os.path.join(HERE, 'libsnet_hip.so')
+ARCH = 'gfx950'
+STATIC_SOURCES = ['snet_api.cpp', 'snet_gemm.hip', 'snet_edge.hip', 'snet_node.hip', 'snet_force.hip']
+
+
+def _hipcc() -> str:
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found; the HIP force engine cannot be built')
+    return exe
+
+
+def _flags() -> List[str]:
+    return [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC',
+            f'-I{INCLUDE}', f'-I{CSRC}']
+
+
+def _stamp(src: str) -> str:
+    h = hashlib.sha1()
+    for p in [src, os.path.join(CSRC, 'snet_common.h'), os.path.join(INCLUDE, 'snet_hip.h'),
+              os.path.join(GEN, 'sh_generated.h')]:
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(_flags()).encode())
+    return h.hexdigest()
+
+
+def _compile(src: str, force: bool) -> str:
+    obj = os.path.join(OBJ, os.path.basename(src).rsplit('.', 1)[0] + '.o')
+    stamp_file = obj + '.stamp'
+    stamp = _stamp(src)
+    if not force and os.path.exists(obj) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return obj
+    cmd = [_hipcc()] + _flags() + ['-x', 'hip', '-c', src, '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr[-4000:]}')
+    with open(stamp_file, 'w') as f:
+        f.write(stamp)
+    return obj
+
+
+def build(jobs: int = 0, force: bool = False, extra_configs=(), verbose: bool = True) -> str:
+    os.makedirs(GEN, exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
+    codegen.write_if_changed(os.path.join(GEN, 'sh_generated.h'), codegen.gen_sh_header(3))
+    specs = aot_conv_specs(extra_configs)
+    sources = [os.path.join(CSRC, s) for s in STATIC_SOURCES]
+    keep = set()
+    for tag, spec in specs.items():
+        path = os.path.join(GEN, f'conv_{tag}.hip')
+        codegen.write_if_changed(path, codegen.gen_conv(spec))
+        sources.append(path)
+        keep.add(os.path.basename(path))
+    for f in os.listdir(GEN):  # drop stale generated shapes
+        if f.startswith('conv_') and f not in keep:
+            os.remove(os.path.join(GEN, f))
+    jobs = jobs or min(16, os.cpu_count() or 4)
+    if verbose:
+        print(f'[sevennet_amd.build] {len(sources)} translation units ({len(specs)} conv shapes), -j{jobs}',
+              flush=True)
+    with cf.ThreadPoolExecutor(jobs) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), sources))
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        cmd = [_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stderr[-4000:]}')
+    if verbose:
+        print(f'[sevennet_amd.build] built {LIB}', flush=True)
+    return LIB
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('-j', type=int, default=0)
+    ap.add_argument('--force', action='store_true')
+    a = ap.parse_args(argv)
+    build(a.j, a.force)
+
+
+if __name__ == '__main__':
+    main()

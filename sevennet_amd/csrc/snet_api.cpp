@@ -1,0 +1,111 @@
+// C-ABI glue of libsnet_hip.so: error state, compiled-shape registry, conv plans, scratch.
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "snet_common.h"
+
+namespace snet {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+static std::vector<const ConvKernels *> &registry() {
+  static std::vector<const ConvKernels *> r;
+  return r;
+}
+void register_conv(const ConvKernels *k) { registry().push_back(k); }
+
+// Small per-device scratch for deterministic two-stage reductions (grown on demand, never
+// shrunk).  Reductions on one device are stream-ordered by the hosts of this library (one
+// host thread per device), so a single buffer per device suffices.
+double *reduce_scratch(int64_t n_doubles, hipStream_t st) {
+  (void)st;
+  static std::mutex mu;
+  static std::map<int, std::pair<double *, int64_t>> bufs;
+  std::lock_guard<std::mutex> lk(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  auto &b = bufs[dev];
+  if (b.second < n_doubles) {
+    if (b.first) (void)hipFree(b.first);
+    const int64_t n = n_doubles < 4096 ? 4096 : n_doubles;
+    if (hipMalloc(&b.first, sizeof(double) * n) != hipSuccess) {
+      b = {nullptr, 0};
+      return nullptr;
+    }
+    b.second = n;
+  }
+  return b.first;
+}
+
+}  // namespace snet
+
+struct snet_conv_plan {
+  const snet::ConvKernels *k;
+};
+
+extern "C" {
+
+int snet_abi_version(void) { return SNET_ABI_VERSION; }
+const char *snet_last_error(void) { return snet::g_err.c_str(); }
+int snet_conv_num_shapes(void) { return (int)snet::registry().size(); }
+const char *snet_conv_shape_tag(int i) {
+  auto &r = snet::registry();
+  return (i >= 0 && i < (int)r.size()) ? r[i]->tag : nullptr;
+}
+
+int snet_conv_plan_create(const char *tag, snet_conv_plan **plan) {
+  SNET_REQUIRE(tag != nullptr && plan != nullptr, "snet_conv_plan_create: null argument");
+  for (const snet::ConvKernels *k : snet::registry()) {
+    if (std::string(k->tag) == tag) {
+      *plan = new snet_conv_plan{k};
+      return 0;
+    }
+  }
+  snet::set_error(std::string("snet_conv_plan_create: tensor-product shape '") + tag +
+                  "' is not compiled into libsnet_hip.so (register the model config in "
+                  "sevennet_amd/shapes.py and rebuild)");
+  return 3;
+}
+void snet_conv_plan_destroy(snet_conv_plan *plan) { delete plan; }
+int snet_conv_plan_dims(const snet_conv_plan *plan, int32_t *dx, int32_t *dout, int32_t *nsh, int32_t *wn) {
+  SNET_REQUIRE(plan != nullptr, "snet_conv_plan_dims: null plan");
+  if (dx) *dx = plan->k->dx;
+  if (dout) *dout = plan->k->dout;
+  if (nsh) *nsh = plan->k->nsh;
+  if (wn) *wn = plan->k->wn;
+  return 0;
+}
+
+int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
+                  const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, float *out, void *stream) {
+  SNET_REQUIRE(plan != nullptr, "snet_conv_fwd: null plan");
+  SNET_REQUIRE(n_dst < (1ll << 31), "snet_conv_fwd: too many nodes");
+  if (n_dst <= 0) return 0;
+  plan->k->fwd(x, sh, w, row_ptr, src, n_dst, scale, out, static_cast<hipStream_t>(stream));
+  SNET_CHECK_LAUNCH("snet_conv_fwd");
+  return 0;
+}
+int snet_conv_bwd_edge(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
+                       const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, const float *g_out,
+                       float *g_w, float *g_sh, void *stream) {
+  SNET_REQUIRE(plan != nullptr, "snet_conv_bwd_edge: null plan");
+  SNET_REQUIRE(n_dst < (1ll << 31), "snet_conv_bwd_edge: too many nodes");
+  if (n_dst <= 0) return 0;
+  plan->k->bwd_edge(x, sh, w, row_ptr, src, n_dst, scale, g_out, g_w, g_sh, static_cast<hipStream_t>(stream));
+  SNET_CHECK_LAUNCH("snet_conv_bwd_edge");
+  return 0;
+}
+int snet_conv_bwd_node(const snet_conv_plan *plan, const float *sh, const float *w, const int32_t *col_ptr,
+                       const int32_t *eperm, const int32_t *dst, int64_t n_src, float scale, const float *g_out,
+                       float *g_x, void *stream) {
+  SNET_REQUIRE(plan != nullptr, "snet_conv_bwd_node: null plan");
+  SNET_REQUIRE(n_src < (1ll << 31), "snet_conv_bwd_node: too many nodes");
+  if (n_src <= 0) return 0;
+  plan->k->bwd_node(sh, w, col_ptr, eperm, dst, n_src, scale, g_out, g_x, static_cast<hipStream_t>(stream));
+  SNET_CHECK_LAUNCH("snet_conv_bwd_node");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+// Edge embedding: |r|, Bessel radial basis x cutoff envelope,
+// real spherical harmonics -- forward and the analytic reverse pass wrt edge_vec.
+// One lane per edge; purely HBM-bound (reads 12 B, writes 4*(n_basis+nsh) B per edge).
+#include "snet_common.h"
+// clang-format off
+#include "generated/sh_generated.h"
+// clang-format on
+
+namespace {
+
+struct EdgeP {
+  float rc, r_on, pref;
+  int nb, kind, p, lmax, normalize;
+  float coeffs[16];
+};
+
+__device__ __forceinline__ void envelope(const EdgeP &P, float r, float &env, float &denv) {
+  if (P.kind == 0) {  // poly_cut: 1 - a x^p + b x^(p+1) - c x^(p+2)   (edge_embedding.py:125-132)
+    const float p = (float)P.p;
+    const float a = (p + 1.f) * (p + 2.f) * 0.5f, b = p * (p + 2.f), c = p * (p + 1.f) * 0.5f;
+    const float x = r / P.rc;
+    float xp1 = 1.f;  // x^(p-1)
+    for (int i = 0; i < P.p - 1; ++i) xp1 *= x;
+    const float xp = xp1 * x;
+    env = 1.f - a * xp + b * xp * x - c * xp * x * x;
+    denv = (-a * p * xp1 + b * (p + 1.f) * xp - c * (p + 2.f) * xp * x) / P.rc;
+  } else {  // XPLOR (edge_embedding.py:150-160)
+    if (r < P.r_on) {
+      env = 1.f;
+      denv = 0.f;
+    } else {
+      const float r2 = r * r, c2 = P.rc * P.rc, o2 = P.r_on * P.r_on;
+      const float D = (c2 - o2) * (c2 - o2) * (c2 - o2);
+      env = (c2 - r2) * (c2 - r2) * (c2 + 2.f * r2 - 3.f * o2) / D;
+      denv = 12.f * r * (c2 - r2) * (o2 - r2) / D;
+    }
+  }
+}
+
+template <int LMAX>
+__device__ __forceinline__ void sh_eval(float x, float y, float z, float (&Y)[(LMAX + 1) * (LMAX + 1)]);
+template <> __device__ __forceinline__ void sh_eval<0>(float x, float y, float z, float (&Y)[1]) { sh_eval_0(x, y, z, Y); }
+template <> __device__ __forceinline__ void sh_eval<1>(float x, float y, float z, float (&Y)[4]) { sh_eval_1(x, y, z, Y); }
+template <> __device__ __forceinline__ void sh_eval<2>(float x, float y, float z, float (&Y)[9]) { sh_eval_2(x, y, z, Y); }
+template <> __device__ __forceinline__ void sh_eval<3>(float x, float y, float z, float (&Y)[16]) { sh_eval_3(x, y, z, Y); }
+template <int LMAX>
+__device__ __forceinline__ void sh_grad(float x, float y, float z, const float (&g)[(LMAX + 1) * (LMAX + 1)], float &gx, float &gy, float &gz);
+template <> __device__ __forceinline__ void sh_grad<0>(float x, float y, float z, const float (&g)[1], float &gx, float &gy, float &gz) { sh_grad_0(x, y, z, g, gx, gy, gz); }
+template <> __device__ __forceinline__ void sh_grad<1>(float x, float y, float z, const float (&g)[4], float &gx, float &gy, float &gz) { sh_grad_1(x, y, z, g, gx, gy, gz); }
+template <> __device__ __forceinline__ void sh_grad<2>(float x, float y, float z, const float (&g)[9], float &gx, float &gy, float &gz) { sh_grad_2(x, y, z, g, gx, gy, gz); }
+template <> __device__ __forceinline__ void sh_grad<3>(float x, float y, float z, const float (&g)[16], float &gx, float &gy, float &gz) { sh_grad_3(x, y, z, g, gx, gy, gz); }
+
+template <int LMAX>
+__global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeP P, const float *__restrict__ vec, int64_t E,
+                                                       float *__restrict__ emb, float *__restrict__ sh) {
+  constexpr int NSH = (LMAX + 1) * (LMAX + 1);
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float x = vec[3 * e + 0], y = vec[3 * e + 1], z = vec[3 * e + 2];
+  const float r = sqrtf(x * x + y * y + z * z);
+  float env, denv;
+  envelope(P, r, env, denv);
+  const float s = P.pref * env / r;
+  for (int k = 0; k < P.nb; ++k) emb[e * P.nb + k] = sinf(P.coeffs[k] * r) * s;
+  float Y[NSH];
+  if (P.normalize) {
+    const float ir = 1.f / r;
+    sh_eval<LMAX>(x * ir, y * ir, z * ir, Y);
+  } else {
+    sh_eval<LMAX>(x, y, z, Y);
+  }
+#pragma unroll
+  for (int i = 0; i < NSH; ++i) sh[e * NSH + i] = Y[i];
+}
+
+template <int LMAX>
+__global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeP P, const float *__restrict__ vec, int64_t E,
+                                                       const float *__restrict__ g_emb,
+                                                       const float *__restrict__ g_sh, float *__restrict__ g_vec) {
+  constexpr int NSH = (LMAX + 1) * (LMAX + 1);
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float x = vec[3 * e + 0], y = vec[3 * e + 1], z = vec[3 * e + 2];
+  const float r = sqrtf(x * x + y * y + z * z);
+  const float ir = 1.f / r;
+  float env, denv;
+  envelope(P, r, env, denv);
+  // d/dr of pref * sin(c r)/r * env(r)
+  float gr = 0.f;
+  for (int k = 0; k < P.nb; ++k) {
+    float sn, cs;
+    sincosf(P.coeffs[k] * r, &sn, &cs);
+    const float f = sn * ir;
+    const float df = (P.coeffs[k] * cs - f) * ir;
+    gr += g_emb[e * P.nb + k] * P.pref * (df * env + f * denv);
+  }
+  float gY[NSH];
+#pragma unroll
+  for (int i = 0; i < NSH; ++i) gY[i] = g_sh[e * NSH + i];
+  float gx, gy, gz;
+  if (P.normalize) {
+    const float ux = x * ir, uy = y * ir, uz = z * ir;
+    sh_grad<LMAX>(ux, uy, uz, gY, gx, gy, gz);
+    const float dot = ux * gx + uy * gy + uz * gz;  // project out the radial part
+    gx = (gx - ux * dot) * ir;
+    gy = (gy - uy * dot) * ir;
+    gz = (gz - uz * dot) * ir;
+  } else {
+    sh_grad<LMAX>(x, y, z, gY, gx, gy, gz);
+  }
+  g_vec[3 * e + 0] = gx + gr * x * ir;
+  g_vec[3 * e + 1] = gy + gr * y * ir;
+  g_vec[3 * e + 2] = gz + gr * z * ir;
+}
+
+int prepare(const snet_edge_params *p, const float *coeffs_host, EdgeP &P) {
+  SNET_REQUIRE(p != nullptr && coeffs_host != nullptr, "snet_edge_embed: null params");
+  SNET_REQUIRE(p->n_basis >= 1 && p->n_basis <= 16, "snet_edge_embed: n_basis must be in 1..16");
+  SNET_REQUIRE(p->lmax >= 0 && p->lmax <= 3, "snet_edge_embed: lmax must be in 0..3");
+  SNET_REQUIRE(p->cutoff_kind == 0 || p->cutoff_kind == 1, "snet_edge_embed: unknown cutoff kind");
+  SNET_REQUIRE(p->cutoff > 0.f, "snet_edge_embed: cutoff must be positive");
+  P.rc = p->cutoff;
+  P.r_on = p->cutoff_on;
+  P.pref = 2.0f / p->cutoff;
+  P.nb = p->n_basis;
+  P.kind = p->cutoff_kind;
+  P.p = p->poly_p;
+  P.lmax = p->lmax;
+  P.normalize = p->normalize;
+  for (int i = 0; i < 16; ++i) P.coeffs[i] = i < p->n_basis ? coeffs_host[i] : 0.f;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int snet_edge_embed_fwd(const snet_edge_params *p, const float *coeffs, const float *edge_vec,
+                                   int64_t E, float *emb, float *sh, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  EdgeP P;
+  if (int rc = prepare(p, coeffs, P)) return rc;
+  if (E <= 0) return 0;
+  const unsigned grid = (unsigned)((E + 255) / 256);
+  switch (P.lmax) {
+    case 0: edge_fwd_kernel<0><<<grid, 256, 0, st>>>(P, edge_vec, E, emb, sh); break;
+    case 1: edge_fwd_kernel<1><<<grid, 256, 0, st>>>(P, edge_vec, E, emb, sh); break;
+    case 2: edge_fwd_kernel<2><<<grid, 256, 0, st>>>(P, edge_vec, E, emb, sh); break;
+    default: edge_fwd_kernel<3><<<grid, 256, 0, st>>>(P, edge_vec, E, emb, sh); break;
+  }
+  SNET_CHECK_LAUNCH("snet_edge_embed_fwd");
+  return 0;
+}
+
+extern "C" int snet_edge_embed_bwd(const snet_edge_params *p, const float *coeffs, const float *edge_vec,
+                                   int64_t E, const float *g_emb, const float *g_sh, float *g_vec,
+                                   void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  EdgeP P;
+  if (int rc = prepare(p, coeffs, P)) return rc;
+  if (E <= 0) return 0;
+  const unsigned grid = (unsigned)((E + 255) / 256);
+  switch (P.lmax) {
+    case 0: edge_bwd_kernel<0><<<grid, 256, 0, st>>>(P, edge_vec, E, g_emb, g_sh, g_vec); break;
+    case 1: edge_bwd_kernel<1><<<grid, 256, 0, st>>>(P, edge_vec, E, g_emb, g_sh, g_vec); break;
+    case 2: edge_bwd_kernel<2><<<grid, 256, 0, st>>>(P, edge_vec, E, g_emb, g_sh, g_vec); break;
+    default: edge_bwd_kernel<3><<<grid, 256, 0, st>>>(P, edge_vec, E, g_emb, g_sh, g_vec); break;
+  }
+  SNET_CHECK_LAUNCH("snet_edge_embed_bwd");
+  return 0;
+}

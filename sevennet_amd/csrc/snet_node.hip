@@ -1,0 +1,265 @@
+// Node-level elementwise kernels of the SevenNet step
+// plus the radial-MLP activation.  All HBM-bound; features are `ir_mul` rows.
+#include "snet_common.h"
+
+namespace {
+
+struct GateTable {
+  int n;
+  int total_ch;  // sum of mul over all segments = lanes needed per node
+  snet_gate_seg seg[SNET_MAX_GATE_SEGS];
+  int ch0[SNET_MAX_GATE_SEGS];
+};
+
+// One lane per (node, segment channel u); a gated lane handles its 2l+1 components so the
+// gate scalar's gradient needs no cross-lane reduction.
+__global__ __launch_bounds__(256) void gate_fwd_kernel(GateTable T, const float *__restrict__ y,
+                                                       float *__restrict__ out, int64_t n_nodes, int dim_in,
+                                                       int dim_out) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t node = gid / T.total_ch;
+  if (node >= n_nodes) return;
+  const int c = (int)(gid - node * T.total_ch);
+  int s = 0;
+  while (s + 1 < T.n && c >= T.ch0[s + 1]) ++s;
+  const snet_gate_seg sg = T.seg[s];
+  const int u = c - T.ch0[s];
+  const float *yr = y + node * dim_in;
+  float *orow = out + node * dim_out;
+  if (sg.kind == 0) {
+    orow[sg.out_off + u] = snet::act_fwd(yr[sg.in_off + u], sg.act) * sg.cst;
+  } else {
+    const float g = snet::act_fwd(yr[sg.gate_off + u], sg.act) * sg.cst;
+    const int d = 2 * sg.l + 1;
+    for (int m = 0; m < d; ++m) orow[sg.out_off + m * sg.mul + u] = yr[sg.in_off + m * sg.mul + u] * g;
+  }
+}
+
+__global__ __launch_bounds__(256) void gate_bwd_kernel(GateTable T, const float *__restrict__ y,
+                                                       const float *__restrict__ g_out, float *__restrict__ g_y,
+                                                       int64_t n_nodes, int dim_in, int dim_out) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t node = gid / T.total_ch;
+  if (node >= n_nodes) return;
+  const int c = (int)(gid - node * T.total_ch);
+  int s = 0;
+  while (s + 1 < T.n && c >= T.ch0[s + 1]) ++s;
+  const snet_gate_seg sg = T.seg[s];
+  const int u = c - T.ch0[s];
+  const float *yr = y + node * dim_in;
+  const float *gor = g_out + node * dim_out;
+  float *gyr = g_y + node * dim_in;
+  if (sg.kind == 0) {
+    gyr[sg.in_off + u] = gor[sg.out_off + u] * sg.cst * snet::act_grad(yr[sg.in_off + u], sg.act);
+  } else {
+    const float z = yr[sg.gate_off + u];
+    const float g = snet::act_fwd(z, sg.act) * sg.cst;
+    const int d = 2 * sg.l + 1;
+    float acc = 0.f;
+    for (int m = 0; m < d; ++m) {
+      const float go = gor[sg.out_off + m * sg.mul + u];
+      acc += go * yr[sg.in_off + m * sg.mul + u];
+      gyr[sg.in_off + m * sg.mul + u] = go * g;
+    }
+    gyr[sg.gate_off + u] = acc * sg.cst * snet::act_grad(z, sg.act);
+  }
+}
+
+int build_gate_table(const snet_gate_seg *segs, int n, GateTable &T) {
+  SNET_REQUIRE(segs != nullptr && n >= 1 && n <= SNET_MAX_GATE_SEGS, "snet_gate: 1..16 segments required");
+  T.n = n;
+  int c = 0;
+  for (int i = 0; i < n; ++i) {
+    SNET_REQUIRE(segs[i].mul > 0 && segs[i].l >= 0 && (segs[i].kind == 0 || segs[i].kind == 1),
+                 "snet_gate: malformed segment");
+    T.seg[i] = segs[i];
+    T.ch0[i] = c;
+    c += segs[i].mul;
+  }
+  T.total_ch = c;
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ z, float *__restrict__ a, int64_t n,
+                                                      int act, float cst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    a[i] = snet::act_fwd(z[i], act) * cst;
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ z, const float *__restrict__ ga,
+                                                      float *__restrict__ gz, int64_t n, int act, float cst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    gz[i] = ga[i] * cst * snet::act_grad(z[i], act);
+}
+__global__ __launch_bounds__(256) void add_kernel(float *__restrict__ y, const float *__restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] += x[i];
+}
+
+// out[r, c] = x[idx_r(r), idx_c(c)] family ------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const float *__restrict__ table, const int32_t *__restrict__ types,
+                                                    float *__restrict__ out, int64_t n, int dim) {
+  const int64_t total = n * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / dim;
+    const int c = (int)(i - r * dim);
+    out[i] = table[(int64_t)types[r] * dim + c];
+  }
+}
+__global__ __launch_bounds__(256) void permute_cols_kernel(const float *__restrict__ x, const int32_t *__restrict__ ci,
+                                                           float *__restrict__ out, int64_t n, int dim) {
+  const int64_t total = n * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / dim;
+    const int c = (int)(i - r * dim);
+    out[i] = x[r * dim + ci[c]];
+  }
+}
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ x, const int32_t *__restrict__ idx,
+                                                          float *__restrict__ out, int64_t n, int dim) {
+  const int64_t total = n * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / dim;
+    const int c = (int)(i - r * dim);
+    out[i] = x[(int64_t)idx[r] * dim + c];
+  }
+}
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *__restrict__ x, const int32_t *__restrict__ idx,
+                                                               float *__restrict__ y, int64_t n, int dim) {
+  const int64_t total = n * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / dim;
+    const int c = (int)(i - r * dim);
+    y[(int64_t)idx[r] * dim + c] += x[i];
+  }
+}
+
+// e_atom = e*scale[t]+shift[t]; deterministic two-stage sum (double)
+constexpr int RED_BLOCKS = 256;
+__global__ __launch_bounds__(256) void rescale_partial_kernel(const float *__restrict__ e, const int32_t *__restrict__ types,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                                              int n_scale, int64_t n, float *__restrict__ e_atom,
+                                                              double *__restrict__ partial) {
+  __shared__ double sm[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = n_scale > 1 ? types[i] : 0;
+    const float v = e[i] * scale[t] + shift[t];
+    e_atom[i] = v;
+    acc += (double)v;
+  }
+  acc = snet::wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ __launch_bounds__(64) void final_sum_kernel(const double *__restrict__ partial, int n, int stride, int ncomp,
+                                                       double *__restrict__ out) {
+  // out[c] = sum_b partial[b*stride + c], fixed order
+  for (int c = 0; c < ncomp; ++c) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < n; b += 64) acc += partial[(int64_t)b * stride + c];
+    acc = snet::wave_sum_d(acc);
+    if (threadIdx.x == 0) out[c] = acc;
+  }
+}
+
+inline unsigned grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+namespace snet {
+double *reduce_scratch(int64_t n_doubles, hipStream_t st);  // snet_api.cpp
+void launch_final_sum(const double *partial, int n, int stride, int ncomp, double *out, hipStream_t st) {
+  final_sum_kernel<<<1, 64, 0, st>>>(partial, n, stride, ncomp, out);
+}
+}  // namespace snet
+
+extern "C" int snet_gate_fwd(const float *y, float *out, int64_t n_nodes, int32_t dim_in, int32_t dim_out,
+                             const snet_gate_seg *segs, int32_t n_segs, void *stream) {
+  GateTable T;
+  if (int rc = build_gate_table(segs, n_segs, T)) return rc;
+  if (n_nodes <= 0) return 0;
+  const int64_t total = n_nodes * T.total_ch;
+  gate_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(T, y, out, n_nodes,
+                                                                                                  dim_in, dim_out);
+  SNET_CHECK_LAUNCH("snet_gate_fwd");
+  return 0;
+}
+extern "C" int snet_gate_bwd(const float *y, const float *g_out, float *g_y, int64_t n_nodes, int32_t dim_in,
+                             int32_t dim_out, const snet_gate_seg *segs, int32_t n_segs, void *stream) {
+  GateTable T;
+  if (int rc = build_gate_table(segs, n_segs, T)) return rc;
+  if (n_nodes <= 0) return 0;
+  const int64_t total = n_nodes * T.total_ch;
+  gate_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      T, y, g_out, g_y, n_nodes, dim_in, dim_out);
+  SNET_CHECK_LAUNCH("snet_gate_bwd");
+  return 0;
+}
+extern "C" int snet_act_fwd(const float *z, float *a, int64_t n, int32_t act, float cst, void *stream) {
+  SNET_REQUIRE(act == 0 || act == 1, "snet_act_fwd: unknown activation");
+  if (n <= 0) return 0;
+  act_fwd_kernel<<<grid_for(n), 256, 0, static_cast<hipStream_t>(stream)>>>(z, a, n, act, cst);
+  SNET_CHECK_LAUNCH("snet_act_fwd");
+  return 0;
+}
+extern "C" int snet_act_bwd(const float *z, const float *g_a, float *g_z, int64_t n, int32_t act, float cst,
+                            void *stream) {
+  SNET_REQUIRE(act == 0 || act == 1, "snet_act_bwd: unknown activation");
+  if (n <= 0) return 0;
+  act_bwd_kernel<<<grid_for(n), 256, 0, static_cast<hipStream_t>(stream)>>>(z, g_a, g_z, n, act, cst);
+  SNET_CHECK_LAUNCH("snet_act_bwd");
+  return 0;
+}
+extern "C" int snet_add_inplace(float *y, const float *x, int64_t n, void *stream) {
+  if (n <= 0) return 0;
+  add_kernel<<<grid_for(n), 256, 0, static_cast<hipStream_t>(stream)>>>(y, x, n);
+  SNET_CHECK_LAUNCH("snet_add_inplace");
+  return 0;
+}
+extern "C" int snet_embed_rows(const float *table, const int32_t *types, float *out, int64_t n, int32_t dim,
+                               void *stream) {
+  if (n <= 0) return 0;
+  embed_kernel<<<grid_for(n * dim), 256, 0, static_cast<hipStream_t>(stream)>>>(table, types, out, n, dim);
+  SNET_CHECK_LAUNCH("snet_embed_rows");
+  return 0;
+}
+extern "C" int snet_permute_cols(const float *x, const int32_t *ci, float *out, int64_t n, int32_t dim,
+                                 void *stream) {
+  if (n <= 0) return 0;
+  permute_cols_kernel<<<grid_for(n * dim), 256, 0, static_cast<hipStream_t>(stream)>>>(x, ci, out, n, dim);
+  SNET_CHECK_LAUNCH("snet_permute_cols");
+  return 0;
+}
+extern "C" int snet_gather_rows(const float *x, const int32_t *idx, float *out, int64_t n, int32_t dim,
+                                void *stream) {
+  if (n <= 0) return 0;
+  gather_rows_kernel<<<grid_for(n * dim), 256, 0, static_cast<hipStream_t>(stream)>>>(x, idx, out, n, dim);
+  SNET_CHECK_LAUNCH("snet_gather_rows");
+  return 0;
+}
+extern "C" int snet_scatter_add_rows(const float *x, const int32_t *idx, float *y, int64_t n, int32_t dim,
+                                     void *stream) {
+  if (n <= 0) return 0;
+  scatter_add_rows_kernel<<<grid_for(n * dim), 256, 0, static_cast<hipStream_t>(stream)>>>(x, idx, y, n, dim);
+  SNET_CHECK_LAUNCH("snet_scatter_add_rows");
+  return 0;
+}
+extern "C" int snet_rescale_reduce(const float *e_scaled, const int32_t *types, const float *scale,
+                                   const float *shift, int32_t n_scale, int64_t n, float *e_atom, double *energy,
+                                   void *stream) {
+  SNET_REQUIRE(n_scale >= 1, "snet_rescale_reduce: n_scale >= 1 required");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double *partial = snet::reduce_scratch(RED_BLOCKS, st);
+  SNET_REQUIRE(partial != nullptr, "snet_rescale_reduce: scratch allocation failed");
+  rescale_partial_kernel<<<RED_BLOCKS, 256, 0, st>>>(e_scaled, types, scale, shift, n_scale, n < 0 ? 0 : n, e_atom,
+                                                     partial);
+  snet::launch_final_sum(partial, RED_BLOCKS, 1, 1, energy, st);
+  SNET_CHECK_LAUNCH("snet_rescale_reduce");
+  return 0;
+}

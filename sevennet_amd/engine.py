@@ -1,0 +1,373 @@
+"""SevenNet energy/force evaluation on MI355X: host-side sequencer over libsnet_hip.so.
+
+One `HipForceEngine.compute()` = one MD-step evaluation:
+forward through edge embedding, L interaction blocks and the readout, then a
+hand-scheduled analytic reverse pass that yields dE/d(edge_vec), forces and
+virial -- no torch autograd anywhere in the step.  PyTorch is used only for
+device memory, streams and (multi-GPU) torch.distributed.
+
+Mirrors, op for op, what the reference executes in
+  AtomGraphSequential.forward            sevenn/nn/sequential.py:179-183
+  NequIP_interaction_block (op order)    sevenn/nn/interaction_blocks.py:41-76
+  ForceStressOutputFromEdge.forward      sevenn/nn/force_output.py:171-230
+and, with a `halo` object, the per-layer ghost exchange of
+  PairE3GNNParallel::compute             sevenn/pair_e3gnn/pair_e3gnn_parallel.cpp:358-441
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model_spec import (ACT_CST, ACT_ID, LinearSpec, ModelSpec, build_model_spec,
+                         linear_weight_matrices)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# --------------------------------------------------------------------------- #
+@dataclass
+class Graph:
+    """Device-resident edge list in the layout the kernels consume.
+
+    Edges are sorted by center atom (CSR `row_ptr` over all n_total rows; ghost
+    rows have empty segments).  `eperm`/`col_ptr` group edge ids by neighbor
+    (source) atom for the deterministic reverse gathers."""
+    n_total: int
+    n_local: int
+    n_edges: int
+    types: torch.Tensor      # int32 [n_total]
+    center: torch.Tensor     # int32 [E]  (edge_index[0], sorted)
+    src: torch.Tensor        # int32 [E]  (edge_index[1])
+    row_ptr: torch.Tensor    # int32 [n_total+1]
+    col_ptr: torch.Tensor    # int32 [n_total+1]
+    eperm: torch.Tensor      # int32 [E]
+    edge_vec: torch.Tensor   # float32 [E,3]
+    order: Optional[torch.Tensor] = None  # permutation applied to the caller's edge order (None = already sorted)
+    species_rows: Optional[List[torch.Tensor]] = None  # per species: int32 local row ids (FCTP self-connection)
+
+
+def build_graph(types, edge_index, edge_vec, n_local: Optional[int] = None, device='cuda',
+                num_species: int = 0) -> Graph:
+    """types[n_total] (species index), edge_index[2,E] (row 0 = center / destination,
+    row 1 = neighbor / source; pair_e3gnn.cpp:192-197 convention), edge_vec[E,3]."""
+    dev = torch.device(device)
+    types = torch.as_tensor(types).to(dev, torch.int32)
+    ei = torch.as_tensor(edge_index).to(dev, torch.int64)
+    ev = torch.as_tensor(edge_vec).to(dev, torch.float32)
+    n_total = int(types.shape[0])
+    n_local = n_total if n_local is None else int(n_local)
+    E = int(ei.shape[1])
+    order = None
+    if E > 1 and bool((ei[0, 1:] < ei[0, :-1]).any()):
+        order = torch.sort(ei[0], stable=True).indices
+        ei = ei[:, order]
+        ev = ev[order]
+    center, src = ei[0], ei[1]
+    if E and (int(center.max()) >= n_local):
+        raise ValueError('edge centers must be owned (local) atoms')
+    row_ptr = torch.zeros(n_total + 1, dtype=torch.int64, device=dev)
+    col_ptr = torch.zeros(n_total + 1, dtype=torch.int64, device=dev)
+    if E:
+        row_ptr[1:] = torch.cumsum(torch.bincount(center, minlength=n_total), 0)
+        col_ptr[1:] = torch.cumsum(torch.bincount(src, minlength=n_total), 0)
+        eperm = torch.sort(src, stable=True).indices
+    else:
+        eperm = torch.zeros(0, dtype=torch.int64, device=dev)
+    rows = None
+    if num_species:
+        rows = [torch.nonzero(types[:n_local] == s).reshape(-1).to(torch.int32) for s in range(num_species)]
+    return Graph(n_total, n_local, E, types, center.to(torch.int32).contiguous(), src.to(torch.int32).contiguous(),
+                 row_ptr.to(torch.int32), col_ptr.to(torch.int32), eperm.to(torch.int32).contiguous(),
+                 ev.contiguous(), order, rows)
+
+
+# --------------------------------------------------------------------------- #
+class _Linear:
+    """Device weights of one LinearSpec (per-GEMM [K,N] and [N,K] copies)."""
+
+    def __init__(self, spec: LinearSpec, flat: np.ndarray, dev):
+        self.spec = spec
+        mats = linear_weight_matrices(spec, flat)
+        self.w = [torch.from_numpy(m).to(dev) for m in mats]
+        self.wt = [torch.from_numpy(np.ascontiguousarray(m.T)).to(dev) for m in mats]
+
+
+class HipForceEngine:
+    def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0'):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError('HipForceEngine needs a ROCm GPU (no CPU fallback exists)')
+        self.dev = torch.device(device)
+        self.spec: ModelSpec = build_model_spec(config)
+        sp = self.spec
+        shapes = sp.param_shapes()
+        sd = {}
+        for k, shp in shapes.items():
+            if k not in state_dict:
+                raise KeyError(f'state_dict is missing {k}')
+            v = state_dict[k]
+            v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            sd[k] = v.astype(np.float64).reshape(shp)
+
+        self.edge_params = _lib.EdgeParams(sp.cutoff, sp.n_basis, sp.cutoff_kind, sp.cutoff_p, sp.cutoff_on,
+                                           sp.lmax_edge, int(sp.normalize_sph))
+        self.coeffs = (C.c_float * sp.n_basis)(*[float(v) for v in sd['edge_embedding.basis_function.coeffs']])
+        self.nsh = sp.irreps_sh.dim
+        with torch.cuda.device(self.dev):
+            emb = linear_weight_matrices(sp.embed, sd[sp.embed.name])
+            assert len(emb) == 1
+            self.embed_table = torch.from_numpy(emb[0]).to(self.dev)  # [n_species, dim0]
+            self.layers = []
+            for ls in sp.layers:
+                L = type('L', (), {})()
+                L.spec = ls
+                L.sc = _Linear(ls.sc, sd[ls.sc.name], self.dev) if ls.sc is not None else None
+                L.si1 = _Linear(ls.si1, sd[ls.si1.name], self.dev)
+                L.si2 = _Linear(ls.si2, sd[ls.si2.name], self.dev)
+                L.mlp_w, L.mlp_wt = [], []
+                for i in range(len(ls.mlp_dims) - 1):
+                    w = sd[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] / np.sqrt(ls.mlp_dims[i])
+                    L.mlp_w.append(torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(self.dev))
+                    L.mlp_wt.append(torch.from_numpy(np.ascontiguousarray(w.T, dtype=np.float32)).to(self.dev))
+                L.scale = 1.0 / float(sd[f'{ls.t}_convolution.denominator'][0])
+                plan = C.c_void_p()
+                _lib.check(self.lib.snet_conv_plan_create(ls.conv.tag.encode(), C.byref(plan)), 'snet_conv_plan_create')
+                L.plan = plan
+                segs = (_lib.GateSeg * len(ls.gate.segs))()
+                inv_act = {v: k for k, v in ACT_ID.items()}
+                for i, s in enumerate(ls.gate.segs):
+                    segs[i] = _lib.GateSeg(s.kind, s.in_off, s.out_off, s.mul, s.l, s.gate_off, s.act,
+                                           ACT_CST[inv_act[s.act]])
+                L.gate_segs = segs
+                self.layers.append(L)
+            self.ro1 = _Linear(sp.readout1, sd[sp.readout1.name], self.dev)
+            self.ro2 = _Linear(sp.readout2, sd[sp.readout2.name], self.dev)
+            n_sc = shapes['rescale_atomic_energy.scale'][0]
+            self.n_scale = n_sc
+            self.scale = torch.tensor(sd['rescale_atomic_energy.scale'], dtype=torch.float32, device=self.dev)
+            self.shift = torch.tensor(sd['rescale_atomic_energy.shift'], dtype=torch.float32, device=self.dev)
+            self.scale0 = float(sd['rescale_atomic_energy.scale'][0])
+        self.act_radial = ACT_ID[sp.act_radial]
+        self.act_cst = ACT_CST[sp.act_radial]
+        self.needs_species_rows = any(ls.sc is not None and ls.sc.n_species for ls in sp.layers)
+
+    def __del__(self):
+        try:
+            for L in getattr(self, 'layers', []):
+                self.lib.snet_conv_plan_destroy(L.plan)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ ops
+    def _new(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.dev)
+
+    def _gemm(self, A, B, Cm, n_nodes, d, K, N, a_stride, a_off, c_stride, c_off, rows=None, acc=False):
+        _lib.check(self.lib.snet_gemm(_ptr(A), _ptr(B), _ptr(Cm), n_nodes, d, K, N, a_stride, a_off, c_stride,
+                                      c_off, _ptr(rows), int(acc), _stream()), 'snet_gemm')
+
+    def _linear(self, lin: _Linear, x, n, g: Graph, out=None):
+        """y[:n] = Linear(x[:n]) on ir_mul rows."""
+        sp = lin.spec
+        y = self._new(max(n, 0), sp.dim_out) if out is None else out
+        for off, ln in sp.zero_out:
+            y[:, off:off + ln].zero_()
+        for b, w in zip(sp.blocks, lin.w):
+            if b.species >= 0:
+                rows = g.species_rows[b.species]
+                if rows.numel() == 0:
+                    continue
+                # a species' rows only ever see that species' matrix: the first species writes,
+                # accumulation across in-blocks follows b.accumulate
+                self._gemm(x, w, y, rows.numel(), 2 * b.l + 1, b.mul_in, b.mul_out, sp.dim_in, b.in_off,
+                           sp.dim_out, b.out_off, rows, b.accumulate)
+            else:
+                self._gemm(x, w, y, n, 2 * b.l + 1, b.mul_in, b.mul_out, sp.dim_in, b.in_off, sp.dim_out,
+                           b.out_off, None, b.accumulate)
+        return y
+
+    def _linear_T(self, lin: _Linear, gy, n, g: Graph, out=None, accumulate=False):
+        """g_x[:n] (+)= Linear^T(g_y[:n]).  The first (in,out) pair that reaches an input block
+        overwrites it, later pairs accumulate; the species slices of one pair hit disjoint rows."""
+        sp = lin.spec
+        gx = out if out is not None else self._new(max(n, 0), sp.dim_in)
+        if not accumulate:
+            fed = {b.in_off for b in sp.blocks}
+            for off, (m, l, _) in zip(sp.irreps_in.offsets(), sp.irreps_in):
+                if off not in fed:
+                    gx[:, off:off + m * (2 * l + 1)].zero_()
+        done_in, cur_pair = set(), None
+        for b, wt in zip(sp.blocks, lin.wt):
+            pair = (b.in_off, b.out_off)
+            if pair != cur_pair:
+                if cur_pair is not None:
+                    done_in.add(cur_pair[0])
+                cur_pair = pair
+            acc = accumulate or (b.in_off in done_in)
+            rows, cnt = None, n
+            if b.species >= 0:
+                rows = g.species_rows[b.species]
+                cnt = rows.numel()
+                if cnt == 0:
+                    continue
+            self._gemm(gy, wt, gx, cnt, 2 * b.l + 1, b.mul_out, b.mul_in, sp.dim_out, b.out_off, sp.dim_in,
+                       b.in_off, rows, acc)
+        return gx
+
+    def _mlp_fwd(self, L, emb, E):
+        dims = L.spec.mlp_dims
+        zs, a = [], emb
+        for i, w in enumerate(L.mlp_w):
+            z = self._new(E, dims[i + 1])
+            self._gemm(a, w, z, E, 1, dims[i], dims[i + 1], dims[i], 0, dims[i + 1], 0)
+            if i + 1 < len(L.mlp_w):
+                zs.append(z)
+                a = self._new(E, dims[i + 1])
+                _lib.check(self.lib.snet_act_fwd(_ptr(z), _ptr(a), z.numel(), self.act_radial, self.act_cst,
+                                                 _stream()), 'snet_act_fwd')
+                zs.append(a)
+            else:
+                return z, zs  # zs = [z1, a1, z2, a2, ...]
+
+    def _mlp_bwd(self, L, emb, zs, g_w, g_emb_total, E):
+        dims = L.spec.mlp_dims
+        g = g_w
+        nl = len(L.mlp_w)
+        for i in range(nl - 1, -1, -1):
+            if i == 0:
+                # accumulate straight into the all-layer edge-embedding gradient
+                self._gemm(g, L.mlp_wt[0], g_emb_total, E, 1, dims[1], dims[0], dims[1], 0, dims[0], 0, None, True)
+            else:
+                ga = self._new(E, dims[i])
+                self._gemm(g, L.mlp_wt[i], ga, E, 1, dims[i + 1], dims[i], dims[i + 1], 0, dims[i], 0)
+                z = zs[2 * (i - 1)]
+                gz = ga  # in place
+                _lib.check(self.lib.snet_act_bwd(_ptr(z), _ptr(ga), _ptr(gz), z.numel(), self.act_radial,
+                                                 self.act_cst, _stream()), 'snet_act_bwd')
+                g = gz
+
+    # -------------------------------------------------------------- compute
+    def compute(self, g: Graph, halo=None, want_atomic_virial: bool = False, keep: bool = False):
+        """Energy, per-atom energies, dE/d(edge_vec), forces and virial for one graph.
+
+        halo: object with forward(x[n_total,dim], n_local) filling ghost rows from their owners
+        and reverse(gx[n_total,dim], n_local) accumulating ghost-row gradients into the owners
+        (sevennet_amd.parallel.HaloExchange); None for a single-process graph."""
+        lib, sp = self.lib, self.spec
+        if self.needs_species_rows and g.species_rows is None:
+            raise ValueError('graph was built without num_species but the model has a per-species self-connection')
+        with torch.cuda.device(self.dev):
+            st = _stream()
+            N, NT, E = g.n_local, g.n_total, g.n_edges
+            nb, nsh = sp.n_basis, self.nsh
+            inter = {}
+            emb, sh = self._new(E, nb), self._new(E, nsh)
+            _lib.check(lib.snet_edge_embed_fwd(C.byref(self.edge_params), self.coeffs, _ptr(g.edge_vec), E,
+                                               _ptr(emb), _ptr(sh), st), 'snet_edge_embed_fwd')
+            d0 = sp.embed.dim_out
+            x = self._new(NT, d0)  # ghost layer-0 features depend only on species (model_build.py:383-421)
+            _lib.check(lib.snet_embed_rows(_ptr(self.embed_table), _ptr(g.types), _ptr(x), NT, d0, st),
+                       'snet_embed_rows')
+            if keep:
+                inter['edge_embedding'], inter['edge_attr'], inter['x_embed'] = emb, sh, x[:N]
+            saved = []
+            for t, L in enumerate(self.layers):
+                ls = L.spec
+                n_in = NT if t == 0 else N  # rows of x that are valid
+                sc = self._linear(L.sc, x, N, g) if L.sc is not None else None
+                h = self._new(NT, ls.si1.dim_out)
+                self._linear(L.si1, x, n_in, g, out=h)
+                if t > 0 and halo is not None:
+                    halo.forward(h, N)
+                w, zs = self._mlp_fwd(L, emb, E)
+                dmid = ls.conv.irreps_out.dim
+                m = self._new(N, dmid)
+                if E == 0:
+                    m.zero_()
+                _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N,
+                                             L.scale, _ptr(m), st), 'snet_conv_fwd')
+                y = self._linear(L.si2, m, N, g)
+                if sc is not None:
+                    _lib.check(lib.snet_add_inplace(_ptr(y), _ptr(sc), y.numel(), st), 'snet_add_inplace')
+                xo = self._new(N, ls.gate.irreps_out.dim)
+                _lib.check(lib.snet_gate_fwd(_ptr(y), _ptr(xo), N, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim,
+                                             L.gate_segs, len(ls.gate.segs), st), 'snet_gate_fwd')
+                saved.append((h, w, zs, y))
+                if keep:
+                    inter[f'{t}_si1'], inter[f'{t}_conv'], inter[f'{t}_gate_in'], inter[f'{t}_x'] = h[:N], m, y, xo
+                x = xo
+            h1 = self._linear(self.ro1, x, N, g)
+            e_sc = self._linear(self.ro2, h1, N, g)
+            e_atom = self._new(N)
+            energy = torch.empty(1, dtype=torch.float64, device=self.dev)
+            _lib.check(lib.snet_rescale_reduce(_ptr(e_sc), _ptr(g.types), _ptr(self.scale), _ptr(self.shift),
+                                               self.n_scale, N, _ptr(e_atom), _ptr(energy), st), 'snet_rescale_reduce')
+
+            # ---------------- reverse pass: dE/d(e_scaled) = scale[type]
+            g_e = self._new(N, 1)
+            if self.n_scale > 1:
+                _lib.check(lib.snet_embed_rows(_ptr(self.scale), _ptr(g.types), _ptr(g_e), N, 1, st), 'snet_embed_rows')
+            else:
+                g_e.fill_(self.scale0)
+            g_h1 = self._linear_T(self.ro2, g_e, N, g)
+            g_x = self._linear_T(self.ro1, g_h1, N, g)
+            g_sh = torch.zeros(E, nsh, dtype=torch.float32, device=self.dev)
+            g_emb = torch.zeros(E, nb, dtype=torch.float32, device=self.dev)
+            for t in range(len(self.layers) - 1, -1, -1):
+                L = self.layers[t]
+                ls = L.spec
+                h, w, zs, y = saved[t]
+                g_y = self._new(N, ls.gate.irreps_in.dim)
+                _lib.check(lib.snet_gate_bwd(_ptr(y), _ptr(g_x), _ptr(g_y), N, ls.gate.irreps_in.dim,
+                                             ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st), 'snet_gate_bwd')
+                g_m = self._linear_T(L.si2, g_y, N, g)
+                g_w = self._new(E, ls.conv.weight_numel)
+                _lib.check(lib.snet_conv_bwd_edge(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N,
+                                                  L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_sh), st), 'snet_conv_bwd_edge')
+                self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
+                del g_w
+                if t == 0:
+                    break  # layer-0 inputs depend on species only: nothing upstream needs a gradient
+                g_h = self._new(NT, ls.si1.dim_out)
+                _lib.check(lib.snet_conv_bwd_node(L.plan, _ptr(sh), _ptr(w), _ptr(g.col_ptr), _ptr(g.eperm),
+                                                  _ptr(g.center), NT, L.scale, _ptr(g_m), _ptr(g_h), st), 'snet_conv_bwd_node')
+                if halo is not None:
+                    halo.reverse(g_h, N)
+                g_x = self._linear_T(L.si1, g_h, N, g)
+                if L.sc is not None:
+                    self._linear_T(L.sc, g_y, N, g, out=g_x, accumulate=True)
+                saved[t] = None
+            g_vec = self._new(E, 3)
+            _lib.check(lib.snet_edge_embed_bwd(C.byref(self.edge_params), self.coeffs, _ptr(g.edge_vec), E, _ptr(g_emb),
+                                               _ptr(g_sh), _ptr(g_vec), st), 'snet_edge_embed_bwd')
+            forces = self._new(NT, 3)
+            vir_atom = self._new(NT, 6) if want_atomic_virial else None
+            virial = torch.empty(6, dtype=torch.float64, device=self.dev)
+            _lib.check(lib.snet_edge_force(_ptr(g_vec), _ptr(g.edge_vec), _ptr(g.row_ptr), _ptr(g.col_ptr),
+                                           _ptr(g.eperm), NT, E, _ptr(forces), _ptr(vir_atom), _ptr(virial), st),
+                       'snet_edge_force')
+            if halo is not None:
+                halo.reverse(forces, N)  # fold ghost-atom force contributions into their owners
+                if vir_atom is not None:
+                    halo.reverse(vir_atom, N)
+            if g.order is not None:  # report dE/dr in the caller's edge order
+                tmp = torch.empty_like(g_vec)
+                tmp[g.order] = g_vec
+                g_vec = tmp
+            out = dict(energy=energy, atomic_energy=e_atom, dE_dr=g_vec, forces=forces[:N], virial=virial)
+            if vir_atom is not None:
+                out['atomic_virial'] = vir_atom[:N]
+            if keep:
+                out['inter'] = inter
+            return out

@@ -1,0 +1,393 @@
+"""Model description for the HIP force engine: reference config -> op specs.
+
+Reproduces the layer/irreps structure the reference builds in
+sevenn/model_build.py:448-636 and sevenn/nn/interaction_blocks.py:41-76, but
+expressed as flat tables for GPU kernels operating on the engine's `ir_mul`
+feature layout:
+
+  * LinearSpec   -- o3.Linear / per-species FCTP as a list of per-irrep GEMMs
+                    (sevenn/nn/linear.py:94-100, self_connection.py:11-114)
+  * ConvSpec     -- 'uvu' tensor-product paths, weight-column offsets, merged
+                    output blocks (sevenn/nn/convolution.py:61-82)
+  * GateSpec     -- scalar / gate / gated segments of e3nn Gate
+                    (sevenn/nn/equivariant_gate.py:26-49)
+
+Parameter names are the reference checkpoint's state_dict keys so that
+`checkpoint['model_state_dict']` can be fed to the engine unchanged.
+"""
+from __future__ import annotations
+
+import hashlib
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .irreps import Irreps, infer_irreps_out
+
+ACT_ID = {'silu': 0, 'tanh': 1}
+# e3nn normalize2mom constants as baked into the reference's deployed models
+ACT_CST = {'silu': 1.6791767923989418, 'tanh': 1.5937334472592695}
+
+DEFAULT_CONFIG = dict(  # sevenn/_const.py:95-135
+    cutoff=4.5, channel=32, irreps_manual=False, lmax=1, lmax_edge=-1, lmax_node=-1,
+    is_parity=True, num_convolution_layer=3,
+    radial_basis={'radial_basis_name': 'bessel'},
+    cutoff_function={'cutoff_function_name': 'poly_cut'},
+    act_radial='silu', act_scalar={'e': 'silu', 'o': 'tanh'}, act_gate={'e': 'silu', 'o': 'tanh'},
+    weight_nn_hidden_neurons=[64, 64], conv_denominator=1.0, self_connection_type='nequip',
+    _normalize_sph=True, shift=0.0, scale=1.0, version='0.12.0', use_bias_in_linear=False,
+)
+
+
+# --------------------------------------------------------------------------- #
+@dataclass
+class GemmBlock:
+    l: int            # rows per node = 2l+1
+    in_off: int
+    mul_in: int       # K
+    out_off: int
+    mul_out: int      # N
+    w_off: int        # offset into the e3nn flat weight
+    alpha: float
+    accumulate: bool  # C += (another in-block already wrote this out-block)
+    species: int = -1  # FCTP: which species' slice (w[u, species, w])
+
+
+@dataclass
+class LinearSpec:
+    name: str                  # state_dict key of the flat weight
+    irreps_in: Irreps
+    irreps_out: Irreps
+    blocks: List[GemmBlock]
+    zero_out: List[Tuple[int, int]]  # (offset, length) of output blocks nobody writes
+    n_species: int = 0         # >0: FullyConnectedTensorProduct with a one-hot operand
+    numel: int = 0
+
+    @property
+    def dim_in(self):
+        return self.irreps_in.dim
+
+    @property
+    def dim_out(self):
+        return self.irreps_out.dim
+
+
+def make_linear(name: str, irreps_in: Irreps, irreps_out: Irreps, n_species: int = 0) -> LinearSpec:
+    """o3.Linear (n_species=0) or FCTP(x, n_species x 0e) -> per-irrep GEMM list.
+    Normalisation: 1/sqrt(total fan-in of the output block)."""
+    ns = max(n_species, 1)
+    in_off, out_off = irreps_in.offsets(), irreps_out.offsets()
+    pairs = [(i, j) for i, (_, li, pi) in enumerate(irreps_in)
+             for j, (_, lj, pj) in enumerate(irreps_out) if (li, pi) == (lj, pj)]
+    fan = [0] * len(irreps_out)
+    for i, j in pairs:
+        fan[j] += irreps_in[i][0] * ns
+    blocks, seen, w_off = [], set(), 0
+    for i, j in pairs:
+        mi, l, _ = irreps_in[i]
+        mo = irreps_out[j][0]
+        for s in range(ns):
+            blocks.append(GemmBlock(l, in_off[i], mi, out_off[j], mo, w_off, 1.0 / math.sqrt(fan[j]),
+                                    accumulate=(j in seen), species=(s if n_species else -1)))
+        seen.add(j)
+        w_off += mi * ns * mo
+    zero = [(out_off[j], irreps_out[j][0] * (2 * irreps_out[j][1] + 1))
+            for j in range(len(irreps_out)) if j not in seen]
+    return LinearSpec(name, irreps_in, irreps_out, blocks, zero, n_species, w_off)
+
+
+def linear_weight_matrices(spec: LinearSpec, flat: np.ndarray):
+    """Split the e3nn flat weight into per-GEMM [K, N] matrices with alpha folded."""
+    flat = np.asarray(flat, dtype=np.float64).reshape(-1)
+    assert flat.size == spec.numel, (spec.name, flat.size, spec.numel)
+    ns = max(spec.n_species, 1)
+    out = []
+    for b in spec.blocks:
+        w = flat[b.w_off:b.w_off + b.mul_in * ns * b.mul_out]
+        if spec.n_species:
+            w = w.reshape(b.mul_in, ns, b.mul_out)[:, b.species, :]
+        else:
+            w = w.reshape(b.mul_in, b.mul_out)
+        out.append(np.ascontiguousarray(w * b.alpha, dtype=np.float32))
+    return out
+
+
+# --------------------------------------------------------------------------- #
+@dataclass
+class ConvPath:
+    i_x: int
+    i_sh: int
+    l1: int
+    l2: int
+    l3: int
+    mul: int
+    w_off: int        # column offset in the per-edge weight row
+    x_off: int        # offset of the x block (ir_mul)
+    sh_off: int
+    out_off: int      # offset of the *merged* output block
+    out_mul: int      # multiplicity of the merged output block
+    out_ch: int       # channel offset of this path inside the merged block
+
+
+@dataclass
+class ConvSpec:
+    irreps_x: Irreps
+    irreps_sh: Irreps
+    irreps_mid: Irreps        # sorted, one block per path (reference layout)
+    irreps_out: Irreps        # merged (simplified) -- the engine's output layout
+    paths: List[ConvPath]
+    weight_numel: int
+
+    @property
+    def key(self) -> str:
+        ps = ';'.join(f'{p.i_x},{p.i_sh},{p.l3},{p.w_off},{p.out_off},{p.out_mul},{p.out_ch}' for p in self.paths)
+        return f'x={self.irreps_x}|sh={self.irreps_sh}|{ps}'
+
+    @property
+    def tag(self) -> str:
+        return hashlib.sha1(self.key.encode()).hexdigest()[:12]
+
+
+def make_conv(irreps_x: Irreps, irreps_sh: Irreps, irreps_target: Irreps, sort_by_out: bool) -> ConvSpec:
+    """Instruction generation of sevenn/nn/convolution.py:61-82.  Weight columns
+    follow the (possibly re-sorted) instruction order, `mul_x` per instruction;
+    the output is `irreps_mid.sort()` which in memory equals its simplified form."""
+    ins, mid = [], []
+    for i, (mul, l1, p1) in enumerate(irreps_x):
+        for j, (_, l2, p2) in enumerate(irreps_sh):
+            for l3 in range(abs(l1 - l2), l1 + l2 + 1):
+                if irreps_target.has(l3, p1 * p2):
+                    ins.append((i, j, len(mid)))
+                    mid.append((mul, l3, p1 * p2))
+    mid_sorted, perm = Irreps(mid).sorted()
+    ins = [(i, j, perm[k]) for i, j, k in ins]
+    if sort_by_out:
+        ins = sorted(ins, key=lambda t: t[2])
+    merged = mid_sorted.simplified()
+    m_off = merged.offsets()
+    # position of each sorted mid block inside the merged blocks
+    where, cur, ch = [], -1, 0
+    for (mul, l, p) in mid_sorted:
+        if cur < 0 or (merged[cur][1], merged[cur][2]) != (l, p) or ch + mul > merged[cur][0]:
+            cur += 1
+            ch = 0
+        where.append((cur, ch))
+        ch += mul
+    x_off, sh_off = irreps_x.offsets(), irreps_sh.offsets()
+    paths, w_off = [], 0
+    for i, j, k in ins:
+        mul, l1, _ = irreps_x[i]
+        blk, ch = where[k]
+        paths.append(ConvPath(i, j, l1, irreps_sh[j][1], mid_sorted[k][1], mul, w_off, x_off[i], sh_off[j],
+                              m_off[blk], merged[blk][0], ch))
+        w_off += mul
+    return ConvSpec(irreps_x, irreps_sh, mid_sorted, merged, paths, w_off)
+
+
+# --------------------------------------------------------------------------- #
+@dataclass
+class GateSeg:
+    kind: int        # 0 scalar, 1 gated
+    in_off: int
+    out_off: int
+    mul: int
+    l: int
+    gate_off: int    # offset of this segment's gate scalars in the input (-1 for scalars)
+    act: int
+
+
+@dataclass
+class GateSpec:
+    irreps_in: Irreps
+    irreps_out: Irreps
+    segs: List[GateSeg]
+
+
+def make_gate(irreps_x: Irreps, act_scalar: Dict[str, str], act_gate: Dict[str, str]) -> GateSpec:
+    """e3nn Gate input layout = sort(scalars + gates + gated).simplify()
+    (SURVEY.md §9): [l=0 odd scalars | l=0 even scalars | gates | gated...]."""
+    pm = {1: 'e', -1: 'o'}
+    scalars = [(m, l, p) for m, l, p in irreps_x if l == 0]
+    gated = [(m, l, p) for m, l, p in irreps_x if l > 0]
+    gp = 1 if any(p == 1 for _, _, p in scalars) else -1
+    gates = [(m, 0, gp) for m, _, _ in gated]
+    cat = Irreps(scalars + gates + gated)
+    srt, perm = cat.sorted()
+    starts = srt.offsets()
+    irreps_in = srt.simplified()
+    out_irreps = Irreps(scalars + gated)
+    out_off = out_irreps.offsets()
+    segs = []
+    ns, ng = len(scalars), len(gates)
+    for b, (m, l, p) in enumerate(scalars):
+        segs.append(GateSeg(0, starts[perm[b]], out_off[b], m, 0, -1, ACT_ID[act_scalar[pm[p]]]))
+    for b, (m, l, p) in enumerate(gated):
+        segs.append(GateSeg(1, starts[perm[ns + ng + b]], out_off[ns + b], m, l,
+                            starts[perm[ns + b]], ACT_ID[act_gate[pm[gp]]]))
+    return GateSpec(irreps_in, out_irreps, segs)
+
+
+# --------------------------------------------------------------------------- #
+@dataclass
+class LayerSpec:
+    t: int
+    irreps_x: Irreps
+    irreps_out: Irreps
+    sc: Optional[LinearSpec]
+    si1: LinearSpec
+    conv: ConvSpec
+    mlp_dims: List[int]
+    si2: LinearSpec
+    gate: GateSpec
+    denominator: float
+
+
+@dataclass
+class ModelSpec:
+    config: dict
+    cutoff: float
+    num_species: int
+    lmax_edge: int
+    normalize_sph: bool
+    irreps_sh: Irreps
+    n_basis: int
+    cutoff_kind: int       # 0 poly_cut, 1 XPLOR
+    cutoff_p: int
+    cutoff_on: float
+    act_radial: str
+    embed: LinearSpec
+    layers: List[LayerSpec]
+    readout1: LinearSpec
+    readout2: LinearSpec
+    type_map: Dict[int, int] = field(default_factory=dict)
+
+    def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        s: Dict[str, Tuple[int, ...]] = {}
+        s['edge_embedding.basis_function.coeffs'] = (self.n_basis,)
+        s[self.embed.name] = (self.embed.numel,)
+        for ls in self.layers:
+            if ls.sc is not None:
+                s[ls.sc.name] = (ls.sc.numel,)
+            s[ls.si1.name] = (ls.si1.numel,)
+            s[f'{ls.t}_convolution.denominator'] = (1,)
+            for i in range(len(ls.mlp_dims) - 1):
+                s[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] = (ls.mlp_dims[i], ls.mlp_dims[i + 1])
+            s[ls.si2.name] = (ls.si2.numel,)
+        s[self.readout1.name] = (self.readout1.numel,)
+        s[self.readout2.name] = (self.readout2.numel,)
+        n = max(np.asarray(self.config['shift']).size, np.asarray(self.config['scale']).size)
+        s['rescale_atomic_energy.shift'] = (n,)
+        s['rescale_atomic_energy.scale'] = (n,)
+        return s
+
+    def num_weights(self) -> int:
+        return sum(int(np.prod(v)) for k, v in self.param_shapes().items()
+                   if not (k.endswith('denominator') or k.startswith('rescale')))
+
+
+def _vt(v: str):
+    return tuple(int(t) for t in str(v).split('.')[:3] if t.isdigit())
+
+
+def build_model_spec(config: dict) -> ModelSpec:
+    cfg = dict(DEFAULT_CONFIG)
+    cfg.update(config)
+    if cfg.get('use_bias_in_linear'):
+        raise NotImplementedError('use_bias_in_linear=True is not supported by the HIP engine')
+    if cfg.get('use_modality') or cfg.get('readout_as_fcn'):
+        raise NotImplementedError('modal / readout_as_fcn models are not supported by the HIP engine yet')
+    ns = int(cfg.get('_number_of_species') or cfg.get('num_species') or len(cfg['chemical_species']))
+    ch = int(cfg['channel'])
+    L = int(cfg['num_convolution_layer'])
+    lmax_edge = cfg['lmax_edge'] if cfg['lmax_edge'] > 0 else cfg['lmax']
+    lmax_node = cfg['lmax_node'] if cfg['lmax_node'] > 0 else cfg['lmax']
+    irreps_sh = Irreps.spherical_harmonics(lmax_edge, -1 if cfg['is_parity'] else 1)
+    legacy = bool(cfg.get('_legacy_v08', False))
+    sort_by_out = _vt(cfg['version']) >= (0, 11, 0)
+    manual = cfg['irreps_manual']
+    if manual is not False:
+        manual = [Irreps(s) for s in manual]
+        if len(manual) != L + 1:
+            raise RuntimeError('invalid irreps_manual input given')
+    sc_types = cfg['self_connection_type']
+    if isinstance(sc_types, str):
+        sc_types = [sc_types] * L
+    denom = cfg['conv_denominator']
+    if not isinstance(denom, (list, tuple)):
+        denom = [denom] * L
+    cf = cfg['cutoff_function']
+    ckind = {'poly_cut': 0, 'XPLOR': 1}[cf['cutoff_function_name']]
+    n_basis = int(cfg['radial_basis'].get('bessel_basis_num', 8))
+    hidden = list(cfg['weight_nn_hidden_neurons'])
+
+    irreps_x = Irreps(f'{ch}x0e') if manual is False else manual[0]
+    embed = make_linear('onehot_to_feature_x.linear.weight', Irreps(f'{ns}x0e'), irreps_x)
+    layers = []
+    for t in range(L):
+        parity_mode = 'full'
+        if t == L - 1 and not legacy:
+            lmax_node, parity_mode = 0, 'even'
+        irreps_out = (infer_irreps_out(irreps_x, irreps_sh, lmax_node, parity_mode, ch)
+                      if manual is False else manual[t + 1])
+        irreps_out_tp = infer_irreps_out(irreps_x, irreps_sh, irreps_out.lmax, parity_mode, False)
+        gate = make_gate(irreps_out, cfg['act_scalar'], cfg['act_gate'])
+        conv = make_conv(irreps_x, irreps_sh, irreps_out_tp, sort_by_out)
+        assert conv.irreps_out == irreps_out_tp, (conv.irreps_out, irreps_out_tp)
+        if sc_types[t] == 'nequip':
+            sc = make_linear(f'{t}_self_connection_intro.fc_tensor_product.weight', irreps_x, gate.irreps_in, ns)
+        elif sc_types[t] == 'linear':
+            sc = make_linear(f'{t}_self_connection_intro.linear.weight', irreps_x, gate.irreps_in)
+        elif sc_types[t] == 'none':
+            sc = None
+        else:
+            raise ValueError(f'Unknown self_connection_type found: {sc_types[t]}')
+        layers.append(LayerSpec(
+            t, irreps_x, irreps_out, sc,
+            make_linear(f'{t}_self_interaction_1.linear.weight', irreps_x, irreps_x),
+            conv, [n_basis] + hidden + [conv.weight_numel],
+            make_linear(f'{t}_self_interaction_2.linear.weight', irreps_out_tp, gate.irreps_in),
+            gate, float(denom[t])))
+        irreps_x = irreps_out
+    hid = Irreps([((ch if legacy else irreps_x.dim) // 2, 0, 1)])
+    tm = cfg.get('_type_map') or {}
+    return ModelSpec(
+        cfg, float(cfg['cutoff']), ns, lmax_edge, bool(cfg['_normalize_sph']), irreps_sh, n_basis,
+        ckind, int(cf.get('poly_cut_p_value', 6)), float(cf.get('cutoff_on', 0.0)), cfg['act_radial'],
+        embed, layers,
+        make_linear('reduce_input_to_hidden.linear.weight', irreps_x, hid),
+        make_linear('reduce_hidden_to_energy.linear.weight', hid, Irreps('1x0e')),
+        {int(k): int(v) for k, v in tm.items()})
+
+
+# --------------------------------------------------------------------------- #
+# named model shapes (hyper-parameters from the reference presets)
+# --------------------------------------------------------------------------- #
+def sevennet_0_config(num_species: int = 1, conv_denominator: float = 28.0) -> dict:
+    """sevenn/presets/sevennet-0.yaml:4-31 (5 layers, SO(3)-only, XPLOR 4.5/5.0,
+    `linear` self-connection).  The released checkpoints predate v0.10, so the
+    spherical harmonics are evaluated on the raw edge vector
+    (backward_compatibility.py:38-39)."""
+    return dict(
+        cutoff=5.0, channel=128, is_parity=False, lmax=2, num_convolution_layer=5,
+        irreps_manual=['128x0e', '128x0e+64x1e+32x2e', '128x0e+64x1e+32x2e', '128x0e+64x1e+32x2e',
+                       '128x0e+64x1e+32x2e', '128x0e'],
+        weight_nn_hidden_neurons=[64, 64],
+        radial_basis={'radial_basis_name': 'bessel', 'bessel_basis_num': 8},
+        cutoff_function={'cutoff_function_name': 'XPLOR', 'cutoff_on': 4.5},
+        act_gate={'e': 'silu', 'o': 'tanh'}, act_scalar={'e': 'silu', 'o': 'tanh'},
+        conv_denominator=conv_denominator, self_connection_type='linear',
+        _normalize_sph=False, _number_of_species=num_species, shift=0.0, scale=1.0, version='0.9.5')
+
+
+def sevennet_l3i5_config(num_species: int = 1, conv_denominator: float = 28.0) -> dict:
+    """sevenn/presets/sevennet-l3i5.yaml:4-40."""
+    return dict(
+        cutoff=5.0, channel=128, is_parity=False, lmax=3, num_convolution_layer=5,
+        irreps_manual=['128x0e'] + ['128x0e+64x1e+32x2e+32x3e'] * 4 + ['128x0e'],
+        weight_nn_hidden_neurons=[64, 64],
+        radial_basis={'radial_basis_name': 'bessel', 'bessel_basis_num': 8},
+        cutoff_function={'cutoff_function_name': 'poly_cut', 'poly_cut_p_value': 6},
+        conv_denominator=conv_denominator, self_connection_type='linear',
+        _normalize_sph=True, _number_of_species=num_species, shift=0.0, scale=1.0, version='0.10.0')

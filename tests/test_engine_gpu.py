@@ -1,0 +1,118 @@
+"""GPU: HIP force engine (through the C ABI) vs the CPU oracle and the golden fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import irmul_to_mulir, load_ts_golden, oracle_model, synthetic_system
+
+pytestmark = pytest.mark.gpu
+
+F_TOL = 1e-4  # eV/A, BASELINE.json north_star tolerance
+
+
+def _engine(cfg, sd):
+    from sevennet_amd.engine import HipForceEngine
+    return HipForceEngine(cfg, sd, device='cuda:0')
+
+
+def _run(cfg, sd, types, ei, ev, keep=False):
+    from sevennet_amd.engine import build_graph
+    eng = _engine(cfg, sd)
+    g = build_graph(types, ei, ev, device='cuda:0', num_species=eng.spec.num_species)
+    out = eng.compute(g, want_atomic_virial=True, keep=keep)
+    torch.cuda.synchronize()
+    return eng, out
+
+
+def _compare(eng, out, ref, n, feat_tol=2e-5, check_inter=True):
+    e, er = float(out['energy'].cpu()), float(ref['energy'])
+    assert abs(e - er) / n < 1e-5, (e, er)
+    assert np.abs(out['atomic_energy'].cpu().numpy() - ref['atomic_energy'].numpy()).max() < 1e-4
+    assert np.abs(out['dE_dr'].cpu().numpy() - ref['dE_dr'].numpy()).max() < F_TOL
+    assert np.abs(out['forces'].cpu().numpy() - ref['forces'].numpy()).max() < F_TOL
+    assert np.abs(out['virial'].cpu().numpy() - ref['virial'].numpy()).max() < 1e-3 * max(1.0, np.abs(ref['virial'].numpy()).max())
+    assert np.abs(out['atomic_virial'].cpu().numpy() - ref['atomic_virial'].numpy()).max() < 1e-3
+    if check_inter and 'inter' in out:
+        for t, L in enumerate(eng.layers):
+            ls = L.spec
+            for key, irr in ((f'{t}_si1', ls.si1.irreps_out), (f'{t}_conv', ls.conv.irreps_out),
+                             (f'{t}_gate_in', ls.gate.irreps_in), (f'{t}_x', ls.gate.irreps_out)):
+                a = irmul_to_mulir(out['inter'][key], irr)
+                b = ref['inter'][key].numpy()
+                scale = max(1.0, np.abs(b).max())
+                assert np.abs(a - b).max() < feat_tol * scale, (key, np.abs(a - b).max(), scale)
+
+
+@pytest.mark.parametrize('name', ['hfo2_12', 'hfo_rs64', 'hfo2_96'])
+def test_engine_vs_reference_torchscript_outputs(name):
+    """the reference's own deployed model: E / F on the fixtures produced by running it"""
+    d, cfg, sd = load_ts_golden(name)
+    eng, out = _run(cfg, sd, d['types'], d['edge_index'], d['out_edge_vec'], keep=True)
+    n = len(d['types'])
+    assert abs(float(out['energy'].cpu()) - float(d['out_energy'])) / n < 1e-5
+    assert np.abs(out['forces'].cpu().numpy() - d['out_forces']).max() < F_TOL
+    assert np.abs(out['atomic_energy'].cpu().numpy() - d['out_atomic_energy']).max() < 1e-4
+    vol = abs(np.linalg.det(d['cell']))
+    assert np.abs(out['virial'].cpu().numpy() / vol - d['out_stress']).max() < 1e-5
+    assert np.abs(out['inter']['edge_embedding'].cpu().numpy() - d['out_edge_embedding']).max() < 2e-6
+    assert np.abs(out['inter']['edge_attr'].cpu().numpy() - d['out_edge_attr']).max() < 2e-6
+    assert np.abs(out['dE_dr'].cpu().numpy() - d['par_dE_dr']).max() < F_TOL
+    # module-by-module against the fp64 oracle (reference bar: atol 1e-6 features on O(1) values)
+    ref = oracle_model(cfg, sd).forward(d['types'], d['edge_index'], d['out_edge_vec'].astype(np.float64), keep=True)
+    _compare(eng, out, ref, n)
+
+
+CASES = {
+    'unit_o3_l2': dict(cfg='unit', over={}, cutoff=4.0, nsp=4),
+    'unit_o3_l3': dict(cfg='unit', over={'lmax': 3}, cutoff=4.0, nsp=4),
+    'unit_so3_l2_linear': dict(cfg='unit', over={'is_parity': False, 'self_connection_type': 'linear'}, cutoff=4.0, nsp=4),
+    'mini_7net0': dict(cfg='mini', over={}, cutoff=5.0, nsp=2),
+}
+
+
+@pytest.mark.parametrize('case', list(CASES))
+def test_engine_vs_oracle_synthetic_weights(case):
+    from sevennet_amd.shapes import mini_sevennet_0_config, unit_test_config
+    from sevennet_amd.synthetic import random_state_dict
+    c = CASES[case]
+    cfg = unit_test_config(**c['over']) if c['cfg'] == 'unit' else mini_sevennet_0_config()
+    sd = random_state_dict(cfg, seed=7)
+    types, pos, cell, ei, ev = synthetic_system((2, 2, 2), sigma=0.08, seed=11, cutoff=c['cutoff'], n_species=c['nsp'])
+    eng, out = _run(cfg, sd, types, ei, ev, keep=True)
+    ref = oracle_model(cfg, sd).forward(types, ei, ev, keep=True)
+    _compare(eng, out, ref, len(types))
+
+
+def test_engine_unsorted_edges_and_empty_graph():
+    from sevennet_amd.engine import build_graph
+    from sevennet_amd.shapes import unit_test_config
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = unit_test_config()
+    sd = random_state_dict(cfg, seed=1)
+    types, pos, cell, ei, ev = synthetic_system((1, 1, 1), sigma=0.05, seed=3, cutoff=4.0, n_species=4)
+    perm = np.random.default_rng(0).permutation(ei.shape[1])
+    eng = _engine(cfg, sd)
+    a = eng.compute(build_graph(types, ei, ev, device='cuda:0', num_species=4))
+    b = eng.compute(build_graph(types, ei[:, perm], ev[perm], device='cuda:0', num_species=4))
+    assert abs(float(a['energy'].cpu()) - float(b['energy'].cpu())) < 1e-4
+    assert np.abs(a['dE_dr'].cpu().numpy()[perm] - b['dE_dr'].cpu().numpy()).max() < 1e-5
+    # isolated atom: no edges (reference: convolution.py:265-268)
+    iso = eng.compute(build_graph(np.array([2]), np.zeros((2, 0), np.int64), np.zeros((0, 3)), device='cuda:0', num_species=4))
+    ref = oracle_model(cfg, sd).forward(np.array([2]), np.zeros((2, 0), np.int64), np.zeros((0, 3)))
+    assert abs(float(iso['energy'].cpu()) - float(ref['energy'])) < 1e-4
+    assert iso['forces'].abs().max().item() == 0.0
+
+
+def test_sevennet_0_shape_vs_oracle_small_cell():
+    """BASELINE config 1: SevenNet-0 shape on 64-atom Si, synthetic weights; fp32 GPU vs fp64 oracle"""
+    from sevennet_amd.model_spec import sevennet_0_config
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = sevennet_0_config()
+    sd = random_state_dict(cfg, seed=0)
+    types, pos, cell, ei, ev = synthetic_system((2, 2, 2), sigma=0.05, seed=0, cutoff=5.0)
+    eng, out = _run(cfg, sd, types, ei, ev, keep=True)
+    ref = oracle_model(cfg, sd).forward(types, ei, ev, keep=True)
+    # synthetic N(0,1) weights give O(1e2..1e4) energies/forces: compare relative to the force scale
+    fs = max(1.0, ref['forces'].abs().max().item())
+    assert np.abs(out['forces'].cpu().numpy() - ref['forces'].numpy()).max() < 2e-5 * fs
+    assert abs(float(out['energy'].cpu()) - float(ref['energy'])) < 2e-5 * max(1.0, abs(float(ref['energy'])))
