@@ -76,6 +76,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64 and owns the device context, streams and memory this
+    # library works on: it must be loaded first so that libsnet_hip.so binds to the same HIP runtime.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f'{LIB_PATH} not found: the HIP force engine has not been built '
