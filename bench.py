@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- atom-steps/s of one SevenNet-0 energy+force evaluation on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one energy+forces evaluation of the hot path (edge embedding -> 5
+interaction blocks -> readout -> analytic reverse pass -> forces/virial) on a
+synthetic periodic diamond-Si cell with seeded synthetic weights (no checkpoints
+exist offline; throughput is weight-independent).  Workload at every N: the
+~100k-atom cell BASELINE.json's metric is quoted on (97 336 atoms, Si x 23^3,
+sigma = 0.05 A, cutoff 5.0 A); with N > 1 the SAME cell is split into N spatial
+bricks (strong scaling) with an RCCL ghost-feature halo exchange per layer.
+Inputs (graph + weights) are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline     -- dominant kernel class, achieved vs gfx950 peak, from HIP events
+                  recorded around every launch of that class inside the timed steps
+  cpu_baseline -- the CPU oracle (reference-equivalent PyTorch path) timed on this
+                  box's host cores on a bounded sample (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak
+MFMA_F32_PEAK_TF = 157.3   # dense fp32-input MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--reps', type=int, default=23, help='diamond cells per axis (23 -> 97 336 atoms)')
+    ap.add_argument('--model', default='sevennet_0', choices=['sevennet_0', 'sevennet_l3i5'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-reps', type=int, default=5, help='CPU-baseline sample: cells per axis (5 -> 1000 atoms)')
+    return ap.parse_args()
+
+
+def model_config(name):
+    from sevennet_amd.model_spec import sevennet_0_config, sevennet_l3i5_config
+    return {'sevennet_0': sevennet_0_config, 'sevennet_l3i5': sevennet_l3i5_config}[name]()
+
+
+def kernel_model(ls, n_nodes, n_edges):
+    """Algorithmic bytes / flops per launch of each kernel class of one layer
+    (SURVEY.md §8(d) conventions: dst rows once per node, src rows once per edge,
+    radial weights NOT counted for the tensor-product kernels, no cache credit)."""
+    dx, dmid, wn = ls.conv.irreps_x.dim, ls.conv.irreps_out.dim, ls.conv.weight_numel
+    nsh = ls.conv.irreps_sh.dim
+    h = ls.mlp_dims
+    mlp_flops = 2.0 * n_edges * sum(h[i] * h[i + 1] for i in range(len(h) - 1))
+    return {
+        f'conv_fwd[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 4 * nsh + 8) + n_nodes * 4 * dmid),
+        f'conv_bwd_edge[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 2 * 4 * nsh + 8) + n_nodes * 4 * dmid),
+        f'conv_bwd_node[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dmid + 4 * nsh + 12) + n_nodes * 4 * dx),
+        f'radial_mlp_fwd[wn={wn}]': dict(bound='mfma', flops=mlp_flops),
+        f'radial_mlp_bwd[wn={wn}]': dict(bound='mfma', flops=mlp_flops),
+    }
+
+
+def cpu_baseline(cfg, sd, reps, threads):
+    """The oracle = this repo's CPU restatement of the reference's e3nn/PyTorch path, fp32."""
+    from oracle.model import OracleModel
+    from sevennet_amd.neighbor import diamond_cubic, neighbor_list
+    torch.set_num_threads(threads)
+    pos, cell = diamond_cubic(5.431, (reps,) * 3, 0.05, 2)
+    ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
+    types = np.zeros(len(pos), np.int64)
+    m = OracleModel(cfg, sd, dtype=torch.float32)
+    m.forward(types, ei, ev)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        m.forward(types, ei, ev)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 12.0 or n >= 5:
+            break
+    return dict(value=len(pos) * n / dt, unit='atom-steps/s', cores=threads, kind='port',
+                sample=f'SevenNet-0 shape, {len(pos)}-atom Si cell ({ei.shape[1]} edges), {n} energy+force '
+                       f'evaluations in {dt:.1f} s, fp32 torch CPU oracle (oracle/model.py)')
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+    if a.gpus > 1 and world == 1:
+        raise SystemExit('launch N>1 with torch.distributed.run (one process per GPU)')
+    torch.cuda.set_device(local_rank)
+    dev = f'cuda:{local_rank}'
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device(dev))
+
+    from sevennet_amd.engine import HipForceEngine, build_graph
+    from sevennet_amd.neighbor import diamond_cubic, neighbor_list
+    from sevennet_amd.synthetic import random_state_dict
+
+    cfg = model_config(a.model)
+    sd = random_state_dict(cfg, seed=0)
+    eng = HipForceEngine(cfg, sd, device=dev)
+
+    pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
+    n_atoms = len(pos)
+    t0 = time.perf_counter()
+    halo = None
+    if world == 1:
+        ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
+        types = np.zeros(n_atoms, np.int64)
+        graph = build_graph(types, ei, ev, device=dev)
+        n_edges_total = graph.n_edges
+    else:
+        from sevennet_amd.parallel import HaloExchange, build_brick_graph
+        bg = build_brick_graph(pos, cell, np.zeros(n_atoms, np.int64), cfg['cutoff'], world, rank)
+        graph = build_graph(bg.types, bg.edge_index, bg.edge_vec, n_local=bg.n_local, device=dev)
+        halo = HaloExchange(bg.send_lists, bg.recv_counts, dev)
+        ne = torch.tensor([graph.n_edges], device=dev, dtype=torch.int64)
+        dist.all_reduce(ne)
+        n_edges_total = int(ne.item())
+    t_graph = time.perf_counter() - t0
+
+    def step():
+        return eng.compute(graph, halo=halo)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    eng.events = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    times = eng.kernel_times_ms()
+    eng.events = None
+
+    # ---- per-kernel-class time over the timed region -> dominant kernel + roofline
+    totals = {k: float(np.sum(v)) for k, v in times.items()}
+    counts = {k: len(v) for k, v in times.items()}
+    models = {}
+    for ls in eng.spec.layers:
+        models.update(kernel_model(ls, graph.n_local, graph.n_edges))
+    dominant = max((k for k in totals if k in models), key=lambda k: totals[k])
+    avg_ms = totals[dominant] / counts[dominant]
+    km = models[dominant]
+    if km['bound'] == 'hbm':
+        ach = km['bytes'] / (avg_ms * 1e-3) / 1e9
+        roof = dict(bound='hbm', kernel=dominant, achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=ach / HBM_PEAK_GBS, traffic=None, avg_ms=avg_ms,
+                    algorithmic_bytes_per_launch=km['bytes'])
+    else:
+        ach = km['flops'] / (avg_ms * 1e-3) / 1e12
+        roof = dict(bound='mfma', kernel=dominant, achieved=ach, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
+                    frac=ach / MFMA_F32_PEAK_TF, traffic=None, avg_ms=avg_ms,
+                    algorithmic_flops_per_launch=km['flops'])
+    step_ms = dt / a.steps * 1e3
+    roof['kernel_ms_per_step'] = {k: round(v / a.steps, 4) for k, v in sorted(totals.items(), key=lambda kv: -kv[1])}
+
+    if rank == 0:
+        res = {
+            'metric': 'atom-steps/sec (energy+forces), SevenNet-0 100k-atom cell, 1/2/4/8 MI355X',
+            'value': n_atoms * a.steps / dt, 'unit': 'atom-steps/s', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': step_ms, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{a.model} shape (5 interaction layers), {n_atoms}-atom periodic diamond-Si '
+                                   f'cell (a=5.431 A x {a.reps}^3, sigma=0.05 A), cutoff {cfg["cutoff"]} A, '
+                                   f'{n_edges_total} directed edges, seeded synthetic weights',
+                       'atoms': n_atoms, 'edges': n_edges_total,
+                       'parallelism': 'single GPU' if world == 1 else f'spatial decomposition x{world}, RCCL halo',
+                       'graph_build_s': round(t_graph, 3),
+                       'energy': float(out['energy'].cpu())},
+            'roofline': roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(cfg, sd, a.cpu_reps, os.cpu_count() or 1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -186,7 +186,7 @@ def tp_uvu(x_src, sh, weight, irreps_x: Irreps, irreps_sh: Irreps, irreps_mid: I
         C = wigner_3j(l1, l2, l3, dtype=x_src.dtype).to(x_src.device) * math.sqrt(2 * l3 + 1)
         xi = x_src[:, sl_x[i]].reshape(E, mul, 2 * l1 + 1)
         yj = sh[:, sl_sh[j]]
-        outs[k] = torch.einsum('eu,eui,ej,ijk->euk', w, xi, yj, C).reshape(E, -1)
+        outs[k] = torch.einsum('eu,eui,ej,ijk->euk', w, xi, yj, C).reshape(E, mul * (2 * l3 + 1))
     assert o == weight.shape[1]
     return torch.cat(outs, dim=1)
 

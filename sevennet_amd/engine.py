@@ -103,8 +103,27 @@ class _Linear:
         self.wt = [torch.from_numpy(np.ascontiguousarray(m.T)).to(dev) for m in mats]
 
 
+class _Span:
+    """HIP-event bracket around one kernel class (bench.py's per-kernel timing)."""
+
+    def __init__(self, eng, name):
+        self.eng, self.name = eng, name
+
+    def __enter__(self):
+        if self.eng.events is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.eng.events is not None:
+            self.b.record()
+            self.eng.events.append((self.name, self.a, self.b))
+
+
 class HipForceEngine:
     def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0'):
+        self.events = None  # set to [] to collect (name, start, end) HIP events per kernel class
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('HipForceEngine needs a ROCm GPU (no CPU fallback exists)')
@@ -168,6 +187,13 @@ class HipForceEngine:
                 self.lib.snet_conv_plan_destroy(L.plan)
         except Exception:
             pass
+
+    def kernel_times_ms(self) -> Dict[str, List[float]]:
+        """Elapsed ms of every recorded span, grouped by kernel class (call after a device sync)."""
+        out: Dict[str, List[float]] = {}
+        for name, a, b in self.events or []:
+            out.setdefault(name, []).append(a.elapsed_time(b))
+        return out
 
     # ------------------------------------------------------------------ ops
     def _new(self, *shape):
@@ -273,8 +299,9 @@ class HipForceEngine:
             nb, nsh = sp.n_basis, self.nsh
             inter = {}
             emb, sh = self._new(E, nb), self._new(E, nsh)
-            _lib.check(lib.snet_edge_embed_fwd(C.byref(self.edge_params), self.coeffs, _ptr(g.edge_vec), E,
-                                               _ptr(emb), _ptr(sh), st), 'snet_edge_embed_fwd')
+            with _Span(self, 'edge_embed_fwd'):
+                _lib.check(lib.snet_edge_embed_fwd(C.byref(self.edge_params), self.coeffs, _ptr(g.edge_vec), E,
+                                                   _ptr(emb), _ptr(sh), st), 'snet_edge_embed_fwd')
             d0 = sp.embed.dim_out
             x = self._new(NT, d0)  # ghost layer-0 features depend only on species (model_build.py:383-421)
             _lib.check(lib.snet_embed_rows(_ptr(self.embed_table), _ptr(g.types), _ptr(x), NT, d0, st),
@@ -285,19 +312,24 @@ class HipForceEngine:
             for t, L in enumerate(self.layers):
                 ls = L.spec
                 n_in = NT if t == 0 else N  # rows of x that are valid
-                sc = self._linear(L.sc, x, N, g) if L.sc is not None else None
-                h = self._new(NT, ls.si1.dim_out)
-                self._linear(L.si1, x, n_in, g, out=h)
+                with _Span(self, 'node_linear_fwd'):
+                    sc = self._linear(L.sc, x, N, g) if L.sc is not None else None
+                    h = self._new(NT, ls.si1.dim_out)
+                    self._linear(L.si1, x, n_in, g, out=h)
                 if t > 0 and halo is not None:
-                    halo.forward(h, N)
-                w, zs = self._mlp_fwd(L, emb, E)
+                    with _Span(self, 'halo_fwd'):
+                        halo.forward(h, N)
+                with _Span(self, f'radial_mlp_fwd[wn={ls.conv.weight_numel}]'):
+                    w, zs = self._mlp_fwd(L, emb, E)
                 dmid = ls.conv.irreps_out.dim
                 m = self._new(N, dmid)
                 if E == 0:
                     m.zero_()
-                _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N,
-                                             L.scale, _ptr(m), st), 'snet_conv_fwd')
-                y = self._linear(L.si2, m, N, g)
+                with _Span(self, f'conv_fwd[{ls.conv.tag}]'):
+                    _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N,
+                                                 L.scale, _ptr(m), st), 'snet_conv_fwd')
+                with _Span(self, 'node_linear_fwd'):
+                    y = self._linear(L.si2, m, N, g)
                 if sc is not None:
                     _lib.check(lib.snet_add_inplace(_ptr(y), _ptr(sc), y.numel(), st), 'snet_add_inplace')
                 xo = self._new(N, ls.gate.irreps_out.dim)
@@ -331,22 +363,28 @@ class HipForceEngine:
                 g_y = self._new(N, ls.gate.irreps_in.dim)
                 _lib.check(lib.snet_gate_bwd(_ptr(y), _ptr(g_x), _ptr(g_y), N, ls.gate.irreps_in.dim,
                                              ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st), 'snet_gate_bwd')
-                g_m = self._linear_T(L.si2, g_y, N, g)
+                with _Span(self, 'node_linear_bwd'):
+                    g_m = self._linear_T(L.si2, g_y, N, g)
                 g_w = self._new(E, ls.conv.weight_numel)
-                _lib.check(lib.snet_conv_bwd_edge(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N,
-                                                  L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_sh), st), 'snet_conv_bwd_edge')
-                self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
+                with _Span(self, f'conv_bwd_edge[{ls.conv.tag}]'):
+                    _lib.check(lib.snet_conv_bwd_edge(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N,
+                                                      L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_sh), st), 'snet_conv_bwd_edge')
+                with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]'):
+                    self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
                 del g_w
                 if t == 0:
                     break  # layer-0 inputs depend on species only: nothing upstream needs a gradient
                 g_h = self._new(NT, ls.si1.dim_out)
-                _lib.check(lib.snet_conv_bwd_node(L.plan, _ptr(sh), _ptr(w), _ptr(g.col_ptr), _ptr(g.eperm),
-                                                  _ptr(g.center), NT, L.scale, _ptr(g_m), _ptr(g_h), st), 'snet_conv_bwd_node')
+                with _Span(self, f'conv_bwd_node[{ls.conv.tag}]'):
+                    _lib.check(lib.snet_conv_bwd_node(L.plan, _ptr(sh), _ptr(w), _ptr(g.col_ptr), _ptr(g.eperm),
+                                                      _ptr(g.center), NT, L.scale, _ptr(g_m), _ptr(g_h), st), 'snet_conv_bwd_node')
                 if halo is not None:
-                    halo.reverse(g_h, N)
-                g_x = self._linear_T(L.si1, g_h, N, g)
-                if L.sc is not None:
-                    self._linear_T(L.sc, g_y, N, g, out=g_x, accumulate=True)
+                    with _Span(self, 'halo_rev'):
+                        halo.reverse(g_h, N)
+                with _Span(self, 'node_linear_bwd'):
+                    g_x = self._linear_T(L.si1, g_h, N, g)
+                    if L.sc is not None:
+                        self._linear_T(L.sc, g_y, N, g, out=g_x, accumulate=True)
                 saved[t] = None
             g_vec = self._new(E, 3)
             _lib.check(lib.snet_edge_embed_bwd(C.byref(self.edge_params), self.coeffs, _ptr(g.edge_vec), E, _ptr(g_emb),
