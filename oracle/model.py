@@ -186,7 +186,9 @@ def tp_uvu(x_src, sh, weight, irreps_x: Irreps, irreps_sh: Irreps, irreps_mid: I
         C = wigner_3j(l1, l2, l3, dtype=x_src.dtype).to(x_src.device) * math.sqrt(2 * l3 + 1)
         xi = x_src[:, sl_x[i]].reshape(E, mul, 2 * l1 + 1)
         yj = sh[:, sl_sh[j]]
-        outs[k] = torch.einsum('eu,eui,ej,ijk->euk', w, xi, yj, C).reshape(E, mul * (2 * l3 + 1))
+        # pairwise contractions like e3nn's lowering: (x (x) Y) @ C, then the per-edge weight
+        xy = (xi.unsqueeze(-1) * yj.reshape(E, 1, 1, 2 * l2 + 1)).reshape(E, mul, -1)
+        outs[k] = ((xy @ C.reshape(-1, 2 * l3 + 1)) * w.unsqueeze(-1)).reshape(E, mul * (2 * l3 + 1))
     assert o == weight.shape[1]
     return torch.cat(outs, dim=1)
 
@@ -418,6 +420,44 @@ class OracleModel:
         if sc.numel() == 1:
             return e * sc + sh  # Rescale, sevenn/nn/scale.py:53-56
         return e * sc[types].view(-1, 1) + sh[types].view(-1, 1)  # SpeciesWiseRescale :155-162
+
+    # ------------------------------------------------------- one brick of a decomposition
+    def forward_brick(self, types_all, edge_index, edge_vec, n_local, exchange):
+        """One rank of the reference's parallel scheme (model_build.py:361-431,
+        pair_e3gnn_parallel.cpp:358-441): `types_all` = local then ghost species;
+        edges have local centers; `exchange(h_local) -> h_all` must return the
+        conv input with ghost rows filled from their owners and be differentiable
+        (its backward accumulates ghost-row gradients into the owners).  Returns the
+        local energy sum, local atomic energies, dE/dr of the local edges and the
+        force/virial rows of all n_total atoms (ghost rows still to be folded)."""
+        types_all = torch.as_tensor(types_all, dtype=torch.long)
+        edge_index = torch.as_tensor(edge_index, dtype=torch.long)
+        edge_vec = torch.as_tensor(edge_vec, dtype=self.dtype).clone().requires_grad_(True)
+        nt = types_all.shape[0]
+        emb, sh = self.edge_embedding(edge_vec)
+        onehot_all, x_all = self.node_embed(types_all)
+        onehot = onehot_all[:n_local]
+        src, dst = edge_index[1], edge_index[0]
+        x = x_all[:n_local]
+        for ls in self.layers:
+            sc = self.sc_intro(ls, x, onehot)
+            if ls.t == 0:
+                h_all = self.si1(ls, x_all)  # ghost layer-0 features depend on species only
+            else:
+                h_all = exchange(self.si1(ls, x))
+            m = self.conv(ls, h_all, emb, sh, src, dst, n_local)
+            y = self.si2(ls, m)
+            if sc is not None:
+                y = y + sc
+            x = ls.gate.apply(y)
+        e_atom = self.readout(x, types_all[:n_local])
+        energy = e_atom.sum()
+        (g,) = torch.autograd.grad(energy, edge_vec, allow_unused=True)
+        if g is None:
+            g = torch.zeros_like(edge_vec)
+        out = force_virial_from_edge(g, edge_vec.detach(), edge_index, nt)
+        out.update(energy=energy.detach(), atomic_energy=e_atom.detach().squeeze(-1), dE_dr=g)
+        return out
 
     # ---------------------------------------------------------------- forward
     def forward(self, types, edge_index, edge_vec, keep=False):

@@ -121,3 +121,53 @@ def test_sevennet_0_shape_vs_oracle_small_cell():
     ref = oracle_model(cfg, sd).forward(types, ei, ev, keep=True)
     # synthetic N(0,1) weights give O(1e2..1e4) energies/forces: compare relative to the force scale
     _compare(eng, out, ref, len(types), rel=5e-5)
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_engine_bricks_equal_single_graph_on_one_gpu(world):
+    """N bricks (threads sharing cuda:0, in-process halo with the same pack/unpack kernels and
+    exchange semantics as the RCCL path) == the un-split evaluation; reference analogue:
+    tests/lammps_tests/test_lammps.py:540-578."""
+    import threading
+    from sevennet_amd.engine import build_graph
+    from sevennet_amd.parallel import InProcessHaloGroup, build_brick_graph
+    from sevennet_amd.shapes import mini_sevennet_0_config
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = mini_sevennet_0_config()
+    sd = random_state_dict(cfg, seed=9)
+    types, pos, cell, ei, ev = synthetic_system((4, 4, 4), sigma=0.06, seed=4, cutoff=5.0, n_species=2)
+    eng = _engine(cfg, sd)
+    ref = eng.compute(build_graph(types, ei, ev, device='cuda:0'))
+    torch.cuda.synchronize()
+    bricks = [build_brick_graph(pos, cell, types, 5.0, world, r, neighbors=(ei, ev)) for r in range(world)]
+    grp = InProcessHaloGroup(bricks, 'cuda:0')
+    engines = [_engine(cfg, sd) for _ in range(world)]
+    results, errors = [None] * world, []
+
+    def run(r):
+        try:
+            b = bricks[r]
+            g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, device='cuda:0')
+            results[r] = engines[r].compute(g, halo=grp.members[r])
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            grp.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errors, errors
+    F = np.zeros((len(types), 3), np.float32)
+    Ea = np.zeros(len(types), np.float32)
+    e_tot = 0.0
+    for b, r in zip(bricks, results):
+        F[b.global_ids[:b.n_local]] = r['forces'].cpu().numpy()
+        Ea[b.global_ids[:b.n_local]] = r['atomic_energy'].cpu().numpy()
+        e_tot += float(r['energy'].cpu())
+        assert sum(b.recv_counts) > 0
+    assert abs(e_tot - float(ref['energy'].cpu())) < 2e-6 * abs(float(ref['energy'].cpu()))
+    _close(Ea, ref['atomic_energy'], 1e-5, 1e-7, 'atomic energies (bricks)')
+    _close(F, ref['forces'], 2e-5, 1e-8, 'forces (bricks)')
