@@ -51,12 +51,17 @@ typedef struct snet_edge_params {
   int32_t normalize;   /* SH on unit vector (1) or raw vector (0, <0.10 checkpoints) */
 } snet_edge_params;
 
-/* edge_vec[E,3] -> emb[E,n_basis], sh[E,(lmax+1)^2]; coeffs_host[n_basis] = Bessel c_n (HOST) */
+/* edge_vec[E,3] -> emb[E,n_basis], sh[E,nsh], nsh = (lmax+1)^2; coeffs_host[n_basis] = Bessel c_n
+ * (HOST).  dsh (nullable) receives the Jacobian d sh[e,i] / d edge_vec[e,a] as [E,nsh,3]; the
+ * tensor-product reverse kernel contracts with it so only 3 values per edge are reduced. */
 int snet_edge_embed_fwd(const snet_edge_params *p_host, const float *coeffs_host, const float *edge_vec,
-                        int64_t n_edges, float *emb, float *sh, void *stream);
-/* g_vec[E,3] = d/d edge_vec of <g_emb,emb> + <g_sh,sh>  (replaces autograd through a1) */
+                        int64_t n_edges, float *emb, float *sh, float *dsh, void *stream);
+/* g_vec[E,3] (+)= d/d edge_vec of <g_emb,emb> + <g_sh,sh>  (replaces autograd through a1).
+ * g_sh may be NULL (spherical part already accumulated by snet_conv_bwd_edge_vec);
+ * accumulate != 0 adds to g_vec instead of overwriting it. */
 int snet_edge_embed_bwd(const snet_edge_params *p_host, const float *coeffs_host, const float *edge_vec,
-                        int64_t n_edges, const float *g_emb, const float *g_sh, float *g_vec, void *stream);
+                        int64_t n_edges, const float *g_emb, const float *g_sh, float *g_vec, int32_t accumulate,
+                        void *stream);
 
 /* ---- a3/a4/a2.1: dense channel mixing on MFMA (fp32 in / fp32 acc) --------
  * One call = one per-irrep block of e3nn o3.Linear (sevenn/nn/linear.py:94-100),
@@ -70,6 +75,18 @@ int snet_edge_embed_bwd(const snet_edge_params *p_host, const float *coeffs_host
 int snet_gemm(const float *A, const float *B, float *C, int64_t n_nodes, int32_t d, int32_t K, int32_t N,
               int64_t a_node_stride, int64_t a_off, int64_t c_node_stride, int64_t c_off,
               const int32_t *row_idx, int32_t accumulate, void *stream);
+
+/* Fused radial MLP, e3nn FullyConnectedNet([nb,h1,h2,wn], act) (convolution.py:93-95,121):
+ *   fwd  w[E,wn] = (act(act(emb W0) cst W1) cst) W2          W0[nb,h1] W1[h1,h2] W2[h2,wn]
+ *   bwd  g_emb[E,nb] += d<g_w,w>/d emb                        W2T = W2^T [wn,h2]
+ * weights row-major with 1/sqrt(fan_in) folded; hidden activations stay in registers (fwd) or are
+ * recomputed (bwd).  Only h1 = h2 = 64 and nb <= 32 are fused (rc 2 otherwise: use snet_gemm). */
+int snet_radial_mlp_fwd(const float *emb, int64_t n_edges, int32_t nb, int32_t h1, int32_t h2, int32_t wn,
+                        const float *W0, const float *W1, const float *W2, int32_t act, float cst, float *w_out,
+                        void *stream);
+int snet_radial_mlp_bwd(const float *emb, const float *g_w, int64_t n_edges, int32_t nb, int32_t h1, int32_t h2,
+                        int32_t wn, const float *W0, const float *W1, const float *W2T, int32_t act, float cst,
+                        float *g_emb, void *stream);
 
 /* a = act(z)*cst  /  g_z = g_a * cst * act'(z)   (act: 0 silu, 1 tanh);
  * radial-MLP hidden activations, normalize2mom constant `cst` */
@@ -97,6 +114,12 @@ int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, c
 int snet_conv_bwd_edge(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
                        const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
                        const float *g_out, float *g_w, float *g_sh, void *stream);
+/* same, but the spherical-harmonic gradient is contracted with dsh[E,nsh,3] (snet_edge_embed_fwd)
+ * inside the kernel and ACCUMULATED into g_vec[E,3]: 3 instead of nsh values per edge cross the
+ * wavefront reduction.  This is the variant the whole-model engine uses. */
+int snet_conv_bwd_edge_vec(const snet_conv_plan *plan, const float *x, const float *sh, const float *dsh,
+                           const float *w, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
+                           const float *g_out, float *g_w, float *g_vec, void *stream);
 /* source-node gradient g_x[n_src,dx] (overwritten) via the source-sorted edge
  * permutation: col_ptr[n_src+1], eperm[E] (edge ids grouped by source), dst[E].
  * Deterministic replacement of the scatter-add autograd performs for x[src]. */

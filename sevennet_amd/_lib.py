@@ -36,9 +36,15 @@ SIGNATURES = {
     'snet_conv_num_shapes': (C.c_int, []),
     'snet_conv_shape_tag': (C.c_char_p, [C.c_int]),
     'snet_edge_embed_fwd': (C.c_int, [C.POINTER(EdgeParams), C.POINTER(C.c_float), c_f32p, C.c_int64, c_f32p,
-                                      c_f32p, c_stream]),
-    'snet_edge_embed_bwd': (C.c_int, [C.POINTER(EdgeParams), C.POINTER(C.c_float), c_f32p, C.c_int64, c_f32p,
                                       c_f32p, c_f32p, c_stream]),
+    'snet_edge_embed_bwd': (C.c_int, [C.POINTER(EdgeParams), C.POINTER(C.c_float), c_f32p, C.c_int64, c_f32p,
+                                      c_f32p, c_f32p, C.c_int32, c_stream]),
+    'snet_radial_mlp_fwd': (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p,
+                                      c_f32p, C.c_int32, C.c_float, c_f32p, c_stream]),
+    'snet_radial_mlp_bwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p,
+                                      c_f32p, c_f32p, C.c_int32, C.c_float, c_f32p, c_stream]),
+    'snet_conv_bwd_edge_vec': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int64,
+                                         C.c_float, c_f32p, c_f32p, c_f32p, c_stream]),
     'snet_gemm': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                             C.c_int64, C.c_int64, C.c_int64, c_i32p, C.c_int32, c_stream]),
     'snet_act_fwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_stream]),

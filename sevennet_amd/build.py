@@ -28,7 +28,7 @@ OBJ = os.path.join(CSRC, 'build')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB = os.path.join(HERE, 'libsnet_hip.so')
 ARCH = 'gfx950'
-STATIC_SOURCES = ['snet_api.cpp', 'snet_gemm.hip', 'snet_edge.hip', 'snet_node.hip', 'snet_force.hip']
+STATIC_SOURCES = ['snet_api.cpp', 'snet_gemm.hip', 'snet_mlp.hip', 'snet_edge.hip', 'snet_node.hip', 'snet_force.hip']
 
 
 def _hipcc() -> str:

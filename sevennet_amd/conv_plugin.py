@@ -1,0 +1,173 @@
+"""Drop-in for the reference's tensor-product accelerator plug-in point.
+
+The reference swaps `IrrepsScatterGatterFusedConvolution.convolution_cls`
+(sevenn/nn/convolution.py:145-284) for a third-party fused gather-TP-scatter op
+(flash_helper.py:33-48, cue_helper.py:201-248, oeq_helper.py:74-83).  This module
+is the MI355X equivalent:
+
+    conv = HipUvuConvolution(irreps_in1, irreps_in2, irreps_out, instructions)
+    out  = conv(x[N,dx], edge_filter[E,nsh], weight[E,wn], edge_src[E] i32, edge_dst[E] i32)
+
+with the reference's semantics (convolution.py:270-276): e3nn `mul_ir` layout,
+out[i] = sum_{e: dst=i} TP_uvu(x[src_e], filter_e; weight_e), differentiable wrt
+x, edge_filter and weight (first order: forces are taken by autograd through it).
+`patch_convolution(irreps_convolution)` mirrors the reference's patch helpers.
+
+All arithmetic runs in libsnet_hip.so through the C ABI; there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .irreps import Irreps, irmul_to_mulir_index, mulir_to_irmul_index
+from .model_spec import ConvPath, ConvSpec
+
+
+def _irreps(obj) -> Irreps:
+    return obj if isinstance(obj, Irreps) else Irreps(str(obj))
+
+
+def conv_spec_from_instructions(irreps_in1, irreps_in2, irreps_out, instructions: Sequence) -> ConvSpec:
+    """ConvSpec for an explicit e3nn-style instruction list [(i_in1, i_in2, i_out, 'uvu', ...)];
+    weight columns follow the list order (convolution.py:69,94), output blocks are `irreps_out`
+    (= sorted irreps_mid, one block per instruction)."""
+    x, sh, mid = _irreps(irreps_in1), _irreps(irreps_in2), _irreps(irreps_out)
+    merged = mid.simplified()
+    m_off = merged.offsets()
+    where, cur, ch = [], -1, 0
+    for (mul, l, p) in mid:
+        if cur < 0 or (merged[cur][1], merged[cur][2]) != (l, p) or ch + mul > merged[cur][0]:
+            cur += 1
+            ch = 0
+        where.append((cur, ch))
+        ch += mul
+    x_off, sh_off = x.offsets(), sh.offsets()
+    paths: List[ConvPath] = []
+    w_off = 0
+    for ins in instructions:
+        i, j, k = int(ins[0]), int(ins[1]), int(ins[2])
+        if len(ins) > 3 and ins[3] != 'uvu':
+            raise NotImplementedError(f"only 'uvu' instructions are supported, got {ins[3]!r}")
+        mul, l1, p1 = x[i]
+        _, l2, p2 = sh[j]
+        mo, l3, p3 = mid[k]
+        if mo != mul or p3 != p1 * p2 or not abs(l1 - l2) <= l3 <= l1 + l2:
+            raise ValueError(f'inconsistent instruction {ins}')
+        blk, c = where[k]
+        paths.append(ConvPath(i, j, l1, l2, l3, mul, w_off, x_off[i], sh_off[j], m_off[blk], merged[blk][0], c))
+        w_off += mul
+    return ConvSpec(x, sh, mid, merged, paths, w_off)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _UvuConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sh, w, edge_src, edge_dst, mod):
+        lib = mod.lib
+        if not (x.is_cuda and sh.is_cuda and w.is_cuda):
+            raise RuntimeError('HipUvuConvolution needs ROCm tensors (no CPU path exists)')
+        N, E = x.shape[0], sh.shape[0]
+        dst = edge_dst.to(torch.int64)
+        order = torch.sort(dst, stable=True).indices
+        src_s = edge_src.to(torch.int64)[order].to(torch.int32).contiguous()
+        dst_s = dst[order]
+        row_ptr = torch.zeros(N + 1, dtype=torch.int64, device=x.device)
+        row_ptr[1:] = torch.cumsum(torch.bincount(dst_s, minlength=N), 0)
+        row_ptr = row_ptr.to(torch.int32)
+        sh_s = sh.detach().float()[order].contiguous()
+        w_s = w.detach().float()[order].contiguous()
+        x_im = torch.empty(N, mod.dx, dtype=torch.float32, device=x.device)
+        xc = x.detach().float().contiguous()
+        _lib.check(lib.snet_permute_cols(_p(xc), _p(mod.idx_in), _p(x_im), N, mod.dx, _st()), 'snet_permute_cols')
+        out_im = torch.empty(N, mod.dout, dtype=torch.float32, device=x.device)
+        _lib.check(lib.snet_conv_fwd(mod.plan, _p(x_im), _p(sh_s), _p(w_s), _p(row_ptr), _p(src_s), N, 1.0,
+                                     _p(out_im), _st()), 'snet_conv_fwd')
+        out = torch.empty_like(out_im)
+        _lib.check(lib.snet_permute_cols(_p(out_im), _p(mod.idx_out_inv), _p(out), N, mod.dout, _st()), 'snet_permute_cols')
+        ctx.mod = mod
+        ctx.save_for_backward(x_im, sh_s, w_s, row_ptr, src_s, dst_s.to(torch.int32).contiguous(), order)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        mod, lib = ctx.mod, ctx.mod.lib
+        x_im, sh_s, w_s, row_ptr, src_s, dst_s, order = ctx.saved_tensors
+        N, E = x_im.shape[0], sh_s.shape[0]
+        dev = x_im.device
+        g_im = torch.empty(N, mod.dout, dtype=torch.float32, device=dev)
+        _lib.check(lib.snet_permute_cols(_p(g_out.float().contiguous()), _p(mod.idx_out), _p(g_im), N, mod.dout, _st()),
+                   'snet_permute_cols')
+        g_w_s = torch.empty(E, mod.wn, dtype=torch.float32, device=dev)
+        g_sh_s = torch.zeros(E, mod.nsh, dtype=torch.float32, device=dev)
+        _lib.check(lib.snet_conv_bwd_edge(mod.plan, _p(x_im), _p(sh_s), _p(w_s), _p(row_ptr), _p(src_s), N, 1.0,
+                                          _p(g_im), _p(g_w_s), _p(g_sh_s), _st()), 'snet_conv_bwd_edge')
+        col_ptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+        col_ptr[1:] = torch.cumsum(torch.bincount(src_s.long(), minlength=N), 0)
+        eperm = torch.sort(src_s.long(), stable=True).indices.to(torch.int32)
+        g_x_im = torch.empty(N, mod.dx, dtype=torch.float32, device=dev)
+        _lib.check(lib.snet_conv_bwd_node(mod.plan, _p(sh_s), _p(w_s), _p(col_ptr.to(torch.int32)), _p(eperm), _p(dst_s),
+                                          N, 1.0, _p(g_im), _p(g_x_im), _st()), 'snet_conv_bwd_node')
+        g_x = torch.empty_like(g_x_im)
+        _lib.check(lib.snet_permute_cols(_p(g_x_im), _p(mod.idx_in_inv), _p(g_x), N, mod.dx, _st()), 'snet_permute_cols')
+        g_w = torch.empty_like(g_w_s)
+        g_sh = torch.empty_like(g_sh_s)
+        g_w[order] = g_w_s
+        g_sh[order] = g_sh_s
+        return g_x, g_sh, g_w, None, None, None
+
+
+class HipUvuConvolution(torch.nn.Module):
+    """`convolution_cls` for IrrepsScatterGatterFusedConvolution (convolution.py:237-247)."""
+
+    def __init__(self, irreps_in1, irreps_in2, irreps_out, instructions, shared_weights: bool = False,
+                 internal_weights: bool = False, **_ignored):
+        super().__init__()
+        if shared_weights or internal_weights:
+            raise NotImplementedError('HipUvuConvolution: per-edge external weights only')
+        self.lib = _lib.load()
+        self.spec = conv_spec_from_instructions(irreps_in1, irreps_in2, irreps_out, instructions)
+        plan = C.c_void_p()
+        _lib.check(self.lib.snet_conv_plan_create(self.spec.tag.encode(), C.byref(plan)), 'snet_conv_plan_create')
+        self.plan = plan
+        self.dx, self.dout = self.spec.irreps_x.dim, self.spec.irreps_out.dim
+        self.nsh, self.wn = self.spec.irreps_sh.dim, self.spec.weight_numel
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32)  # noqa: E731
+        self.register_buffer('idx_in', i32(mulir_to_irmul_index(self.spec.irreps_x)), persistent=False)
+        self.register_buffer('idx_in_inv', i32(irmul_to_mulir_index(self.spec.irreps_x)), persistent=False)
+        self.register_buffer('idx_out', i32(mulir_to_irmul_index(self.spec.irreps_out)), persistent=False)
+        self.register_buffer('idx_out_inv', i32(irmul_to_mulir_index(self.spec.irreps_out)), persistent=False)
+
+    def forward(self, x, edge_filter, weight, edge_src, edge_dst):
+        if self.idx_in.device != x.device:
+            self.to(x.device)
+        return _UvuConvFn.apply(x, edge_filter, weight, edge_src, edge_dst, self)
+
+
+def is_hip_available() -> bool:
+    try:
+        _lib.load()
+    except Exception:  # noqa: BLE001
+        return False
+    return torch.cuda.is_available()
+
+
+def patch_convolution(irreps_convolution):
+    """Analogue of sevenn.nn.flash_helper.patch_convolution (flash_helper.py:33-48): turn a not yet
+    instantiated reference `IrrepsConvolution` into the fused variant backed by this library."""
+    from sevenn.nn.convolution import IrrepsScatterGatterFusedConvolution  # reference package, if installed
+    assert not irreps_convolution.layer_instantiated
+    ret = IrrepsScatterGatterFusedConvolution.from_irreps_convolution(irreps_convolution)
+    ret.convolution_cls = HipUvuConvolution
+    return ret

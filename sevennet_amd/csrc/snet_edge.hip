@@ -51,8 +51,16 @@ template <> __device__ __forceinline__ void sh_grad<2>(float x, float y, float z
 template <> __device__ __forceinline__ void sh_grad<3>(float x, float y, float z, const float (&g)[16], float &gx, float &gy, float &gz) { sh_grad_3(x, y, z, g, gx, gy, gz); }
 
 template <int LMAX>
+__device__ __forceinline__ void sh_jac(float x, float y, float z, float (&J)[(LMAX + 1) * (LMAX + 1)][3]);
+template <> __device__ __forceinline__ void sh_jac<0>(float x, float y, float z, float (&J)[1][3]) { sh_jac_0(x, y, z, J); }
+template <> __device__ __forceinline__ void sh_jac<1>(float x, float y, float z, float (&J)[4][3]) { sh_jac_1(x, y, z, J); }
+template <> __device__ __forceinline__ void sh_jac<2>(float x, float y, float z, float (&J)[9][3]) { sh_jac_2(x, y, z, J); }
+template <> __device__ __forceinline__ void sh_jac<3>(float x, float y, float z, float (&J)[16][3]) { sh_jac_3(x, y, z, J); }
+
+template <int LMAX>
 __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeP P, const float *__restrict__ vec, int64_t E,
-                                                       float *__restrict__ emb, float *__restrict__ sh) {
+                                                       float *__restrict__ emb, float *__restrict__ sh,
+                                                       float *__restrict__ dsh) {
   constexpr int NSH = (LMAX + 1) * (LMAX + 1);
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
@@ -71,12 +79,37 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeP P, const float *__r
   }
 #pragma unroll
   for (int i = 0; i < NSH; ++i) sh[e * NSH + i] = Y[i];
+  if (dsh) {
+    float J[NSH][3];
+    float *o = dsh + e * (NSH * 3);
+    if (P.normalize) {
+      const float ir = 1.f / r;
+      const float ux = x * ir, uy = y * ir, uz = z * ir;
+      sh_jac<LMAX>(ux, uy, uz, J);
+#pragma unroll
+      for (int i = 0; i < NSH; ++i) {  // chain rule through u = v/|v|: (I - u u^T)/r
+        const float dot = ux * J[i][0] + uy * J[i][1] + uz * J[i][2];
+        o[3 * i + 0] = (J[i][0] - ux * dot) * ir;
+        o[3 * i + 1] = (J[i][1] - uy * dot) * ir;
+        o[3 * i + 2] = (J[i][2] - uz * dot) * ir;
+      }
+    } else {
+      sh_jac<LMAX>(x, y, z, J);
+#pragma unroll
+      for (int i = 0; i < NSH; ++i) {
+        o[3 * i + 0] = J[i][0];
+        o[3 * i + 1] = J[i][1];
+        o[3 * i + 2] = J[i][2];
+      }
+    }
+  }
 }
 
 template <int LMAX>
 __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeP P, const float *__restrict__ vec, int64_t E,
                                                        const float *__restrict__ g_emb,
-                                                       const float *__restrict__ g_sh, float *__restrict__ g_vec) {
+                                                       const float *__restrict__ g_sh, float *__restrict__ g_vec,
+                                                       int accumulate) {
   constexpr int NSH = (LMAX + 1) * (LMAX + 1);
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
@@ -94,10 +127,11 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeP P, const float *__r
     const float df = (P.coeffs[k] * cs - f) * ir;
     gr += g_emb[e * P.nb + k] * P.pref * (df * env + f * denv);
   }
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (g_sh) {
   float gY[NSH];
 #pragma unroll
   for (int i = 0; i < NSH; ++i) gY[i] = g_sh[e * NSH + i];
-  float gx, gy, gz;
   if (P.normalize) {
     const float ux = x * ir, uy = y * ir, uz = z * ir;
     sh_grad<LMAX>(ux, uy, uz, gY, gx, gy, gz);
@@ -108,9 +142,18 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeP P, const float *__r
   } else {
     sh_grad<LMAX>(x, y, z, gY, gx, gy, gz);
   }
-  g_vec[3 * e + 0] = gx + gr * x * ir;
-  g_vec[3 * e + 1] = gy + gr * y * ir;
-  g_vec[3 * e + 2] = gz + gr * z * ir;
+  }
+  gx += gr * x * ir;
+  gy += gr * y * ir;
+  gz += gr * z * ir;
+  if (accumulate) {
+    gx += g_vec[3 * e + 0];
+    gy += g_vec[3 * e + 1];
+    gz += g_vec[3 * e + 2];
+  }
+  g_vec[3 * e + 0] = gx;
+  g_vec[3 * e + 1] = gy;
+  g_vec[3 * e + 2] = gz;
 }
 
 int prepare(const snet_edge_params *p, const float *coeffs_host, EdgeP &P) {
@@ -134,17 +177,17 @@ int prepare(const snet_edge_params *p, const float *coeffs_host, EdgeP &P) {
 }  // namespace
 
 extern "C" int snet_edge_embed_fwd(const snet_edge_params *p, const float *coeffs, const float *edge_vec,
-                                   int64_t E, float *emb, float *sh, void *stream) {
+                                   int64_t E, float *emb, float *sh, float *dsh, void *stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   EdgeP P;
   if (int rc = prepare(p, coeffs, P)) return rc;
   if (E <= 0) return 0;
   const unsigned grid = (unsigned)((E + 255) / 256);
   switch (P.lmax) {
-    case 0: edge_fwd_kernel<0><<<grid, 256, 0, st>>>(P, edge_vec, E, emb, sh); break;
-    case 1: edge_fwd_kernel<1><<<grid, 256, 0, st>>>(P, edge_vec, E, emb, sh); break;
-    case 2: edge_fwd_kernel<2><<<grid, 256, 0, st>>>(P, edge_vec, E, emb, sh); break;
-    default: edge_fwd_kernel<3><<<grid, 256, 0, st>>>(P, edge_vec, E, emb, sh); break;
+    case 0: edge_fwd_kernel<0><<<grid, 256, 0, st>>>(P, edge_vec, E, emb, sh, dsh); break;
+    case 1: edge_fwd_kernel<1><<<grid, 256, 0, st>>>(P, edge_vec, E, emb, sh, dsh); break;
+    case 2: edge_fwd_kernel<2><<<grid, 256, 0, st>>>(P, edge_vec, E, emb, sh, dsh); break;
+    default: edge_fwd_kernel<3><<<grid, 256, 0, st>>>(P, edge_vec, E, emb, sh, dsh); break;
   }
   SNET_CHECK_LAUNCH("snet_edge_embed_fwd");
   return 0;
@@ -152,17 +195,17 @@ extern "C" int snet_edge_embed_fwd(const snet_edge_params *p, const float *coeff
 
 extern "C" int snet_edge_embed_bwd(const snet_edge_params *p, const float *coeffs, const float *edge_vec,
                                    int64_t E, const float *g_emb, const float *g_sh, float *g_vec,
-                                   void *stream) {
+                                   int32_t accumulate, void *stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   EdgeP P;
   if (int rc = prepare(p, coeffs, P)) return rc;
   if (E <= 0) return 0;
   const unsigned grid = (unsigned)((E + 255) / 256);
   switch (P.lmax) {
-    case 0: edge_bwd_kernel<0><<<grid, 256, 0, st>>>(P, edge_vec, E, g_emb, g_sh, g_vec); break;
-    case 1: edge_bwd_kernel<1><<<grid, 256, 0, st>>>(P, edge_vec, E, g_emb, g_sh, g_vec); break;
-    case 2: edge_bwd_kernel<2><<<grid, 256, 0, st>>>(P, edge_vec, E, g_emb, g_sh, g_vec); break;
-    default: edge_bwd_kernel<3><<<grid, 256, 0, st>>>(P, edge_vec, E, g_emb, g_sh, g_vec); break;
+    case 0: edge_bwd_kernel<0><<<grid, 256, 0, st>>>(P, edge_vec, E, g_emb, g_sh, g_vec, accumulate); break;
+    case 1: edge_bwd_kernel<1><<<grid, 256, 0, st>>>(P, edge_vec, E, g_emb, g_sh, g_vec, accumulate); break;
+    case 2: edge_bwd_kernel<2><<<grid, 256, 0, st>>>(P, edge_vec, E, g_emb, g_sh, g_vec, accumulate); break;
+    default: edge_bwd_kernel<3><<<grid, 256, 0, st>>>(P, edge_vec, E, g_emb, g_sh, g_vec, accumulate); break;
   }
   SNET_CHECK_LAUNCH("snet_edge_embed_bwd");
   return 0;

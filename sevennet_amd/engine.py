@@ -159,6 +159,8 @@ class HipForceEngine:
                     w = sd[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] / np.sqrt(ls.mlp_dims[i])
                     L.mlp_w.append(torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(self.dev))
                     L.mlp_wt.append(torch.from_numpy(np.ascontiguousarray(w.T, dtype=np.float32)).to(self.dev))
+                L.fused_mlp = (len(ls.mlp_dims) == 4 and ls.mlp_dims[1] == 64 and ls.mlp_dims[2] == 64
+                               and ls.mlp_dims[0] <= 32)
                 L.scale = 1.0 / float(sd[f'{ls.t}_convolution.denominator'][0])
                 plan = C.c_void_p()
                 _lib.check(self.lib.snet_conv_plan_create(ls.conv.tag.encode(), C.byref(plan)), 'snet_conv_plan_create')
@@ -252,11 +254,18 @@ class HipForceEngine:
         return gx
 
     def _mlp_fwd(self, L, emb, E):
+        """radial weights w[E,wn]; returns (w, saved) where saved feeds _mlp_bwd."""
         dims = L.spec.mlp_dims
+        if L.fused_mlp:
+            w = self._new(E, dims[3])
+            _lib.check(self.lib.snet_radial_mlp_fwd(_ptr(emb), E, dims[0], dims[1], dims[2], dims[3], _ptr(L.mlp_w[0]),
+                                                    _ptr(L.mlp_w[1]), _ptr(L.mlp_w[2]), self.act_radial, self.act_cst,
+                                                    _ptr(w), _stream()), 'snet_radial_mlp_fwd')
+            return w, None
         zs, a = [], emb
-        for i, w in enumerate(L.mlp_w):
+        for i, wm in enumerate(L.mlp_w):
             z = self._new(E, dims[i + 1])
-            self._gemm(a, w, z, E, 1, dims[i], dims[i + 1], dims[i], 0, dims[i + 1], 0)
+            self._gemm(a, wm, z, E, 1, dims[i], dims[i + 1], dims[i], 0, dims[i + 1], 0)
             if i + 1 < len(L.mlp_w):
                 zs.append(z)
                 a = self._new(E, dims[i + 1])
@@ -268,6 +277,12 @@ class HipForceEngine:
 
     def _mlp_bwd(self, L, emb, zs, g_w, g_emb_total, E):
         dims = L.spec.mlp_dims
+        if L.fused_mlp:
+            _lib.check(self.lib.snet_radial_mlp_bwd(_ptr(emb), _ptr(g_w), E, dims[0], dims[1], dims[2], dims[3],
+                                                    _ptr(L.mlp_w[0]), _ptr(L.mlp_w[1]), _ptr(L.mlp_wt[2]),
+                                                    self.act_radial, self.act_cst, _ptr(g_emb_total), _stream()),
+                       'snet_radial_mlp_bwd')
+            return
         g = g_w
         nl = len(L.mlp_w)
         for i in range(nl - 1, -1, -1):
@@ -278,10 +293,9 @@ class HipForceEngine:
                 ga = self._new(E, dims[i])
                 self._gemm(g, L.mlp_wt[i], ga, E, 1, dims[i + 1], dims[i], dims[i + 1], 0, dims[i], 0)
                 z = zs[2 * (i - 1)]
-                gz = ga  # in place
-                _lib.check(self.lib.snet_act_bwd(_ptr(z), _ptr(ga), _ptr(gz), z.numel(), self.act_radial,
+                _lib.check(self.lib.snet_act_bwd(_ptr(z), _ptr(ga), _ptr(ga), z.numel(), self.act_radial,
                                                  self.act_cst, _stream()), 'snet_act_bwd')
-                g = gz
+                g = ga
 
     # -------------------------------------------------------------- compute
     def compute(self, g: Graph, halo=None, want_atomic_virial: bool = False, keep: bool = False):
@@ -298,10 +312,10 @@ class HipForceEngine:
             N, NT, E = g.n_local, g.n_total, g.n_edges
             nb, nsh = sp.n_basis, self.nsh
             inter = {}
-            emb, sh = self._new(E, nb), self._new(E, nsh)
+            emb, sh, dsh = self._new(E, nb), self._new(E, nsh), self._new(E, nsh * 3)
             with _Span(self, 'edge_embed_fwd'):
                 _lib.check(lib.snet_edge_embed_fwd(C.byref(self.edge_params), self.coeffs, _ptr(g.edge_vec), E,
-                                                   _ptr(emb), _ptr(sh), st), 'snet_edge_embed_fwd')
+                                                   _ptr(emb), _ptr(sh), _ptr(dsh), st), 'snet_edge_embed_fwd')
             d0 = sp.embed.dim_out
             x = self._new(NT, d0)  # ghost layer-0 features depend only on species (model_build.py:383-421)
             _lib.check(lib.snet_embed_rows(_ptr(self.embed_table), _ptr(g.types), _ptr(x), NT, d0, st),
@@ -354,7 +368,7 @@ class HipForceEngine:
                 g_e.fill_(self.scale0)
             g_h1 = self._linear_T(self.ro2, g_e, N, g)
             g_x = self._linear_T(self.ro1, g_h1, N, g)
-            g_sh = torch.zeros(E, nsh, dtype=torch.float32, device=self.dev)
+            g_vec = torch.zeros(E, 3, dtype=torch.float32, device=self.dev)  # spherical part, all layers
             g_emb = torch.zeros(E, nb, dtype=torch.float32, device=self.dev)
             for t in range(len(self.layers) - 1, -1, -1):
                 L = self.layers[t]
@@ -367,8 +381,9 @@ class HipForceEngine:
                     g_m = self._linear_T(L.si2, g_y, N, g)
                 g_w = self._new(E, ls.conv.weight_numel)
                 with _Span(self, f'conv_bwd_edge[{ls.conv.tag}]'):
-                    _lib.check(lib.snet_conv_bwd_edge(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N,
-                                                      L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_sh), st), 'snet_conv_bwd_edge')
+                    _lib.check(lib.snet_conv_bwd_edge_vec(L.plan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(w), _ptr(g.row_ptr),
+                                                          _ptr(g.src), N, L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_vec), st),
+                               'snet_conv_bwd_edge_vec')
                 with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]'):
                     self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
                 del g_w
@@ -386,9 +401,8 @@ class HipForceEngine:
                     if L.sc is not None:
                         self._linear_T(L.sc, g_y, N, g, out=g_x, accumulate=True)
                 saved[t] = None
-            g_vec = self._new(E, 3)
             _lib.check(lib.snet_edge_embed_bwd(C.byref(self.edge_params), self.coeffs, _ptr(g.edge_vec), E, _ptr(g_emb),
-                                               _ptr(g_sh), _ptr(g_vec), st), 'snet_edge_embed_bwd')
+                                               None, _ptr(g_vec), 1, st), 'snet_edge_embed_bwd')
             forces = self._new(NT, 3)
             vir_atom = self._new(NT, 6) if want_atomic_virial else None
             virial = torch.empty(6, dtype=torch.float64, device=self.dev)

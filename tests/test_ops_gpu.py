@@ -1,0 +1,225 @@
+"""GPU: individual C-ABI entry points vs plain PyTorch fp32/fp64 references of the same op."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from sevennet_amd import _lib
+    return _lib, _lib.load()
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize('shape', [(1000, 1, 8, 64), (777, 3, 64, 64), (513, 5, 352, 32), (300, 1, 224, 224),
+                                   (4097, 1, 64, 960), (129, 1, 960, 64), (50, 3, 4, 12), (33, 1, 2, 1)])
+def test_gemm_vs_torch(shape):
+    L, lib = _lib()
+    n, d, K, N = shape
+    dev = 'cuda:0'
+    g = torch.Generator(device='cpu').manual_seed(1)
+    a_stride, a_off = d * K + 8, 4
+    c_stride, c_off = d * N + 4, 4
+    A = torch.randn(n, a_stride, generator=g).to(dev)
+    B = torch.randn(K, N, generator=g).to(dev)
+    Cm = torch.randn(n, c_stride, generator=g).to(dev)
+    C0 = Cm.clone()
+    ref = (A[:, a_off:a_off + d * K].reshape(n, d, K).double() @ B.double()).reshape(n, d * N)
+    L.check(lib.snet_gemm(_p(A), _p(B), _p(Cm), n, d, K, N, a_stride, a_off, c_stride, c_off, None, 0, None))
+    torch.cuda.synchronize()
+    tol = 2e-6 * K ** 0.5 * 8
+    assert (Cm[:, c_off:c_off + d * N].double() - ref).abs().max() < tol
+    assert torch.equal(Cm[:, :c_off], C0[:, :c_off])  # nothing outside the block is touched
+    L.check(lib.snet_gemm(_p(A), _p(B), _p(Cm), n, d, K, N, a_stride, a_off, c_stride, c_off, None, 1, None))
+    torch.cuda.synchronize()
+    assert (Cm[:, c_off:c_off + d * N].double() - 2 * ref).abs().max() < 2 * tol
+    # row indirection (species-grouped rows)
+    rows = torch.randperm(n, generator=g)[: n // 2].to(torch.int32).to(dev)
+    C2 = torch.zeros_like(Cm)
+    L.check(lib.snet_gemm(_p(A), _p(B), _p(C2), rows.numel(), d, K, N, a_stride, a_off, c_stride, c_off, _p(rows), 0, None))
+    torch.cuda.synchronize()
+    sel = rows.long()
+    assert (C2[sel][:, c_off:c_off + d * N].double() - ref[sel]).abs().max() < tol
+    mask = torch.ones(n, dtype=torch.bool, device=dev)
+    mask[sel] = False
+    assert C2[mask].abs().max() == 0
+
+
+@pytest.mark.parametrize('nb,wn,E', [(8, 960, 5000), (8, 224, 333), (8, 12, 100), (12, 60, 257), (8, 384, 128)])
+def test_fused_radial_mlp_vs_torch(nb, wn, E):
+    L, lib = _lib()
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(2)
+    emb = torch.randn(E, nb, generator=g).to(dev)
+    W0 = (torch.randn(nb, 64, generator=g) / nb ** 0.5).to(dev)
+    W1 = (torch.randn(64, 64, generator=g) / 8).to(dev)
+    W2 = (torch.randn(64, wn, generator=g) / 8).to(dev)
+    cst = 1.6791767923989418
+    w = torch.empty(E, wn, device=dev)
+    L.check(lib.snet_radial_mlp_fwd(_p(emb), E, nb, 64, 64, wn, _p(W0), _p(W1), _p(W2), 0, cst, _p(w), None))
+    torch.cuda.synchronize()
+    e64 = emb.double().requires_grad_(True)
+    a1 = torch.nn.functional.silu(e64 @ W0.double()) * cst
+    a2 = torch.nn.functional.silu(a1 @ W1.double()) * cst
+    ref = a2 @ W2.double()
+    assert (w.double() - ref).abs().max() < 2e-5 * ref.abs().max()
+    gw = torch.randn(E, wn, generator=g).to(dev)
+    (gref,) = torch.autograd.grad(ref, e64, gw.double())
+    g_emb = torch.ones(E, nb, device=dev)  # accumulates
+    L.check(lib.snet_radial_mlp_bwd(_p(emb), _p(gw), E, nb, 64, 64, wn, _p(W0), _p(W1), _p(W2.t().contiguous()), 0, cst,
+                                    _p(g_emb), None))
+    torch.cuda.synchronize()
+    assert (g_emb.double() - 1.0 - gref).abs().max() < 3e-5 * gref.abs().max()
+
+
+@pytest.mark.parametrize('lmax,normalize,kind', [(1, 0, 0), (2, 0, 1), (2, 1, 0), (3, 1, 0), (3, 0, 1)])
+def test_edge_embedding_fwd_bwd_vs_oracle(lmax, normalize, kind):
+    from oracle.e3 import spherical_harmonics
+    from oracle.model import bessel_basis, poly_cutoff, xplor_cutoff
+    L, lib = _lib()
+    dev = 'cuda:0'
+    E, nb, rc, r_on = 2000, 8, 5.0, 4.5
+    g = torch.Generator().manual_seed(3)
+    v = torch.randn(E, 3, generator=g)
+    v = v / v.norm(dim=1, keepdim=True) * (1.5 + 3.4 * torch.rand(E, 1, generator=g))
+    coeffs = torch.tensor([n * np.pi / rc * (1 + 0.01 * n) for n in range(1, nb + 1)])
+    P = L.EdgeParams(rc, nb, kind, 6, r_on, lmax, normalize)
+    cf = (C.c_float * nb)(*coeffs.tolist())
+    nsh = (lmax + 1) ** 2
+    vd = v.to(dev)
+    emb, sh, dsh = torch.empty(E, nb, device=dev), torch.empty(E, nsh, device=dev), torch.empty(E, nsh, 3, device=dev)
+    L.check(lib.snet_edge_embed_fwd(C.byref(P), cf, _p(vd), E, _p(emb), _p(sh), _p(dsh), None))
+    v64 = v.double().requires_grad_(True)
+    r = v64.norm(dim=1)
+    env = poly_cutoff(r, rc, 6) if kind == 0 else xplor_cutoff(r, rc, r_on)
+    emb_ref = bessel_basis(r, coeffs.double(), rc) * env.unsqueeze(-1)
+    sh_ref = spherical_harmonics(lmax, v64, bool(normalize))
+    torch.cuda.synchronize()
+    assert (emb.cpu().double() - emb_ref).abs().max() < 2e-6
+    assert (sh.cpu().double() - sh_ref).abs().max() < 5e-6 * max(1.0, sh_ref.abs().max().item())
+    g_emb = torch.randn(E, nb, generator=g)
+    g_sh = torch.randn(E, nsh, generator=g)
+    (gref,) = torch.autograd.grad((emb_ref * g_emb.double()).sum() + (sh_ref * g_sh.double()).sum(), v64)
+    gv = torch.full((E, 3), 7.0, device=dev)
+    L.check(lib.snet_edge_embed_bwd(C.byref(P), cf, _p(vd), E, _p(g_emb.to(dev)), _p(g_sh.to(dev)), _p(gv), 0, None))
+    torch.cuda.synchronize()
+    tol = 2e-5 * max(1.0, gref.abs().max().item())
+    assert (gv.cpu().double() - gref).abs().max() < tol
+    # Jacobian path: g_vec = dsh^T g_sh + radial part (accumulate)
+    gv2 = torch.einsum('eia,ei->ea', dsh, g_sh.to(dev)).contiguous()
+    L.check(lib.snet_edge_embed_bwd(C.byref(P), cf, _p(vd), E, _p(g_emb.to(dev)), None, _p(gv2), 1, None))
+    torch.cuda.synchronize()
+    assert (gv2.cpu().double() - gref).abs().max() < tol
+
+
+def _conv_case(cfg_name):
+    from sevennet_amd.model_spec import build_model_spec, sevennet_0_config
+    from sevennet_amd.shapes import unit_test_config
+    if cfg_name == 'unit_l3':
+        return build_model_spec(unit_test_config(lmax=3)).layers[1].conv
+    if cfg_name == 'unit_l2':
+        return build_model_spec(unit_test_config()).layers[1].conv
+    return build_model_spec(sevennet_0_config()).layers[1].conv
+
+
+@pytest.mark.parametrize('cfg_name', ['unit_l2', 'unit_l3', '7net0_mid'])
+def test_conv_plugin_vs_oracle_autograd(cfg_name):
+    """b1 boundary: HipUvuConvolution (mul_ir in/out, unsorted int32 edges, ghost rows) against the
+    oracle's e3nn-style tensor product + scatter, forward and all three gradients."""
+    from oracle.e3 import Irreps as OIrreps
+    from oracle.model import tp_uvu
+    from sevennet_amd.conv_plugin import HipUvuConvolution
+    spec = _conv_case(cfg_name)
+    dev = 'cuda:0'
+    ins = [(p.i_x, p.i_sh, k, 'uvu', True) for p, k in zip(spec.paths, _mid_index(spec))]
+    conv = HipUvuConvolution(str(spec.irreps_x), str(spec.irreps_sh), str(spec.irreps_mid), ins).to(dev)
+    g = torch.Generator().manual_seed(4)
+    N, E = 37, 411
+    x = torch.randn(N, spec.irreps_x.dim, generator=g)
+    sh = torch.randn(E, spec.irreps_sh.dim, generator=g)
+    w = torch.randn(E, spec.weight_numel, generator=g)
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, N - 5, (E,), generator=g)  # last rows act as ghosts: sources only
+    xd, shd, wd = [t.to(dev).requires_grad_(True) for t in (x, sh, w)]
+    out = conv(xd, shd, wd, src.to(dev).to(torch.int32), dst.to(dev).to(torch.int32))
+    go = torch.randn(N, spec.irreps_out.dim, generator=g)
+    out.backward(go.to(dev))
+    torch.cuda.synchronize()
+    x64, sh64, w64 = [t.double().requires_grad_(True) for t in (x, sh, w)]
+    oins = [(i, j, k) for (i, j, k, _, _) in ins]
+    msg = tp_uvu(x64[src], sh64, w64, OIrreps(str(spec.irreps_x)), OIrreps(str(spec.irreps_sh)),
+                 OIrreps(str(spec.irreps_mid)), oins)
+    ref = torch.zeros(N, msg.shape[1], dtype=torch.float64).index_add_(0, dst, msg)
+    ref.backward(go.double())
+    for a, b, name in ((out, ref, 'out'), (xd.grad, x64.grad, 'g_x'), (shd.grad, sh64.grad, 'g_sh'), (wd.grad, w64.grad, 'g_w')):
+        err = (a.detach().cpu().double() - b.detach()).abs().max().item()
+        assert err < 3e-5 * max(1.0, b.abs().max().item()), (name, err)
+
+
+def _mid_index(spec):
+    """index of each path's block inside irreps_mid (sorted, one block per path)"""
+    offs = {}
+    out = []
+    # blocks of irreps_mid with the same irrep appear in the order their paths fill the merged block
+    mid = list(spec.irreps_mid)
+    used = [False] * len(mid)
+    order = sorted(range(len(spec.paths)), key=lambda q: (spec.paths[q].out_off, spec.paths[q].out_ch))
+    k = 0
+    idx = [0] * len(spec.paths)
+    for q in order:
+        idx[q] = k
+        k += 1
+    return idx
+
+
+def test_gate_and_halo_kernels():
+    from oracle.model import GateSpec
+    from oracle.e3 import Irreps as OIrreps
+    from sevennet_amd.irreps import Irreps, mulir_to_irmul_index, irmul_to_mulir_index
+    from sevennet_amd.model_spec import ACT_CST, make_gate
+    L, lib = _lib()
+    dev = 'cuda:0'
+    irr = '4x0o+6x0e+3x1o+5x1e+2x2e'
+    act = {'e': 'silu', 'o': 'tanh'}
+    gs = make_gate(Irreps(irr), act, act)
+    og = GateSpec(OIrreps(irr), act, act)
+    N = 301
+    g = torch.Generator().manual_seed(5)
+    y = torch.randn(N, gs.irreps_in.dim, generator=g)
+    y64 = y.double().requires_grad_(True)
+    ref = og.apply(y64)
+    go = torch.randn(N, gs.irreps_out.dim, generator=g)
+    (gref,) = torch.autograd.grad(ref, y64, go.double())
+    segs = (L.GateSeg * len(gs.segs))()
+    inv = {0: 'silu', 1: 'tanh'}
+    for i, s in enumerate(gs.segs):
+        segs[i] = L.GateSeg(s.kind, s.in_off, s.out_off, s.mul, s.l, s.gate_off, s.act, ACT_CST[inv[s.act]])
+    to_im_in = torch.as_tensor(mulir_to_irmul_index(gs.irreps_in))
+    to_im_out = torch.as_tensor(mulir_to_irmul_index(gs.irreps_out))
+    yd = y[:, to_im_in].contiguous().to(dev)
+    out = torch.empty(N, gs.irreps_out.dim, device=dev)
+    L.check(lib.snet_gate_fwd(_p(yd), _p(out), N, gs.irreps_in.dim, gs.irreps_out.dim, segs, len(gs.segs), None))
+    gy = torch.empty_like(yd)
+    god = go[:, to_im_out].contiguous().to(dev)
+    L.check(lib.snet_gate_bwd(_p(yd), _p(god), _p(gy), N, gs.irreps_in.dim, gs.irreps_out.dim, segs, len(gs.segs), None))
+    torch.cuda.synchronize()
+    back_out = torch.as_tensor(irmul_to_mulir_index(gs.irreps_out))
+    back_in = torch.as_tensor(irmul_to_mulir_index(gs.irreps_in))
+    assert (out.cpu()[:, back_out].double() - ref.detach()).abs().max() < 2e-6
+    assert (gy.cpu()[:, back_in].double() - gref).abs().max() < 5e-6
+    # halo pack / unpack
+    x = torch.randn(50, 7, generator=g).to(dev)
+    idx = torch.randperm(50, generator=g)[:20].to(torch.int32).to(dev)
+    o = torch.empty(20, 7, device=dev)
+    L.check(lib.snet_gather_rows(_p(x), _p(idx), _p(o), 20, 7, None))
+    yb = torch.zeros(50, 7, device=dev)
+    L.check(lib.snet_scatter_add_rows(_p(o), _p(idx), _p(yb), 20, 7, None))
+    torch.cuda.synchronize()
+    assert torch.equal(o, x[idx.long()])
+    assert torch.equal(yb[idx.long()], x[idx.long()]) and yb.abs().sum() == x[idx.long()].abs().sum()
