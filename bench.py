@@ -44,7 +44,7 @@ def parse():
     ap.add_argument('--reps', type=int, default=23, help='diamond cells per axis (23 -> 97 336 atoms)')
     ap.add_argument('--model', default='sevennet_0', choices=['sevennet_0', 'sevennet_l3i5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-reps', type=int, default=6, help='CPU-baseline sample: cells per axis (6 -> 1728 atoms)')
+    ap.add_argument('--cpu-reps', type=int, default=5, help='CPU-baseline sample: cells per axis (5 -> 1000 atoms)')
     return ap.parse_args()
 
 
@@ -75,25 +75,32 @@ def cpu_baseline(cfg, sd, reps):
     on a bounded sample (about 10-20 s of CPU work)."""
     from oracle.model import OracleModel
     from sevennet_amd.neighbor import diamond_cubic, neighbor_list
-    threads = torch.get_num_threads()
     pos, cell = diamond_cubic(5.431, (reps,) * 3, 0.05, 2)
     ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
     types = np.zeros(len(pos), np.int64)
     m = OracleModel(cfg, sd, dtype=torch.float32)
-    t0 = time.perf_counter()
-    m.forward(types, ei, ev)  # warm-up
-    warm = time.perf_counter() - t0
-    n_max = int(max(1, min(10, 12.0 / max(warm, 1e-3))))
-    t0 = time.perf_counter()
-    n = 0
-    while n < n_max:
-        m.forward(types, ei, ev)
-        n += 1
-    dt = time.perf_counter() - t0
-    return dict(value=len(pos) * n / dt, unit='atom-steps/s', cores=threads, kind='port',
+    best = None
+    default_threads = torch.get_num_threads()
+    # eager PyTorch on many small ops does not scale to every core: try the default and 32 threads
+    for threads in sorted({default_threads, min(32, default_threads)}):
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        m.forward(types, ei, ev)  # warm-up
+        warm = time.perf_counter() - t0
+        n_max = int(max(1, min(8, 6.0 / max(warm, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(n_max):
+            m.forward(types, ei, ev)
+        dt = time.perf_counter() - t0
+        rate = len(pos) * n_max / dt
+        if best is None or rate > best[0]:
+            best = (rate, threads, n_max, dt)
+    torch.set_num_threads(default_threads)
+    rate, threads, n, dt = best
+    return dict(value=rate, unit='atom-steps/s', cores=threads, kind='port',
                 sample=f'SevenNet-0 shape, {len(pos)}-atom Si cell ({ei.shape[1]} edges), {n} energy+force '
                        f'evaluations in {dt:.1f} s after one warm-up, fp32 torch CPU oracle (oracle/model.py), '
-                       f'{threads} torch threads on {os.cpu_count()} logical CPUs')
+                       f'best of {{default, 32}} torch threads = {threads} on {os.cpu_count()} logical CPUs')
 
 
 def main():

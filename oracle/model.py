@@ -187,7 +187,7 @@ def tp_uvu(x_src, sh, weight, irreps_x: Irreps, irreps_sh: Irreps, irreps_mid: I
         xi = x_src[:, sl_x[i]].reshape(E, mul, 2 * l1 + 1)
         yj = sh[:, sl_sh[j]]
         # pairwise contractions like e3nn's lowering: (x (x) Y) @ C, then the per-edge weight
-        xy = (xi.unsqueeze(-1) * yj.reshape(E, 1, 1, 2 * l2 + 1)).reshape(E, mul, -1)
+        xy = (xi.unsqueeze(-1) * yj.reshape(E, 1, 1, 2 * l2 + 1)).reshape(E, mul, (2 * l1 + 1) * (2 * l2 + 1))
         outs[k] = ((xy @ C.reshape(-1, 2 * l3 + 1)) * w.unsqueeze(-1)).reshape(E, mul * (2 * l3 + 1))
     assert o == weight.shape[1]
     return torch.cat(outs, dim=1)

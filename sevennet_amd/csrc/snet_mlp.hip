@@ -153,35 +153,42 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float *__rest
   hidden_forward(emb, e_ok ? e_lane : 0, e_ok, nb, W0, W1s, act, cst, lane, z1, a1, z2);
 
   // G_a2^T[k, e] = sum_ch W2'[k][ch] g_w[e][ch]   (A from W2T[ch][k], B from the LDS-transposed g_w tile)
+  // The tile is private to the wave (LDS operations of one wave execute in order, so no barrier is
+  // needed); the next 64-channel chunk is prefetched into registers while the current one feeds MFMA.
   f32x16 ga2[2];
   ga2[0] = zero16();
   ga2[1] = zero16();
   float *tile = gws + wave * GW_TILE;
   const bool vec_ok = (wn & 3) == 0;
-  for (int c0 = 0; c0 < wn; c0 += 64) {
-    // stage g_w[e0..e0+32, c0..c0+64): 16 lanes cover one row, 8 rows per pass
+  const int srow = lane >> 4, scol = 4 * (lane & 15);
+  float4 stage[8];
+  auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int row = 4 * i + (lane >> 4);
-      const int col = 4 * (lane & 15);
-      const int64_t e = e0 + row;
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-      if (wave_ok && e < E) {
-        const float *p = g_w + e * wn + c0 + col;
-        if (vec_ok && c0 + col + 3 < wn) {
-          const float4 q = *reinterpret_cast<const float4 *>(p);
-          v0 = q.x; v1 = q.y; v2 = q.z; v3 = q.w;
+      const int64_t e = e0 + 4 * i + srow;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wave_ok && e < E && c0 + scol < wn) {
+        const float *p = g_w + e * wn + c0 + scol;
+        if (vec_ok && c0 + scol + 3 < wn) {
+          q = *reinterpret_cast<const float4 *>(p);
         } else {
-          if (c0 + col + 0 < wn) v0 = p[0];
-          if (c0 + col + 1 < wn) v1 = p[1];
-          if (c0 + col + 2 < wn) v2 = p[2];
-          if (c0 + col + 3 < wn) v3 = p[3];
+          q.x = p[0];
+          if (c0 + scol + 1 < wn) q.y = p[1];
+          if (c0 + scol + 2 < wn) q.z = p[2];
+          if (c0 + scol + 3 < wn) q.w = p[3];
         }
       }
-      float *q = tile + row * GW_STRIDE + col;
-      q[0] = v0; q[1] = v1; q[2] = v2; q[3] = v3;
+      stage[i] = q;
     }
-    __syncthreads();
+  };
+  load_chunk(0);
+  for (int c0 = 0; c0 < wn; c0 += 64) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float *q = tile + (4 * i + srow) * GW_STRIDE + scol;
+      q[0] = stage[i].x; q[1] = stage[i].y; q[2] = stage[i].z; q[3] = stage[i].w;
+    }
+    if (c0 + 64 < wn) load_chunk(c0 + 64);
 #pragma unroll 8
     for (int s = 0; s < 32; ++s) {
       const int ch = c0 + 2 * s + half;
@@ -192,7 +199,6 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float *__rest
         ga2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, ga2[t], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
   // g_z2 = g_a2 * cst * act'(z2)
 #pragma unroll
