@@ -107,8 +107,8 @@ class _UvuConvFn(torch.autograd.Function):
         N, E = x_im.shape[0], sh_s.shape[0]
         dev = x_im.device
         g_im = torch.empty(N, mod.dout, dtype=torch.float32, device=dev)
-        _lib.check(lib.snet_permute_cols(_p(g_out.float().contiguous()), _p(mod.idx_out), _p(g_im), N, mod.dout, _st()),
-                   'snet_permute_cols')
+        g_c = g_out.float().contiguous()
+        _lib.check(lib.snet_permute_cols(_p(g_c), _p(mod.idx_out), _p(g_im), N, mod.dout, _st()), 'snet_permute_cols')
         g_w_s = torch.empty(E, mod.wn, dtype=torch.float32, device=dev)
         g_sh_s = torch.zeros(E, mod.nsh, dtype=torch.float32, device=dev)
         _lib.check(lib.snet_conv_bwd_edge(mod.plan, _p(x_im), _p(sh_s), _p(w_s), _p(row_ptr), _p(src_s), N, 1.0,

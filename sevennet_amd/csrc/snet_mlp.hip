@@ -123,9 +123,16 @@ __global__ __launch_bounds__(256) void radial_mlp_fwd_kernel(const float *__rest
   }
 }
 
-// LDS per wave for the g_w transpose: 32 rows x 64 cols, row stride 65 (conflict-free column reads)
-constexpr int GW_STRIDE = 65;
+// ---- backward -------------------------------------------------------------------------------
+// LDS plan (50 KB -> 3 workgroups per CU):
+//   W1p   [64][65]      W1' padded: conflict-free both as A[i=h'][k=h] (forward recompute) and as
+//                       A[i=h][k=h'] (G_a1), so no transposed copy is needed
+//   gws   4 x [32][33]  per-wave transpose tile of g_w (32 edges x 32 channels)
+//   w2t   2 x [32][64]  double-buffered 32-channel slab of W2^T shared by the 4 waves
+constexpr int W1P = 65;
+constexpr int GW_STRIDE = 33;
 constexpr int GW_TILE = 32 * GW_STRIDE;
+constexpr int CH = 32;  // channels per chunk
 
 __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float *__restrict__ emb,
                                                              const float *__restrict__ g_w, int64_t E, int nb, int wn,
@@ -133,39 +140,25 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float *__rest
                                                              const float *__restrict__ W1,
                                                              const float *__restrict__ W2T, int act, float cst,
                                                              float *__restrict__ g_emb) {
-  __shared__ float W1s[H * H];       // [h][h']
-  __shared__ float W1Ts[H * H];      // [h'][h]
-  __shared__ float gws[4 * GW_TILE];  // per-wave g_w staging tile
-  for (int i = threadIdx.x; i < H * H; i += 256) {
-    const float v = W1[i];
-    W1s[i] = v;
-    W1Ts[(i & 63) * H + (i >> 6)] = v;
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float W1p[H * W1P];
+  __shared__ float gws[4 * GW_TILE];
+  __shared__ float w2t[2][CH * H];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, li = lane & 31;
   const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-  const bool wave_ok = e0 < E;  // keep every wave in the block-wide barriers below
+  const bool wave_ok = e0 < E;  // every wave stays in the block-wide barriers
   const int64_t e_lane = e0 + li;
   const bool e_ok = wave_ok && e_lane < E;
-
-  f32x16 z1[2], a1[2], z2[2];
-  hidden_forward(emb, e_ok ? e_lane : 0, e_ok, nb, W0, W1s, act, cst, lane, z1, a1, z2);
-
-  // G_a2^T[k, e] = sum_ch W2'[k][ch] g_w[e][ch]   (A from W2T[ch][k], B from the LDS-transposed g_w tile)
-  // The tile is private to the wave (LDS operations of one wave execute in order, so no barrier is
-  // needed); the next 64-channel chunk is prefetched into registers while the current one feeds MFMA.
-  f32x16 ga2[2];
-  ga2[0] = zero16();
-  ga2[1] = zero16();
   float *tile = gws + wave * GW_TILE;
   const bool vec_ok = (wn & 3) == 0;
-  const int srow = lane >> 4, scol = 4 * (lane & 15);
-  float4 stage[8];
+  const int srow = lane >> 3, scol = 4 * (lane & 7);
+
+  float4 st_g[4], st_w[2];
   auto load_chunk = [&](int c0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int64_t e = e0 + 4 * i + srow;
+    for (int i = 0; i < 4; ++i) {  // g_w[e0 + 8i + srow][c0 + scol .. +4)
+      const int64_t e = e0 + 8 * i + srow;
       float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
       if (wave_ok && e < E && c0 + scol < wn) {
         const float *p = g_w + e * wn + c0 + scol;
@@ -178,34 +171,93 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float *__rest
           if (c0 + scol + 3 < wn) q.w = p[3];
         }
       }
-      stage[i] = q;
+      st_g[i] = q;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // W2T[c0 + row][0..64): 512 float4 per slab, 2 per thread
+      const int f = tid + 256 * i;
+      const int row = f >> 4, col = 4 * (f & 15);
+      st_w[i] = (c0 + row < wn) ? *reinterpret_cast<const float4 *>(W2T + (int64_t)(c0 + row) * H + col)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  load_chunk(0);
-  for (int c0 = 0; c0 < wn; c0 += 64) {
+  auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float *q = tile + (4 * i + srow) * GW_STRIDE + scol;
-      q[0] = stage[i].x; q[1] = stage[i].y; q[2] = stage[i].z; q[3] = stage[i].w;
+    for (int i = 0; i < 4; ++i) {
+      float *q = tile + (8 * i + srow) * GW_STRIDE + scol;
+      q[0] = st_g[i].x; q[1] = st_g[i].y; q[2] = st_g[i].z; q[3] = st_g[i].w;
     }
-    if (c0 + 64 < wn) load_chunk(c0 + 64);
-#pragma unroll 8
-    for (int s = 0; s < 32; ++s) {
-      const int ch = c0 + 2 * s + half;
-      const float b = tile[li * GW_STRIDE + 2 * s + half];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;
+      *reinterpret_cast<float4 *>(&w2t[buf][4 * f]) = st_w[i];
+    }
+  };
+
+  load_chunk(0);
+  for (int i = tid; i < H * H; i += 256) W1p[(i >> 6) * W1P + (i & 63)] = W1[i];
+  store_chunk(0);
+  __syncthreads();
+
+  // recompute z1, z2 (transposed layout: lane&31 = edge, registers = hidden units)
+  f32x16 z1[2], z2[2];
+  {
+    f32x16 a1[2];
+    z1[0] = zero16();
+    z1[1] = zero16();
+    for (int s = 0; 2 * s < nb; ++s) {
+      const int k = 2 * s + half;
+      const float b = (e_ok && k < nb) ? emb[e_lane * nb + k] : 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const float a = (ch < wn) ? W2T[(int64_t)ch * H + 32 * t + li] : 0.f;
-        ga2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, ga2[t], 0, 0, 0);
+        const float a = (k < nb) ? W0[k * H + 32 * t + li] : 0.f;
+        z1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, z1[t], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[t][r] = snet::act_fwd(z1[t][r], act) * cst;
+    z2[0] = zero16();
+    z2[1] = zero16();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = krow(16 * t + r, half);
+#pragma unroll
+        for (int to = 0; to < 2; ++to)
+          z2[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1p[k * W1P + 32 * to + li], a1[t][r], z2[to], 0, 0, 0);
+      }
+  }
+
+  // G_a2^T[k, e] = sum_ch W2'[k][ch] g_w[e][ch]: A = w2t slab [ch][k], B = transposed g_w tile
+  f32x16 ga2[2];
+  ga2[0] = zero16();
+  ga2[1] = zero16();
+  int buf = 0;
+  for (int c0 = 0; c0 < wn; c0 += CH) {
+    const bool more = c0 + CH < wn;
+    if (more) load_chunk(c0 + CH);  // global -> registers, in flight during the MFMAs below
+    const float *wt = w2t[buf];
+#pragma unroll
+    for (int s = 0; s < CH / 2; ++s) {
+      const float b = tile[li * GW_STRIDE + 2 * s + half];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        ga2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[(2 * s + half) * H + 32 * t + li], b, ga2[t], 0, 0, 0);
+    }
+    if (more) store_chunk(buf ^ 1);  // tile: wave-private (in-order LDS); w2t[buf^1]: last read before
+                                     // the previous barrier
+    __syncthreads();
+    buf ^= 1;
   }
   // g_z2 = g_a2 * cst * act'(z2)
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ga2[t][r] *= cst * snet::act_grad(z2[t][r], act);
-  // G_a1^T[h, e] = sum_h' W1'[h][h'] g_z2[e][h']     (A[i=h][k=h'] read from W1Ts[h'][h])
+  // G_a1^T[h, e] = sum_h' W1'[h][h'] g_z2[e][h']     (A[i=h][k=h'] = W1p[h][h'])
   f32x16 ga1[2];
   ga1[0] = zero16();
   ga1[1] = zero16();
@@ -214,12 +266,9 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float *__rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = krow(16 * t + r, half);
-      const float b = ga2[t][r];
 #pragma unroll
-      for (int to = 0; to < 2; ++to) {
-        const float a = W1Ts[k * H + 32 * to + li];
-        ga1[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, ga1[to], 0, 0, 0);
-      }
+      for (int to = 0; to < 2; ++to)
+        ga1[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(W1p[(32 * to + li) * W1P + k], ga2[t][r], ga1[to], 0, 0, 0);
     }
 #pragma unroll
   for (int t = 0; t < 2; ++t)

@@ -72,7 +72,8 @@ def test_fused_radial_mlp_vs_torch(nb, wn, E):
     gw = torch.randn(E, wn, generator=g).to(dev)
     (gref,) = torch.autograd.grad(ref, e64, gw.double())
     g_emb = torch.ones(E, nb, device=dev)  # accumulates
-    L.check(lib.snet_radial_mlp_bwd(_p(emb), _p(gw), E, nb, 64, 64, wn, _p(W0), _p(W1), _p(W2.t().contiguous()), 0, cst,
+    W2T = W2.t().contiguous()
+    L.check(lib.snet_radial_mlp_bwd(_p(emb), _p(gw), E, nb, 64, 64, wn, _p(W0), _p(W1), _p(W2T), 0, cst,
                                     _p(g_emb), None))
     torch.cuda.synchronize()
     assert (g_emb.double() - 1.0 - gref).abs().max() < 3e-5 * gref.abs().max()
@@ -107,13 +108,14 @@ def test_edge_embedding_fwd_bwd_vs_oracle(lmax, normalize, kind):
     g_sh = torch.randn(E, nsh, generator=g)
     (gref,) = torch.autograd.grad((emb_ref * g_emb.double()).sum() + (sh_ref * g_sh.double()).sum(), v64)
     gv = torch.full((E, 3), 7.0, device=dev)
-    L.check(lib.snet_edge_embed_bwd(C.byref(P), cf, _p(vd), E, _p(g_emb.to(dev)), _p(g_sh.to(dev)), _p(gv), 0, None))
+    g_emb_d, g_sh_d = g_emb.to(dev), g_sh.to(dev)  # keep the device buffers alive across the async calls
+    L.check(lib.snet_edge_embed_bwd(C.byref(P), cf, _p(vd), E, _p(g_emb_d), _p(g_sh_d), _p(gv), 0, None))
     torch.cuda.synchronize()
     tol = 2e-5 * max(1.0, gref.abs().max().item())
     assert (gv.cpu().double() - gref).abs().max() < tol
     # Jacobian path: g_vec = dsh^T g_sh + radial part (accumulate)
-    gv2 = torch.einsum('eia,ei->ea', dsh, g_sh.to(dev)).contiguous()
-    L.check(lib.snet_edge_embed_bwd(C.byref(P), cf, _p(vd), E, _p(g_emb.to(dev)), None, _p(gv2), 1, None))
+    gv2 = torch.einsum('eia,ei->ea', dsh, g_sh_d).contiguous()
+    L.check(lib.snet_edge_embed_bwd(C.byref(P), cf, _p(vd), E, _p(g_emb_d), None, _p(gv2), 1, None))
     torch.cuda.synchronize()
     assert (gv2.cpu().double() - gref).abs().max() < tol
 
