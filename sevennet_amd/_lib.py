@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsnet_hip.so')
+LIB_PATH = os.environ.get('SNET_HIP_LIB') or os.path.join(_HERE, 'libsnet_hip.so')  # env: kernel experiments
 
 c_f32p = C.c_void_p   # device float*
 c_i32p = C.c_void_p   # device int32*

@@ -23,10 +23,12 @@ from .shapes import aot_conv_specs
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-GEN = os.path.join(CSRC, 'generated')
-OBJ = os.path.join(CSRC, 'build')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
-LIB = os.path.join(HERE, 'libsnet_hip.so')
+LIB = os.environ.get('SNET_BUILD_LIB') or os.path.join(HERE, 'libsnet_hip.so')
+# experiment builds (SNET_BUILD_LIB=... SNET_CODEGEN_OPTS=...) keep their sources/objects apart
+_sfx = ('_' + os.path.basename(LIB).replace('.so', '')) if os.environ.get('SNET_BUILD_LIB') else ''
+GEN = os.path.join(CSRC, 'generated' + _sfx)
+OBJ = os.path.join(CSRC, 'build' + _sfx)
 ARCH = 'gfx950'
 STATIC_SOURCES = ['snet_api.cpp', 'snet_gemm.hip', 'snet_mlp.hip', 'snet_edge.hip', 'snet_node.hip', 'snet_force.hip']
 
@@ -46,7 +48,7 @@ def _flags() -> List[str]:
 def _stamp(src: str) -> str:
     h = hashlib.sha1()
     for p in [src, os.path.join(CSRC, 'snet_common.h'), os.path.join(INCLUDE, 'snet_hip.h'),
-              os.path.join(GEN, 'sh_generated.h')]:
+              os.path.join(CSRC, 'generated', 'sh_generated.h')]:
         with open(p, 'rb') as f:
             h.update(f.read())
     h.update(' '.join(_flags()).encode())
@@ -71,7 +73,8 @@ def _compile(src: str, force: bool) -> str:
 def build(jobs: int = 0, force: bool = False, extra_configs=(), verbose: bool = True) -> str:
     os.makedirs(GEN, exist_ok=True)
     os.makedirs(OBJ, exist_ok=True)
-    codegen.write_if_changed(os.path.join(GEN, 'sh_generated.h'), codegen.gen_sh_header(3))
+    os.makedirs(os.path.join(CSRC, 'generated'), exist_ok=True)
+    codegen.write_if_changed(os.path.join(CSRC, 'generated', 'sh_generated.h'), codegen.gen_sh_header(3))
     specs = aot_conv_specs(extra_configs)
     sources = [os.path.join(CSRC, s) for s in STATIC_SOURCES]
     keep = set()

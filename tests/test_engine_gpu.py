@@ -36,7 +36,7 @@ def _compare(eng, out, ref, n, rel=3e-5, check_inter=True):
     """fp32 engine vs fp64 oracle: errors relative to each quantity's scale, never looser than
     the north-star 1e-4 eV/A on forces."""
     _close(out['energy'], ref['energy'].reshape(1), 1e-6, 1e-6 * n, 'energy')
-    _close(out['atomic_energy'], ref['atomic_energy'], rel, 1e-7, 'atomic_energy')
+    _close(out['atomic_energy'], ref['atomic_energy'], rel, 5e-6, 'atomic_energy')
     _close(out['dE_dr'], ref['dE_dr'], rel, 1e-8, 'dE_dr')
     _close(out['forces'], ref['forces'], rel, 1e-8, 'forces')
     assert np.abs(out['forces'].cpu().numpy() - ref['forces'].numpy()).max() < F_TOL * max(1.0, ref['forces'].abs().max().item())

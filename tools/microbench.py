@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Per-kernel timing of the C-ABI entry points at the benchmark's scale (MI355X).
+
+    python tools/microbench.py [--reps 23] [--layer 1] [--iters 5]
+    SNET_HIP_LIB=/path/to/experimental.so python tools/microbench.py     # kernel variants
+
+Times each hot kernel of one interaction layer of the SevenNet-0 shape on the
+~100k-atom Si graph with random features (values do not matter for timing),
+reporting ms and achieved GB/s or TFLOP/s against the algorithmic counts of bench.py.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=23)
+    ap.add_argument('--layer', type=int, default=1)
+    ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--model', default='sevennet_0')
+    a = ap.parse_args()
+    from bench import kernel_model, model_config
+    from sevennet_amd import _lib
+    from sevennet_amd.engine import HipForceEngine, _ptr, _stream, build_graph
+    from sevennet_amd.neighbor import diamond_cubic, neighbor_list
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = model_config(a.model)
+    eng = HipForceEngine(cfg, random_state_dict(cfg, 0))
+    lib = eng.lib
+    pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
+    ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
+    g = build_graph(np.zeros(len(pos), np.int64), ei, ev)
+    N, E = g.n_local, g.n_edges
+    L = eng.layers[a.layer]
+    ls = L.spec
+    dx, dmid, wn, nsh, nb = ls.conv.irreps_x.dim, ls.conv.irreps_out.dim, ls.conv.weight_numel, eng.nsh, eng.spec.n_basis
+    dev = eng.dev
+    rnd = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+    emb, sh, dsh = eng._new(E, nb), eng._new(E, nsh), eng._new(E, nsh * 3)
+    _lib.check(lib.snet_edge_embed_fwd(C.byref(eng.edge_params), eng.coeffs, _ptr(g.edge_vec), E, _ptr(emb), _ptr(sh),
+                                       _ptr(dsh), _stream()))
+    h, w, g_m = rnd(N, dx), rnd(E, wn), rnd(N, dmid)
+    m, g_w, g_vec, g_h, g_emb = eng._new(N, dmid), eng._new(E, wn), torch.zeros(E, 3, device=dev), eng._new(N, dx), torch.zeros(E, nb, device=dev)
+    km = kernel_model(ls, N, E)
+    st = _stream()
+    ops = {
+        f'radial_mlp_fwd[wn={wn}]': lambda: eng._mlp_fwd(L, emb, E),
+        f'conv_fwd[{ls.conv.tag}]': lambda: lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
+        f'conv_bwd_edge[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_edge_vec(L.plan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_vec), st),
+        f'radial_mlp_bwd[wn={wn}]': lambda: eng._mlp_bwd(L, emb, None, g_w, g_emb, E),
+        f'conv_bwd_node[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_node(L.plan, _ptr(sh), _ptr(w), _ptr(g.col_ptr), _ptr(g.eperm), _ptr(g.center), N, L.scale, _ptr(g_m), _ptr(g_h), st),
+        'si2_fwd': lambda: eng._linear(L.si2, m, N, g),
+        'si2_bwd': lambda: eng._linear_T(L.si2, rnd(N, ls.si2.dim_out), N, g),
+    }
+    print(f'lib={_lib.LIB_PATH} N={N} E={E} layer={a.layer} dx={dx} dmid={dmid} wn={wn}')
+    for name, fn in ops.items():
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(a.iters):
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            fn()
+            s1.record()
+            torch.cuda.synchronize()
+            ts.append(s0.elapsed_time(s1))
+        ms = float(np.median(ts))
+        extra = ''
+        if name in km:
+            k = km[name]
+            extra = (f"{k['bytes'] / ms / 1e6:8.1f} GB/s (algorithmic)" if k['bound'] == 'hbm'
+                     else f"{k['flops'] / ms / 1e9:8.2f} TFLOP/s")
+        print(f'{name:34s} {ms:8.3f} ms  {extra}')
+
+
+if __name__ == '__main__':
+    main()
