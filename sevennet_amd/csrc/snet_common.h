@@ -65,6 +65,31 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// ---- cross-lane exchange at VALU speed (no LDS): gfx950 permlane swaps + DPP -------------------
+// a + b where the "low" lanes (bit 5 / bit 4 of the lane id clear) end up with a_self + a_partner
+// and the "high" lanes with b_self + b_partner, partner = lane ^ 32 (resp. ^ 16).
+__device__ __forceinline__ float swap_add32(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// value of lane ^ MASK for MASK in {8, 4, 2, 1} (inside a 16-lane DPP row)
+template <int MASK>
+__device__ __forceinline__ float lane_xor(float v) {
+  const int x = __float_as_int(v);
+  if constexpr (MASK == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false));  // row_ror:8
+  if constexpr (MASK == 4) {
+    int t = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);  // banks 0,2 read lane+4 (row_shl:4)
+    t = __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);      // banks 1,3 read lane-4 (row_shr:4)
+    return __int_as_float(t);
+  }
+  if constexpr (MASK == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false));                            // quad_perm [1,0,3,2]
+}
+
 __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == 0) return z / (1.0f + expf(-z));  // silu
   return tanhf(z);
