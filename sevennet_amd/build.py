@@ -41,7 +41,9 @@ def _hipcc() -> str:
 
 
 def _flags() -> List[str]:
-    return [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC',
+    # -fno-slp-vectorize: SLP packing into v_pk_*_f32 duplicates operands into register pairs and
+    # doubled the VGPR count of the tensor-product kernels (217 -> 115), halving their occupancy
+    return [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fno-slp-vectorize',
             f'-I{INCLUDE}', f'-I{CSRC}']
 
 
