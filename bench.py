@@ -190,6 +190,19 @@ def main():
         roof = dict(bound='mfma', kernel=dominant, achieved=ach, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
                     frac=ach / MFMA_F32_PEAK_TF, traffic=None, avg_ms=avg_ms,
                     algorithmic_flops_per_launch=km['flops'])
+    # HBM bytes per launch from the committed PMC passes of the same workload (profiles/README.md)
+    try:
+        import glob
+        pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))[-1]
+        with open(pmc) as f:
+            tr = json.load(f)
+        key = dominant.replace('conv_bwd_edge[', 'conv_bwd_edge_vec_').replace('conv_fwd[', 'conv_fwd_') \
+            .replace('conv_bwd_node[', 'conv_bwd_node_').rstrip(']')
+        if world == 1 and a.reps == 23 and key in tr:
+            roof['traffic'] = tr[key]['hbm_bytes_per_launch']
+            roof['traffic_source'] = os.path.basename(pmc) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)'
+    except Exception:  # noqa: BLE001
+        pass
     step_ms = dt / a.steps * 1e3
     roof['kernel_ms_per_step'] = {k: round(v / a.steps, 4) for k, v in sorted(totals.items(), key=lambda kv: -kv[1])}
 

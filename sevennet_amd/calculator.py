@@ -1,0 +1,156 @@
+"""ASE-facing host of the HIP force engine: drop-in for `sevenn.calculator.SevenNetCalculator`.
+
+Keeps the reference's calculator surface (sevenn/calculator.py:20-233):
+same constructor keywords, `implemented_properties`, result keys, units and sign
+conventions
+  energy / free_energy  eV
+  energies              per-atom eV
+  forces                eV/A  [N,3]
+  stress                eV/A^3, Voigt (xx,yy,zz,yz,xz,xy) = -model_stress[[0,1,2,4,5,3]]  (:198-203)
+  stresses              per-atom virial, model order xx,yy,zz,xy,yz,zx                  (:212-216)
+  num_edges
+and the same errors (`ValueError` on bad file_type, unknown atomic number, modal misuse).
+ASE itself is optional: without it the class is a plain object whose
+`compute(numbers, positions, cell, pbc)` returns the same results dict.
+"""
+from __future__ import annotations
+
+import os
+import pathlib
+import warnings
+from typing import Any, Dict, Optional, Union
+
+import numpy as np
+import torch
+
+from .engine import HipForceEngine, build_graph
+from .neighbor import neighbor_list
+
+try:  # ASE is not a hard dependency of the engine
+    from ase.calculators.calculator import Calculator, all_changes
+    _HAVE_ASE = True
+except ImportError:  # pragma: no cover - depends on the environment
+    _HAVE_ASE = False
+    all_changes = ['positions', 'numbers', 'cell', 'pbc']
+
+    class Calculator:  # minimal stand-in so the class below is importable without ASE
+        def __init__(self, **kwargs):
+            self.results: Dict[str, Any] = {}
+            self.atoms = None
+
+        def calculate(self, atoms=None, properties=None, system_changes=None):
+            self.atoms = atoms
+
+
+def load_reference_checkpoint(path: str):
+    """(config, state_dict) from a reference checkpoint file (sevenn/checkpoint.py:286-308:
+    a torch pickle holding 'config' and 'model_state_dict').  Old-version weight re-ordering
+    (scripts/backward_compatibility.py) is not implemented: configs older than 0.10 are accepted
+    as long as their tensors match the engine's expected shapes."""
+    cp = torch.load(path, map_location='cpu', weights_only=False)
+    if not isinstance(cp, dict) or 'config' not in cp or 'model_state_dict' not in cp:
+        raise ValueError(f'{path} is not a SevenNet checkpoint (config + model_state_dict expected)')
+    cfg = dict(cp['config'])
+    major, minor = (int(t) for t in str(cfg.get('version', '0.12.0')).split('.')[:2])
+    if major == 0 and minor <= 9:  # patch_old_config, backward_compatibility.py:18-41
+        cfg.setdefault('_normalize_sph', False)
+        cfg.setdefault('conv_denominator', 0.0)
+    sd = {k: v.detach().cpu().numpy() for k, v in cp['model_state_dict'].items() if hasattr(v, 'detach')}
+    return cfg, sd
+
+
+class SevenNetCalculator(Calculator):
+    """Supporting properties: 'free_energy', 'energy', 'forces', 'stress', 'stresses', 'energies'."""
+
+    implemented_properties = ['free_energy', 'energy', 'forces', 'stress', 'stresses', 'energies']
+
+    def __init__(
+        self,
+        model: Union[str, pathlib.PurePath, tuple] = '7net-0',
+        file_type: str = 'checkpoint',
+        device: Union[torch.device, str] = 'auto',
+        modal: Optional[str] = None,
+        enable_cueq: Optional[bool] = False,   # accepted for signature compatibility, ignored:
+        enable_flash: Optional[bool] = False,  # the tensor product always runs in libsnet_hip.so
+        enable_oeq: Optional[bool] = False,
+        compute_atomic_virial: bool = False,
+        sevennet_config: Optional[Dict] = None,
+        **kwargs,
+    ) -> None:
+        super().__init__(**kwargs)
+        self.compute_atomic_virial = compute_atomic_virial
+        if isinstance(model, pathlib.PurePath):
+            model = str(model)
+        allowed_file_types = ['checkpoint', 'model_instance']
+        file_type = file_type.lower()
+        if file_type not in allowed_file_types:
+            if file_type == 'torchscript':
+                raise ValueError('torchscript file_type is no longer supported. '
+                                 'Use checkpoint or model_instance instead.')
+            raise ValueError(f'file_type not in {allowed_file_types}')
+        if isinstance(device, str):
+            device = 'cuda:0' if device in ('auto', 'cuda') else device
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise ValueError('the HIP force engine runs on a ROCm GPU only (device must be cuda:N)')
+
+        if file_type == 'checkpoint' and isinstance(model, str):
+            if not os.path.isfile(model):
+                raise ValueError(f'checkpoint file {model!r} not found (pretrained model names need the '
+                                 'reference package to download/resolve them)')
+            cfg, sd = load_reference_checkpoint(model)
+        elif file_type == 'model_instance' and isinstance(model, tuple) and len(model) == 2:
+            cfg, sd = model  # (config dict, state_dict of arrays)
+        else:
+            raise ValueError('Unexpected input combinations')
+        self.sevennet_config = cfg if cfg is not None else sevennet_config
+        tm = cfg.get('_type_map')
+        if not tm:
+            raise ValueError('Model must have the type_map to be used with calculator')
+        self.type_map = {int(k): int(v) for k, v in tm.items()}
+        self.cutoff = float(cfg['cutoff'])
+        if cfg.get('use_modality'):
+            raise ValueError('multi-modal models are not supported by the HIP engine yet')
+        if modal:
+            warnings.warn(f'modal={modal} is ignored as model has no modal_map')
+        self.modal = None
+        self.model = HipForceEngine(cfg, sd, device=str(self.device))
+        self._z2type = np.full(120, -1, np.int64)  # sequential.py:80-83
+        for z, t in self.type_map.items():
+            self._z2type[z] = t
+
+    def set_atoms(self, atoms) -> None:
+        for z in set(atoms.get_atomic_numbers()):
+            if z not in self.type_map:
+                raise ValueError(f'Model do not know atomic number: {z}, (knows: {list(self.type_map.keys())})')
+
+    def compute(self, numbers, positions, cell, pbc) -> Dict[str, Any]:
+        numbers = np.asarray(numbers, np.int64)
+        types = self._z2type[numbers]
+        if (types < 0).any():
+            bad = sorted(set(numbers[types < 0].tolist()))
+            raise ValueError(f'Model do not know atomic number: {bad[0]}, (knows: {list(self.type_map.keys())})')
+        cell = np.asarray(cell, np.float64).reshape(3, 3)
+        ei, ev, _ = neighbor_list(positions, cell, pbc, self.cutoff)
+        g = build_graph(types, ei, ev, device=str(self.device), num_species=self.model.spec.num_species)
+        out = self.model.compute(g, want_atomic_virial=self.compute_atomic_virial)
+        energy = float(out['energy'].cpu())
+        vol = abs(float(np.linalg.det(cell)))
+        vir = out['virial'].cpu().numpy()  # = -sum(r (x) g): model stress * volume, order xx,yy,zz,xy,yz,zx
+        stress = -(vir / vol)[[0, 1, 2, 4, 5, 3]] if vol > 0 else np.full(6, np.nan)
+        res: Dict[str, Any] = {
+            'free_energy': energy, 'energy': energy,
+            'energies': out['atomic_energy'].cpu().numpy().astype(np.float64),
+            'forces': out['forces'].cpu().numpy().astype(np.float64),
+            'stress': stress, 'num_edges': int(ei.shape[1]),
+        }
+        if self.compute_atomic_virial:
+            res['stresses'] = out['atomic_virial'].cpu().numpy()
+        return res
+
+    def calculate(self, atoms=None, properties=None, system_changes=all_changes):
+        Calculator.calculate(self, atoms, properties, system_changes)
+        if atoms is None:
+            raise ValueError('No atoms to evaluate')
+        self.results = self.compute(atoms.get_atomic_numbers(), atoms.get_positions(),
+                                    np.array(atoms.get_cell()), atoms.get_pbc())

@@ -171,3 +171,29 @@ def test_engine_bricks_equal_single_graph_on_one_gpu(world):
     assert abs(e_tot - float(ref['energy'].cpu())) < 2e-6 * abs(float(ref['energy'].cpu()))
     _close(Ea, ref['atomic_energy'], 1e-5, 1e-7, 'atomic energies (bricks)')
     _close(F, ref['forces'], 2e-5, 1e-8, 'forces (bricks)')
+
+
+def test_calculator_surface_matches_reference_results():
+    """b2 boundary: SevenNetCalculator-compatible results (keys, units, signs, Voigt order) on the
+    fixture produced by the reference's own deployed model; reference errors preserved."""
+    from sevennet_amd.calculator import SevenNetCalculator
+    d, cfg, sd = load_ts_golden('hfo2_12')
+    cfg = dict(cfg, _type_map={72: 0, 8: 1})
+    with pytest.raises(ValueError):
+        SevenNetCalculator((cfg, sd), file_type='torchscript')
+    with pytest.raises(ValueError):
+        SevenNetCalculator('/nonexistent/checkpoint.pth')
+    calc = SevenNetCalculator((cfg, sd), file_type='model_instance', device='cuda:0', compute_atomic_virial=True,
+                              enable_flash=True)
+    assert calc.implemented_properties == ['free_energy', 'energy', 'forces', 'stress', 'stresses', 'energies']
+    numbers = np.where(d['types'] == 0, 72, 8)
+    res = calc.compute(numbers, d['pos'], d['cell'], [True, True, True])
+    assert res['num_edges'] == d['edge_index'].shape[1]
+    assert abs(res['energy'] - float(d['out_energy'])) < 1e-5 * len(numbers)
+    assert res['free_energy'] == res['energy']
+    assert np.abs(res['forces'] - d['out_forces']).max() < F_TOL
+    assert np.abs(res['energies'] - d['out_atomic_energy']).max() < 1e-4
+    assert np.abs(res['stress'] - (-d['out_stress'][[0, 1, 2, 4, 5, 3]])).max() < 1e-5
+    assert res['stresses'].shape == (len(numbers), 6)
+    with pytest.raises(ValueError, match='do not know atomic number'):
+        calc.compute(np.array([14]), np.zeros((1, 3)), d['cell'], [True] * 3)
