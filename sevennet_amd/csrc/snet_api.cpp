@@ -1,6 +1,5 @@
 // C-ABI glue of libsnet_hip.so: error state, compiled-shape registry, conv plans, scratch.
 #include <map>
-#include <mutex>
 #include <vector>
 
 #include "snet_common.h"
@@ -16,14 +15,12 @@ static std::vector<const ConvKernels *> &registry() {
 }
 void register_conv(const ConvKernels *k) { registry().push_back(k); }
 
-// Small per-device scratch for deterministic two-stage reductions (grown on demand, never
-// shrunk).  Reductions on one device are stream-ordered by the hosts of this library (one
-// host thread per device), so a single buffer per device suffices.
+// Small scratch for deterministic two-stage reductions, per host thread and device (grown on
+// demand, never shrunk).  Per-thread because the partial-sum kernel and its final-sum kernel are
+// two launches: two host threads sharing one stream must not interleave on one buffer.
 double *reduce_scratch(int64_t n_doubles, hipStream_t st) {
   (void)st;
-  static std::mutex mu;
-  static std::map<int, std::pair<double *, int64_t>> bufs;
-  std::lock_guard<std::mutex> lk(mu);
+  static thread_local std::map<int, std::pair<double *, int64_t>> bufs;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   auto &b = bufs[dev];
