@@ -43,6 +43,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--reps', type=int, default=23, help='diamond cells per axis (23 -> 97 336 atoms)')
     ap.add_argument('--model', default='sevennet_0', choices=['sevennet_0', 'sevennet_l3i5'])
+    ap.add_argument('--mlp-mode', default='bf16x6', choices=['bf16x6', 'fp32'],
+                    help='radial-MLP MFMA mode: bf16 x6 split products (fp32-class accuracy) or exact fp32 MFMA')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-reps', type=int, default=5, help='CPU-baseline sample: cells per axis (5 -> 1000 atoms)')
     return ap.parse_args()
@@ -125,7 +127,7 @@ def main():
 
     cfg = model_config(a.model)
     sd = random_state_dict(cfg, seed=0)
-    eng = HipForceEngine(cfg, sd, device=dev)
+    eng = HipForceEngine(cfg, sd, device=dev, mlp_mode=a.mlp_mode)
 
     pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
     n_atoms = len(pos)

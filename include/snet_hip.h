@@ -78,14 +78,21 @@ int snet_gemm(const float *A, const float *B, float *C, int64_t n_nodes, int32_t
 
 /* Fused radial MLP, e3nn FullyConnectedNet([nb,h1,h2,wn], act) (convolution.py:93-95,121):
  *   fwd  w[E,wn] = (act(act(emb W0) cst W1) cst) W2          W0[nb,h1] W1[h1,h2] W2[h2,wn]
- *   bwd  g_emb[E,nb] += d<g_w,w>/d emb                        W2T = W2^T [wn,h2]
- * weights row-major with 1/sqrt(fan_in) folded; hidden activations stay in registers (fwd) or are
- * recomputed (bwd).  Only h1 = h2 = 64 and nb <= 32 are fused (rc 2 otherwise: use snet_gemm). */
-int snet_radial_mlp_fwd(const float *emb, int64_t n_edges, int32_t nb, int32_t h1, int32_t h2, int32_t wn,
-                        const float *W0, const float *W1, const float *W2, int32_t act, float cst, float *w_out,
-                        void *stream);
-int snet_radial_mlp_bwd(const float *emb, const float *g_w, int64_t n_edges, int32_t nb, int32_t h1, int32_t h2,
-                        int32_t wn, const float *W0, const float *W1, const float *W2T, int32_t act, float cst,
+ *   bwd  g_emb[E,nb] += d<g_w,w>/d emb
+ * A plan holds device copies of the weights (HOST pointers in, row-major, 1/sqrt(fan_in) already
+ * folded).  Hidden activations stay in registers (fwd) or are recomputed (bwd).
+ *   mode 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain)
+ *   mode 1: bf16 x 6 split products on v_mfma_f32_32x32x16_bf16 (operands written as 3-term bf16
+ *           sums, the six products of order <= 2 accumulated in fp32: fp32-rounding-class error at
+ *           6/16 of the fp32 matrix-pipe time)
+ * Only h1 = h2 = 64 and nb <= 32 are fused (rc 2 otherwise: use snet_gemm + snet_act_*). */
+typedef struct snet_mlp_plan snet_mlp_plan;
+int snet_radial_mlp_plan_create(int32_t nb, int32_t h1, int32_t h2, int32_t wn, const float *W0_host,
+                                const float *W1_host, const float *W2_host, int32_t act, float cst, int32_t mode,
+                                snet_mlp_plan **plan);
+void snet_radial_mlp_plan_destroy(snet_mlp_plan *plan);
+int snet_radial_mlp_fwd(const snet_mlp_plan *plan, const float *emb, int64_t n_edges, float *w_out, void *stream);
+int snet_radial_mlp_bwd(const snet_mlp_plan *plan, const float *emb, const float *g_w, int64_t n_edges,
                         float *g_emb, void *stream);
 
 /* a = act(z)*cst  /  g_z = g_a * cst * act'(z)   (act: 0 silu, 1 tanh);

@@ -39,10 +39,12 @@ SIGNATURES = {
                                       c_f32p, c_f32p, c_stream]),
     'snet_edge_embed_bwd': (C.c_int, [C.POINTER(EdgeParams), C.POINTER(C.c_float), c_f32p, C.c_int64, c_f32p,
                                       c_f32p, c_f32p, C.c_int32, c_stream]),
-    'snet_radial_mlp_fwd': (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p,
-                                      c_f32p, C.c_int32, C.c_float, c_f32p, c_stream]),
-    'snet_radial_mlp_bwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p,
-                                      c_f32p, c_f32p, C.c_int32, C.c_float, c_f32p, c_stream]),
+    'snet_radial_mlp_plan_create': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float),
+                                              C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int32, C.c_float,
+                                              C.c_int32, C.POINTER(C.c_void_p)]),
+    'snet_radial_mlp_plan_destroy': (None, [C.c_void_p]),
+    'snet_radial_mlp_fwd': (C.c_int, [C.c_void_p, c_f32p, C.c_int64, c_f32p, c_stream]),
+    'snet_radial_mlp_bwd': (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int64, c_f32p, c_stream]),
     'snet_conv_bwd_edge_vec': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int64,
                                          C.c_float, c_f32p, c_f32p, c_f32p, c_stream]),
     'snet_gemm': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,

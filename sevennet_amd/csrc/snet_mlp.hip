@@ -13,6 +13,10 @@
 // cross-lane traffic between the layers.  W2 (64 x wn, up to 450 KB) streams from L2 as B fragments
 // (one coalesced 128-B row segment per half-wave per step); the output tile is stored as 128-B row
 // segments of w.
+#include <cstring>
+#include <initializer_list>
+#include <vector>
+
 #include "snet_common.h"
 
 namespace {
@@ -295,32 +299,449 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float *__rest
 
 }  // namespace
 
-extern "C" int snet_radial_mlp_fwd(const float *emb, int64_t E, int32_t nb, int32_t h1, int32_t h2, int32_t wn,
-                                   const float *W0, const float *W1, const float *W2, int32_t act, float cst,
-                                   float *w_out, void *stream) {
-  SNET_REQUIRE(h1 == H && h2 == H, "snet_radial_mlp_fwd: fused kernel needs hidden widths [64, 64]");
-  SNET_REQUIRE(nb >= 1 && nb <= 32 && wn >= 1, "snet_radial_mlp_fwd: need 1 <= n_basis <= 32, wn >= 1");
-  SNET_REQUIRE(act == 0 || act == 1, "snet_radial_mlp_fwd: unknown activation");
+
+// =================================================================================================
+// Split-precision variant: every fp32 operand x is written x = x1 + x2 + x3 with bf16 x1, x2, x3
+// (24 mantissa bits), and a*b is evaluated as the six bf16 products of order <= 2
+// (a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1), each exact in the fp32 accumulator of
+// v_mfma_f32_32x32x16_bf16.  Dropped terms are O(2^-24) relative, i.e. fp32 rounding class, while
+// the matrix pipe runs 16x faster per flop than with fp32 inputs: 6/16 of the fp32-MFMA time.
+// Weights are split and packed into per-lane MFMA fragments once at plan creation.
+// Fragment k-slots follow the same accumulator-order permutation as the fp32 kernels:
+//     MFMA q (16 reduction slots), half = lane>>5, slot i8:  r = 8*(q&1) + i8
+//     hidden index kmap(q, half, i8) = 32*(q>>1) + (r&3) + 8*(r>>2) + 4*half
+// =================================================================================================
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+struct Split3 {
+  bf16x8 t[3];
+};
+
+__device__ __forceinline__ Split3 split8(const float (&v)[8]) {
+  union U {
+    bf16x8 v8;
+    bf16x2 v2[4];
+  } h, m, l;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const f32x2 x = {v[2 * p], v[2 * p + 1]};
+    const bf16x2 xh = __builtin_convertvector(x, bf16x2);
+    const f32x2 r1 = x - __builtin_convertvector(xh, f32x2);
+    const bf16x2 xm = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(xm, f32x2);
+    h.v2[p] = xh;
+    m.v2[p] = xm;
+    l.v2[p] = __builtin_convertvector(r2, bf16x2);
+  }
+  Split3 s;
+  s.t[0] = h.v8;
+  s.t[1] = m.v8;
+  s.t[2] = l.v8;
+  return s;
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const uint4 u) {
+  union {
+    uint4 u;
+    bf16x8 b;
+  } c;
+  c.u = u;
+  return c.b;
+}
+
+// acc += A * B with both operands given as 3-term splits (A from packed fragments a[0..2])
+__device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const Split3 &b, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.t[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b.t[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b.t[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.t[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b.t[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.t[0], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f32x16 mfma6(const Split3 &a, const bf16x8 (&b)[3], f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b[0], acc, 0, 0, 0);
+  return acc;
+}
+
+// fragment index helper: packed arrays are [..][term(3)][lane(64)] of uint4
+__device__ __forceinline__ void load_frag3(const uint4 *__restrict__ base, int frag, int lane, bf16x8 (&out)[3]) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) out[t] = as_bf16x8(base[(frag * 3 + t) * 64 + lane]);
+}
+
+// z1 (fp32 MFMA, K = nb) and z2 (split MFMA) in the transposed layout
+__device__ __forceinline__ void hidden_forward_split(const float *__restrict__ emb, int64_t e_lane, bool e_ok, int nb,
+                                                     const float *__restrict__ W0, const uint4 *__restrict__ W1A,
+                                                     int act, float cst, int lane, f32x16 (&z1)[2],
+                                                     f32x16 (&z2)[2]) {
+  const int half = lane >> 5, li = lane & 31;
+  z1[0] = zero16();
+  z1[1] = zero16();
+  for (int s = 0; 2 * s < nb; ++s) {
+    const int k = 2 * s + half;
+    const float b = (e_ok && k < nb) ? emb[e_lane * nb + k] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float a = (k < nb) ? W0[k * H + 32 * t + li] : 0.f;
+      z1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, z1[t], 0, 0, 0);
+    }
+  }
+  z2[0] = zero16();
+  z2[1] = zero16();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = snet::act_fwd(z1[q >> 1][8 * (q & 1) + i], act) * cst;
+    const Split3 b = split8(v);
+#pragma unroll
+    for (int to = 0; to < 2; ++to) {
+      bf16x8 a[3];
+      load_frag3(W1A, to * 4 + q, lane, a);
+      z2[to] = mfma6(a, b, z2[to]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void radial_mlp_fwd_split_kernel(const float *__restrict__ emb, int64_t E, int nb,
+                                                                   int wn, const float *__restrict__ W0,
+                                                                   const uint4 *__restrict__ W1A,
+                                                                   const uint4 *__restrict__ W2B, int act, float cst,
+                                                                   float *__restrict__ w_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, li = lane & 31;
+  const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  if (e0 >= E) return;
+  const int64_t e_lane = e0 + li;
+  const bool e_ok = e_lane < E;
+  f32x16 z1[2], z2[2];
+  hidden_forward_split(emb, e_lane, e_ok, nb, W0, W1A, act, cst, lane, z1, z2);
+  Split3 a2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = snet::act_fwd(z2[q >> 1][8 * (q & 1) + i], act) * cst;
+    a2[q] = split8(v);
+  }
+  const int n_tiles = (wn + 31) >> 5;
+  bf16x8 bcur[4][3], bnxt[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) load_frag3(W2B, q, lane, bcur[q]);
+  for (int c = 0; c < n_tiles; ++c) {
+    if (c + 1 < n_tiles) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) load_frag3(W2B, (c + 1) * 4 + q, lane, bnxt[q]);
+    }
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = mfma6(a2[q], bcur[q], acc);
+    const int ch = 32 * c + li;
+    if (ch < wn) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t e = e0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (e < E) w_out[e * wn + ch] = acc[r];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) bcur[q][t] = bnxt[q][t];
+  }
+}
+
+constexpr int GS_STRIDE = 36;               // g_w tile row stride (floats): conflict-free 16-B column reads
+constexpr int GS_TILE = 32 * GS_STRIDE;
+constexpr int SLAB_U4 = 2 * 2 * 3 * 64;     // uint4 per 32-channel slab of W2A: [step(2)][tile(2)][term(3)][lane]
+
+__global__ __launch_bounds__(256) void radial_mlp_bwd_split_kernel(
+    const float *__restrict__ emb, const float *__restrict__ g_w, int64_t E, int nb, int wn,
+    const float *__restrict__ W0, const uint4 *__restrict__ W1A, const uint4 *__restrict__ W2A,
+    const uint4 *__restrict__ W1A2, const uint4 *__restrict__ W0A, int act, float cst, float *__restrict__ g_emb) {
+  __shared__ float gws[4 * GS_TILE];
+  __shared__ uint4 slab[2][SLAB_U4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, li = lane & 31;
+  const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const bool wave_ok = e0 < E;
+  const int64_t e_lane = e0 + li;
+  const bool e_ok = wave_ok && e_lane < E;
+  float *tile = gws + wave * GS_TILE;
+  const bool vec_ok = (wn & 3) == 0;
+  const int srow = lane >> 3, scol = 4 * (lane & 7);
+  const int n_chunks = (wn + CH - 1) / CH;
+
+  float4 st_g[4];
+  uint4 st_w[3];
+  auto load_chunk = [&](int ck) {
+    const int c0 = ck * CH;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t e = e0 + 8 * i + srow;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (wave_ok && e < E && c0 + scol < wn) {
+        const float *p = g_w + e * wn + c0 + scol;
+        if (vec_ok && c0 + scol + 3 < wn) {
+          q = *reinterpret_cast<const float4 *>(p);
+        } else {
+          q.x = p[0];
+          if (c0 + scol + 1 < wn) q.y = p[1];
+          if (c0 + scol + 2 < wn) q.z = p[2];
+          if (c0 + scol + 3 < wn) q.w = p[3];
+        }
+      }
+      st_g[i] = q;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st_w[i] = W2A[(int64_t)ck * SLAB_U4 + tid + 256 * i];  // slab = 768 uint4
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float4 *>(tile + (8 * i + srow) * GS_STRIDE + scol) = st_g[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) slab[buf][tid + 256 * i] = st_w[i];
+  };
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  f32x16 z1[2], z2[2];
+  hidden_forward_split(emb, e_ok ? e_lane : 0, e_ok, nb, W0, W1A, act, cst, lane, z1, z2);
+
+  // G_a2^T[k, e] = sum_ch W2'[k][ch] g_w[e][ch]
+  f32x16 ga2[2];
+  ga2[0] = zero16();
+  ga2[1] = zero16();
+  int buf = 0;
+  for (int ck = 0; ck < n_chunks; ++ck) {
+    const bool more = ck + 1 < n_chunks;
+    if (more) load_chunk(ck + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float v[8];
+      const float4 lo4 = *reinterpret_cast<const float4 *>(tile + li * GS_STRIDE + 16 * s + 8 * half);
+      const float4 hi4 = *reinterpret_cast<const float4 *>(tile + li * GS_STRIDE + 16 * s + 8 * half + 4);
+      v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w;
+      v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+      const Split3 b = split8(v);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8 a[3];
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm) a[tm] = as_bf16x8(slab[buf][((s * 2 + t) * 3 + tm) * 64 + lane]);
+        ga2[t] = mfma6(a, b, ga2[t]);
+      }
+    }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // g_z2, then G_a1^T[h, e] = sum_h' W1'[h][h'] g_z2[e][h']
+  f32x16 ga1[2];
+  ga1[0] = zero16();
+  ga1[1] = zero16();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 8 * (q & 1) + i;
+      v[i] = ga2[q >> 1][r] * cst * snet::act_grad(z2[q >> 1][r], act);
+    }
+    const Split3 b = split8(v);
+#pragma unroll
+    for (int to = 0; to < 2; ++to) {
+      bf16x8 a[3];
+      load_frag3(W1A2, to * 4 + q, lane, a);
+      ga1[to] = mfma6(a, b, ga1[to]);
+    }
+  }
+  // g_z1, then G_emb^T[k0, e] = sum_h W0'[k0][h] g_z1[e][h]
+  f32x16 ge = zero16();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 8 * (q & 1) + i;
+      v[i] = ga1[q >> 1][r] * cst * snet::act_grad(z1[q >> 1][r], act);
+    }
+    const Split3 b = split8(v);
+    bf16x8 a[3];
+    load_frag3(W0A, q, lane, a);
+    ge = mfma6(a, b, ge);
+  }
+  if (e_ok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k0 = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (k0 < nb) g_emb[e_lane * nb + k0] += ge[r];
+    }
+  }
+}
+
+}  // namespace
+
+// ---- plan: device copies of the (pre-normalised) weights, fp32 and split/packed -----------------
+struct snet_mlp_plan {
+  int nb, wn, act, mode;
+  float cst;
+  float *W0 = nullptr, *W1 = nullptr, *W2 = nullptr, *W2T = nullptr;               // fp32 mode
+  uint4 *W1A = nullptr, *W2B = nullptr, *W2A = nullptr, *W1A2 = nullptr, *W0A = nullptr;  // split mode
+};
+
+namespace {
+
+inline uint16_t bf16_rne(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float bf16_f(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline void split3(float x, uint16_t (&o)[3]) {
+  o[0] = bf16_rne(x);
+  const float r1 = x - bf16_f(o[0]);
+  o[1] = bf16_rne(r1);
+  o[2] = bf16_rne(r1 - bf16_f(o[1]));
+}
+inline int kmap(int q, int half, int i8) {
+  const int r = 8 * (q & 1) + i8;
+  return 32 * (q >> 1) + (r & 3) + 8 * (r >> 2) + 4 * half;
+}
+// frags[(frag*3 + term)*64 + lane][8] <- value(frag, lane, i8)
+template <class F>
+std::vector<uint16_t> pack_frags(int n_frag, F value) {
+  std::vector<uint16_t> out((size_t)n_frag * 3 * 64 * 8);
+  for (int f = 0; f < n_frag; ++f)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int i = 0; i < 8; ++i) {
+        uint16_t s[3];
+        split3(value(f, lane, i), s);
+        for (int t = 0; t < 3; ++t) out[(((size_t)f * 3 + t) * 64 + lane) * 8 + i] = s[t];
+      }
+  return out;
+}
+template <class T>
+int upload(const std::vector<T> &h, void **dev) {
+  if (hipMalloc(dev, h.size() * sizeof(T)) != hipSuccess) return 1;
+  return hipMemcpy(*dev, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess;
+}
+
+}  // namespace
+
+extern "C" int snet_radial_mlp_plan_create(int32_t nb, int32_t h1, int32_t h2, int32_t wn, const float *W0_host,
+                                           const float *W1_host, const float *W2_host, int32_t act, float cst,
+                                           int32_t mode, snet_mlp_plan **plan) {
+  SNET_REQUIRE(plan != nullptr && W0_host && W1_host && W2_host, "snet_radial_mlp_plan_create: null argument");
+  SNET_REQUIRE(h1 == H && h2 == H, "snet_radial_mlp_plan_create: fused kernels need hidden widths [64, 64]");
+  SNET_REQUIRE(nb >= 1 && nb <= 32 && wn >= 1, "snet_radial_mlp_plan_create: need 1 <= n_basis <= 32, wn >= 1");
+  SNET_REQUIRE(act == 0 || act == 1, "snet_radial_mlp_plan_create: unknown activation");
+  SNET_REQUIRE(mode == 0 || mode == 1, "snet_radial_mlp_plan_create: mode 0 (fp32 MFMA) or 1 (bf16 x6 split)");
+  auto *p = new snet_mlp_plan;
+  p->nb = nb; p->wn = wn; p->act = act; p->mode = mode; p->cst = cst;
+  const std::vector<float> w0(W0_host, W0_host + (size_t)nb * H), w1(W1_host, W1_host + (size_t)H * H),
+      w2(W2_host, W2_host + (size_t)H * wn);
+  int bad = upload(w0, (void **)&p->W0);
+  if (mode == 0) {
+    std::vector<float> w2t((size_t)wn * H);
+    for (int k = 0; k < H; ++k)
+      for (int c = 0; c < wn; ++c) w2t[(size_t)c * H + k] = w2[(size_t)k * wn + c];
+    bad |= upload(w1, (void **)&p->W1) | upload(w2, (void **)&p->W2) | upload(w2t, (void **)&p->W2T);
+  } else {
+    const int n_tiles = (wn + 31) / 32, n_chunks = (wn + CH - 1) / CH;
+    // forward L2:  A[i = h'][k = h] = W1'[h][h'], frag = to*4 + q
+    bad |= upload(pack_frags(8, [&](int f, int lane, int i) {
+                    const int to = f >> 2, q = f & 3;
+                    return w1[(size_t)kmap(q, lane >> 5, i) * H + 32 * to + (lane & 31)];
+                  }), (void **)&p->W1A);
+    // forward L3:  B[k = h][j = ch] = W2'[h][ch], frag = c*4 + q
+    bad |= upload(pack_frags(n_tiles * 4, [&](int f, int lane, int i) {
+                    const int c = f >> 2, q = f & 3, ch = 32 * c + (lane & 31);
+                    return ch < wn ? w2[(size_t)kmap(q, lane >> 5, i) * wn + ch] : 0.f;
+                  }), (void **)&p->W2B);
+    // backward G_a2:  A[i = k][kk = ch] = W2'[k][ch], frag = (chunk*2 + step)*2 + tile, ch natural order
+    bad |= upload(pack_frags(n_chunks * 4, [&](int f, int lane, int i) {
+                    const int t = f & 1, s = (f >> 1) & 1, ck = f >> 2;
+                    const int ch = ck * CH + 16 * s + 8 * (lane >> 5) + i;
+                    return ch < wn ? w2[(size_t)(32 * t + (lane & 31)) * wn + ch] : 0.f;
+                  }), (void **)&p->W2A);
+    // backward G_a1:  A[i = h][k = h'] = W1'[h][h'], frag = to*4 + q
+    bad |= upload(pack_frags(8, [&](int f, int lane, int i) {
+                    const int to = f >> 2, q = f & 3;
+                    return w1[(size_t)(32 * to + (lane & 31)) * H + kmap(q, lane >> 5, i)];
+                  }), (void **)&p->W1A2);
+    // backward G_emb:  A[i = k0][k = h] = W0'[k0][h], frag = q
+    bad |= upload(pack_frags(4, [&](int f, int lane, int i) {
+                    const int k0 = lane & 31;
+                    return k0 < nb ? w0[(size_t)k0 * H + kmap(f, lane >> 5, i)] : 0.f;
+                  }), (void **)&p->W0A);
+  }
+  if (bad) {
+    snet::set_error("snet_radial_mlp_plan_create: device allocation / upload failed");
+    delete p;
+    return 1;
+  }
+  *plan = p;
+  return 0;
+}
+
+extern "C" void snet_radial_mlp_plan_destroy(snet_mlp_plan *p) {
+  if (!p) return;
+  for (void *d : {(void *)p->W0, (void *)p->W1, (void *)p->W2, (void *)p->W2T, (void *)p->W1A, (void *)p->W2B,
+                  (void *)p->W2A, (void *)p->W1A2, (void *)p->W0A})
+    if (d) (void)hipFree(d);
+  delete p;
+}
+
+extern "C" int snet_radial_mlp_fwd(const snet_mlp_plan *p, const float *emb, int64_t E, float *w_out, void *stream) {
+  SNET_REQUIRE(p != nullptr, "snet_radial_mlp_fwd: null plan");
   if (E <= 0) return 0;
   const int64_t grid = (E + 127) / 128;
   SNET_REQUIRE(grid < (1ll << 31), "snet_radial_mlp_fwd: too many edges");
-  radial_mlp_fwd_kernel<<<(unsigned)grid, 256, 0, static_cast<hipStream_t>(stream)>>>(emb, E, nb, wn, W0, W1, W2, act,
-                                                                                       cst, w_out);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p->mode == 0)
+    radial_mlp_fwd_kernel<<<(unsigned)grid, 256, 0, st>>>(emb, E, p->nb, p->wn, p->W0, p->W1, p->W2, p->act, p->cst,
+                                                          w_out);
+  else
+    radial_mlp_fwd_split_kernel<<<(unsigned)grid, 256, 0, st>>>(emb, E, p->nb, p->wn, p->W0, p->W1A, p->W2B, p->act,
+                                                                p->cst, w_out);
   SNET_CHECK_LAUNCH("snet_radial_mlp_fwd");
   return 0;
 }
 
-extern "C" int snet_radial_mlp_bwd(const float *emb, const float *g_w, int64_t E, int32_t nb, int32_t h1, int32_t h2,
-                                   int32_t wn, const float *W0, const float *W1, const float *W2T, int32_t act,
-                                   float cst, float *g_emb, void *stream) {
-  SNET_REQUIRE(h1 == H && h2 == H, "snet_radial_mlp_bwd: fused kernel needs hidden widths [64, 64]");
-  SNET_REQUIRE(nb >= 1 && nb <= 32 && wn >= 1, "snet_radial_mlp_bwd: need 1 <= n_basis <= 32, wn >= 1");
-  SNET_REQUIRE(act == 0 || act == 1, "snet_radial_mlp_bwd: unknown activation");
+extern "C" int snet_radial_mlp_bwd(const snet_mlp_plan *p, const float *emb, const float *g_w, int64_t E,
+                                   float *g_emb, void *stream) {
+  SNET_REQUIRE(p != nullptr, "snet_radial_mlp_bwd: null plan");
   if (E <= 0) return 0;
   const int64_t grid = (E + 127) / 128;
   SNET_REQUIRE(grid < (1ll << 31), "snet_radial_mlp_bwd: too many edges");
-  radial_mlp_bwd_kernel<<<(unsigned)grid, 256, 0, static_cast<hipStream_t>(stream)>>>(emb, g_w, E, nb, wn, W0, W1, W2T,
-                                                                                       act, cst, g_emb);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p->mode == 0)
+    radial_mlp_bwd_kernel<<<(unsigned)grid, 256, 0, st>>>(emb, g_w, E, p->nb, p->wn, p->W0, p->W1, p->W2T, p->act,
+                                                          p->cst, g_emb);
+  else
+    radial_mlp_bwd_split_kernel<<<(unsigned)grid, 256, 0, st>>>(emb, g_w, E, p->nb, p->wn, p->W0, p->W1A, p->W2A,
+                                                                p->W1A2, p->W0A, p->act, p->cst, g_emb);
   SNET_CHECK_LAUNCH("snet_radial_mlp_bwd");
   return 0;
 }

@@ -122,7 +122,12 @@ class _Span:
 
 
 class HipForceEngine:
-    def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0'):
+    def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6'):
+        """mlp_mode: 'bf16x6' (split-precision MFMA, fp32-class accuracy, default) or 'fp32'
+        (exact fp32 MFMA) for the fused radial MLP."""
+        if mlp_mode not in ('bf16x6', 'fp32'):
+            raise ValueError("mlp_mode must be 'bf16x6' or 'fp32'")
+        self.mlp_mode = mlp_mode
         self.events = None  # set to [] to collect (name, start, end) HIP events per kernel class
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -161,6 +166,18 @@ class HipForceEngine:
                     L.mlp_wt.append(torch.from_numpy(np.ascontiguousarray(w.T, dtype=np.float32)).to(self.dev))
                 L.fused_mlp = (len(ls.mlp_dims) == 4 and ls.mlp_dims[1] == 64 and ls.mlp_dims[2] == 64
                                and ls.mlp_dims[0] <= 32)
+                L.mlp_plan = None
+                if L.fused_mlp:
+                    d = ls.mlp_dims
+                    hw = [np.ascontiguousarray(sd[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] / np.sqrt(d[i]),
+                                               dtype=np.float32) for i in range(3)]
+                    fp = [w.ctypes.data_as(C.POINTER(C.c_float)) for w in hw]
+                    mp = C.c_void_p()
+                    _lib.check(self.lib.snet_radial_mlp_plan_create(d[0], d[1], d[2], d[3], fp[0], fp[1], fp[2],
+                                                                    ACT_ID[sp.act_radial], ACT_CST[sp.act_radial],
+                                                                    1 if mlp_mode == 'bf16x6' else 0, C.byref(mp)),
+                               'snet_radial_mlp_plan_create')
+                    L.mlp_plan = mp
                 L.scale = 1.0 / float(sd[f'{ls.t}_convolution.denominator'][0])
                 plan = C.c_void_p()
                 _lib.check(self.lib.snet_conv_plan_create(ls.conv.tag.encode(), C.byref(plan)), 'snet_conv_plan_create')
@@ -187,6 +204,8 @@ class HipForceEngine:
         try:
             for L in getattr(self, 'layers', []):
                 self.lib.snet_conv_plan_destroy(L.plan)
+                if getattr(L, 'mlp_plan', None) is not None:
+                    self.lib.snet_radial_mlp_plan_destroy(L.mlp_plan)
         except Exception:
             pass
 
@@ -258,9 +277,7 @@ class HipForceEngine:
         dims = L.spec.mlp_dims
         if L.fused_mlp:
             w = self._new(E, dims[3])
-            _lib.check(self.lib.snet_radial_mlp_fwd(_ptr(emb), E, dims[0], dims[1], dims[2], dims[3], _ptr(L.mlp_w[0]),
-                                                    _ptr(L.mlp_w[1]), _ptr(L.mlp_w[2]), self.act_radial, self.act_cst,
-                                                    _ptr(w), _stream()), 'snet_radial_mlp_fwd')
+            _lib.check(self.lib.snet_radial_mlp_fwd(L.mlp_plan, _ptr(emb), E, _ptr(w), _stream()), 'snet_radial_mlp_fwd')
             return w, None
         zs, a = [], emb
         for i, wm in enumerate(L.mlp_w):
@@ -278,9 +295,7 @@ class HipForceEngine:
     def _mlp_bwd(self, L, emb, zs, g_w, g_emb_total, E):
         dims = L.spec.mlp_dims
         if L.fused_mlp:
-            _lib.check(self.lib.snet_radial_mlp_bwd(_ptr(emb), _ptr(g_w), E, dims[0], dims[1], dims[2], dims[3],
-                                                    _ptr(L.mlp_w[0]), _ptr(L.mlp_w[1]), _ptr(L.mlp_wt[2]),
-                                                    self.act_radial, self.act_cst, _ptr(g_emb_total), _stream()),
+            _lib.check(self.lib.snet_radial_mlp_bwd(L.mlp_plan, _ptr(emb), _ptr(g_w), E, _ptr(g_emb_total), _stream()),
                        'snet_radial_mlp_bwd')
             return
         g = g_w

@@ -51,32 +51,39 @@ def test_gemm_vs_torch(shape):
     assert C2[mask].abs().max() == 0
 
 
+@pytest.mark.parametrize('mode', [0, 1])
 @pytest.mark.parametrize('nb,wn,E', [(8, 960, 5000), (8, 224, 333), (8, 12, 100), (12, 60, 257), (8, 384, 128)])
-def test_fused_radial_mlp_vs_torch(nb, wn, E):
+def test_fused_radial_mlp_vs_torch(nb, wn, E, mode):
+    """mode 0 = exact fp32 MFMA, mode 1 = bf16 x 6 split products: both against an fp64 reference"""
     L, lib = _lib()
     dev = 'cuda:0'
     g = torch.Generator().manual_seed(2)
     emb = torch.randn(E, nb, generator=g).to(dev)
-    W0 = (torch.randn(nb, 64, generator=g) / nb ** 0.5).to(dev)
-    W1 = (torch.randn(64, 64, generator=g) / 8).to(dev)
-    W2 = (torch.randn(64, wn, generator=g) / 8).to(dev)
+    W0 = (torch.randn(nb, 64, generator=g) / nb ** 0.5).contiguous()
+    W1 = (torch.randn(64, 64, generator=g) / 8).contiguous()
+    W2 = (torch.randn(64, wn, generator=g) / 8).contiguous()
     cst = 1.6791767923989418
+    fp = lambda t: t.numpy().ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    plan = C.c_void_p()
+    L.check(lib.snet_radial_mlp_plan_create(nb, 64, 64, wn, fp(W0), fp(W1), fp(W2), 0, cst, mode, C.byref(plan)))
     w = torch.empty(E, wn, device=dev)
-    L.check(lib.snet_radial_mlp_fwd(_p(emb), E, nb, 64, 64, wn, _p(W0), _p(W1), _p(W2), 0, cst, _p(w), None))
+    L.check(lib.snet_radial_mlp_fwd(plan, _p(emb), E, _p(w), None))
     torch.cuda.synchronize()
-    e64 = emb.double().requires_grad_(True)
+    e64 = emb.double().cpu().requires_grad_(True)
     a1 = torch.nn.functional.silu(e64 @ W0.double()) * cst
     a2 = torch.nn.functional.silu(a1 @ W1.double()) * cst
     ref = a2 @ W2.double()
-    assert (w.double() - ref).abs().max() < 2e-5 * ref.abs().max()
-    gw = torch.randn(E, wn, generator=g).to(dev)
+    assert (w.cpu().double() - ref).abs().max() < 5e-6 * ref.abs().max()
+    gw = torch.randn(E, wn, generator=g)
     (gref,) = torch.autograd.grad(ref, e64, gw.double())
+    gwd = gw.to(dev)
     g_emb = torch.ones(E, nb, device=dev)  # accumulates
-    W2T = W2.t().contiguous()
-    L.check(lib.snet_radial_mlp_bwd(_p(emb), _p(gw), E, nb, 64, 64, wn, _p(W0), _p(W1), _p(W2T), 0, cst,
-                                    _p(g_emb), None))
+    L.check(lib.snet_radial_mlp_bwd(plan, _p(emb), _p(gwd), E, _p(g_emb), None))
     torch.cuda.synchronize()
-    assert (g_emb.double() - 1.0 - gref).abs().max() < 3e-5 * gref.abs().max()
+    assert (g_emb.cpu().double() - 1.0 - gref).abs().max() < 1e-5 * gref.abs().max()
+    lib.snet_radial_mlp_plan_destroy(plan)
+    with pytest.raises(RuntimeError):
+        L.check(lib.snet_radial_mlp_plan_create(nb, 32, 64, wn, fp(W0), fp(W1), fp(W2), 0, cst, mode, C.byref(plan)))
 
 
 @pytest.mark.parametrize('lmax,normalize,kind', [(1, 0, 0), (2, 0, 1), (2, 1, 0), (3, 1, 0), (3, 0, 1)])

@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--layer', type=int, default=1)
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--model', default='sevennet_0')
+    ap.add_argument('--mlp-mode', default='bf16x6')
     a = ap.parse_args()
     from bench import kernel_model, model_config
     from sevennet_amd import _lib
@@ -33,7 +34,7 @@ def main():
     from sevennet_amd.neighbor import diamond_cubic, neighbor_list
     from sevennet_amd.synthetic import random_state_dict
     cfg = model_config(a.model)
-    eng = HipForceEngine(cfg, random_state_dict(cfg, 0))
+    eng = HipForceEngine(cfg, random_state_dict(cfg, 0), mlp_mode=a.mlp_mode)
     lib = eng.lib
     pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
     ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
