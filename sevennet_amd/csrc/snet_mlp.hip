@@ -413,19 +413,30 @@ __device__ __forceinline__ void hidden_forward_split(const float *__restrict__ e
   }
 }
 
+constexpr int W2B_TILE_U4 = 4 * 3 * 64;  // uint4 per 32-column tile of W2B: [q(4)][term(3)][lane]
+
 __global__ __launch_bounds__(256) void radial_mlp_fwd_split_kernel(const float *__restrict__ emb, int64_t E, int nb,
                                                                    int wn, const float *__restrict__ W0,
                                                                    const uint4 *__restrict__ W1A,
                                                                    const uint4 *__restrict__ W2B, int act, float cst,
                                                                    float *__restrict__ w_out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // W2 fragments are shared by the 4 waves: one 12-KB slab per 32-column tile, double buffered
+  // (cuts the L2 -> CU fragment traffic 4x relative to per-wave loads)
+  __shared__ uint4 slab[2][W2B_TILE_U4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, li = lane & 31;
   const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-  if (e0 >= E) return;
+  const bool wave_ok = e0 < E;  // all waves stay for the block barriers
   const int64_t e_lane = e0 + li;
-  const bool e_ok = e_lane < E;
+  const bool e_ok = wave_ok && e_lane < E;
+  const int n_tiles = (wn + 31) >> 5;
+  uint4 st[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) slab[0][tid + 256 * i] = W2B[tid + 256 * i];
+  __syncthreads();
   f32x16 z1[2], z2[2];
-  hidden_forward_split(emb, e_lane, e_ok, nb, W0, W1A, act, cst, lane, z1, z2);
+  hidden_forward_split(emb, e_ok ? e_lane : 0, e_ok, nb, W0, W1A, act, cst, lane, z1, z2);
   Split3 a2[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -434,30 +445,35 @@ __global__ __launch_bounds__(256) void radial_mlp_fwd_split_kernel(const float *
     for (int i = 0; i < 8; ++i) v[i] = snet::act_fwd(z2[q >> 1][8 * (q & 1) + i], act) * cst;
     a2[q] = split8(v);
   }
-  const int n_tiles = (wn + 31) >> 5;
-  bf16x8 bcur[4][3], bnxt[4][3];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) load_frag3(W2B, q, lane, bcur[q]);
+  int buf = 0;
   for (int c = 0; c < n_tiles; ++c) {
-    if (c + 1 < n_tiles) {
+    const bool more = c + 1 < n_tiles;
+    if (more) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) load_frag3(W2B, (c + 1) * 4 + q, lane, bnxt[q]);
+      for (int i = 0; i < 3; ++i) st[i] = W2B[(int64_t)(c + 1) * W2B_TILE_U4 + tid + 256 * i];
     }
     f32x16 acc = zero16();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc = mfma6(a2[q], bcur[q], acc);
+    for (int q = 0; q < 4; ++q) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) b[t] = as_bf16x8(slab[buf][(q * 3 + t) * 64 + lane]);
+      acc = mfma6(a2[q], b, acc);
+    }
     const int ch = 32 * c + li;
-    if (ch < wn) {
+    if (wave_ok && ch < wn) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t e = e0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (e < E) w_out[e * wn + ch] = acc[r];
       }
     }
+    if (more) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int t = 0; t < 3; ++t) bcur[q][t] = bnxt[q][t];
+      for (int i = 0; i < 3; ++i) slab[buf ^ 1][tid + 256 * i] = st[i];
+    }
+    __syncthreads();
+    buf ^= 1;
   }
 }
 
@@ -465,7 +481,7 @@ constexpr int GS_STRIDE = 36;               // g_w tile row stride (floats): con
 constexpr int GS_TILE = 32 * GS_STRIDE;
 constexpr int SLAB_U4 = 2 * 2 * 3 * 64;     // uint4 per 32-channel slab of W2A: [step(2)][tile(2)][term(3)][lane]
 
-__global__ __launch_bounds__(256) void radial_mlp_bwd_split_kernel(
+__global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(
     const float *__restrict__ emb, const float *__restrict__ g_w, int64_t E, int nb, int wn,
     const float *__restrict__ W0, const uint4 *__restrict__ W1A, const uint4 *__restrict__ W2A,
     const uint4 *__restrict__ W1A2, const uint4 *__restrict__ W0A, int act, float cst, float *__restrict__ g_emb) {
@@ -483,9 +499,10 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_split_kernel(
   const int srow = lane >> 3, scol = 4 * (lane & 7);
   const int n_chunks = (wn + CH - 1) / CH;
 
-  float4 st_g[4];
-  uint4 st_w[3];
-  auto load_chunk = [&](int ck) {
+  // two chunks in flight in registers (HBM latency exceeds one 24-MFMA chunk): stage[ck & 1]
+  float4 st_g[2][4];
+  uint4 st_w[2][3];
+  auto load_chunk = [&](int ck, int sl) {
     const int c0 = ck * CH;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -502,21 +519,22 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_split_kernel(
           if (c0 + scol + 3 < wn) q.w = p[3];
         }
       }
-      st_g[i] = q;
+      st_g[sl][i] = q;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) st_w[i] = W2A[(int64_t)ck * SLAB_U4 + tid + 256 * i];  // slab = 768 uint4
+    for (int i = 0; i < 3; ++i) st_w[sl][i] = W2A[(int64_t)ck * SLAB_U4 + tid + 256 * i];  // slab = 768 uint4
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, int sl) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4 *>(tile + (8 * i + srow) * GS_STRIDE + scol) = st_g[i];
+      *reinterpret_cast<float4 *>(tile + (8 * i + srow) * GS_STRIDE + scol) = st_g[sl][i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) slab[buf][tid + 256 * i] = st_w[i];
+    for (int i = 0; i < 3; ++i) slab[buf][tid + 256 * i] = st_w[sl][i];
   };
 
-  load_chunk(0);
-  store_chunk(0);
+  load_chunk(0, 0);
+  if (n_chunks > 1) load_chunk(1, 1);
+  store_chunk(0, 0);
   __syncthreads();
 
   f32x16 z1[2], z2[2];
@@ -526,10 +544,10 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_split_kernel(
   f32x16 ga2[2];
   ga2[0] = zero16();
   ga2[1] = zero16();
-  int buf = 0;
-  for (int ck = 0; ck < n_chunks; ++ck) {
-    const bool more = ck + 1 < n_chunks;
-    if (more) load_chunk(ck + 1);
+  // iteration ck: (start) refill the register stage that held chunk ck with chunk ck+2;
+  // (end) move chunk ck+1 from its stage into the LDS tile / the other slab buffer.
+  auto chunk_body = [&](int ck, int par) {  // par = ck & 1, passed as a literal so stages are static
+    if (ck + 2 < n_chunks) load_chunk(ck + 2, par);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       float v[8];
@@ -542,13 +560,16 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_split_kernel(
       for (int t = 0; t < 2; ++t) {
         bf16x8 a[3];
 #pragma unroll
-        for (int tm = 0; tm < 3; ++tm) a[tm] = as_bf16x8(slab[buf][((s * 2 + t) * 3 + tm) * 64 + lane]);
+        for (int tm = 0; tm < 3; ++tm) a[tm] = as_bf16x8(slab[par][((s * 2 + t) * 3 + tm) * 64 + lane]);
         ga2[t] = mfma6(a, b, ga2[t]);
       }
     }
-    if (more) store_chunk(buf ^ 1);
+    if (ck + 1 < n_chunks) store_chunk(par ^ 1, par ^ 1);
     __syncthreads();
-    buf ^= 1;
+  };
+  for (int ck = 0; ck < n_chunks; ck += 2) {
+    chunk_body(ck, 0);
+    if (ck + 1 < n_chunks) chunk_body(ck + 1, 1);
   }
   // g_z2, then G_a1^T[h, e] = sum_h' W1'[h][h'] g_z2[e][h']
   f32x16 ga1[2];
