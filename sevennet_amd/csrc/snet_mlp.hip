@@ -22,6 +22,10 @@
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+// native clang vectors: HIP's float4/uint4 are structs wrapping unions, and arrays of them are not
+// scalarised by SROA (they end up in scratch memory)
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 constexpr int H = 64;  // hidden width of both hidden layers
 
 __device__ __forceinline__ int krow(int s, int half) { return 32 * (s >> 4) + (s & 3) + 8 * ((s & 15) >> 2) + 4 * half; }
@@ -158,16 +162,16 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float *__rest
   const bool vec_ok = (wn & 3) == 0;
   const int srow = lane >> 3, scol = 4 * (lane & 7);
 
-  float4 st_g[4], st_w[2];
+  f32x4 st_g[4], st_w[2];
   auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // g_w[e0 + 8i + srow][c0 + scol .. +4)
       const int64_t e = e0 + 8 * i + srow;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      f32x4 q = {0.f, 0.f, 0.f, 0.f};
       if (wave_ok && e < E && c0 + scol < wn) {
         const float *p = g_w + e * wn + c0 + scol;
         if (vec_ok && c0 + scol + 3 < wn) {
-          q = *reinterpret_cast<const float4 *>(p);
+          q = *reinterpret_cast<const f32x4 *>(p);
         } else {
           q.x = p[0];
           if (c0 + scol + 1 < wn) q.y = p[1];
@@ -181,8 +185,8 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float *__rest
     for (int i = 0; i < 2; ++i) {  // W2T[c0 + row][0..64): 512 float4 per slab, 2 per thread
       const int f = tid + 256 * i;
       const int row = f >> 4, col = 4 * (f & 15);
-      st_w[i] = (c0 + row < wn) ? *reinterpret_cast<const float4 *>(W2T + (int64_t)(c0 + row) * H + col)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      st_w[i] = (c0 + row < wn) ? *reinterpret_cast<const f32x4 *>(W2T + (int64_t)(c0 + row) * H + col)
+                                : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto store_chunk = [&](int buf) {
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float *__rest
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int f = tid + 256 * i;
-      *reinterpret_cast<float4 *>(&w2t[buf][4 * f]) = st_w[i];
+      *reinterpret_cast<f32x4 *>(&w2t[buf][4 * f]) = st_w[i];
     }
   };
 
@@ -321,37 +325,34 @@ struct Split3 {
   bf16x8 t[3];
 };
 
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+
+__device__ __forceinline__ bf16x8 cat4(bf16x2 a, bf16x2 b, bf16x2 c, bf16x2 d) {
+  const bf16x4 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3);
+  const bf16x4 cd = __builtin_shufflevector(c, d, 0, 1, 2, 3);
+  return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// x = x1 + x2 + x3 (bf16 each, round-to-nearest-even via v_cvt_pk_bf16_f32); pure register code
 __device__ __forceinline__ Split3 split8(const float (&v)[8]) {
-  union U {
-    bf16x8 v8;
-    bf16x2 v2[4];
-  } h, m, l;
+  bf16x2 h[4], m[4], l[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const f32x2 x = {v[2 * p], v[2 * p + 1]};
-    const bf16x2 xh = __builtin_convertvector(x, bf16x2);
-    const f32x2 r1 = x - __builtin_convertvector(xh, f32x2);
-    const bf16x2 xm = __builtin_convertvector(r1, bf16x2);
-    const f32x2 r2 = r1 - __builtin_convertvector(xm, f32x2);
-    h.v2[p] = xh;
-    m.v2[p] = xm;
-    l.v2[p] = __builtin_convertvector(r2, bf16x2);
+    h[p] = __builtin_convertvector(x, bf16x2);
+    const f32x2 r1 = x - __builtin_convertvector(h[p], f32x2);
+    m[p] = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(m[p], f32x2);
+    l[p] = __builtin_convertvector(r2, bf16x2);
   }
   Split3 s;
-  s.t[0] = h.v8;
-  s.t[1] = m.v8;
-  s.t[2] = l.v8;
+  s.t[0] = cat4(h[0], h[1], h[2], h[3]);
+  s.t[1] = cat4(m[0], m[1], m[2], m[3]);
+  s.t[2] = cat4(l[0], l[1], l[2], l[3]);
   return s;
 }
 
-__device__ __forceinline__ bf16x8 as_bf16x8(const uint4 u) {
-  union {
-    uint4 u;
-    bf16x8 b;
-  } c;
-  c.u = u;
-  return c.b;
-}
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 u) { return __builtin_bit_cast(bf16x8, u); }
 
 // acc += A * B with both operands given as 3-term splits (A from packed fragments a[0..2])
 __device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const Split3 &b, f32x16 acc) {
@@ -374,14 +375,14 @@ __device__ __forceinline__ f32x16 mfma6(const Split3 &a, const bf16x8 (&b)[3], f
 }
 
 // fragment index helper: packed arrays are [..][term(3)][lane(64)] of uint4
-__device__ __forceinline__ void load_frag3(const uint4 *__restrict__ base, int frag, int lane, bf16x8 (&out)[3]) {
+__device__ __forceinline__ void load_frag3(const u32x4 *__restrict__ base, int frag, int lane, bf16x8 (&out)[3]) {
 #pragma unroll
   for (int t = 0; t < 3; ++t) out[t] = as_bf16x8(base[(frag * 3 + t) * 64 + lane]);
 }
 
 // z1 (fp32 MFMA, K = nb) and z2 (split MFMA) in the transposed layout
 __device__ __forceinline__ void hidden_forward_split(const float *__restrict__ emb, int64_t e_lane, bool e_ok, int nb,
-                                                     const float *__restrict__ W0, const uint4 *__restrict__ W1A,
+                                                     const float *__restrict__ W0, const u32x4 *__restrict__ W1A,
                                                      int act, float cst, int lane, f32x16 (&z1)[2],
                                                      f32x16 (&z2)[2]) {
   const int half = lane >> 5, li = lane & 31;
@@ -415,14 +416,14 @@ __device__ __forceinline__ void hidden_forward_split(const float *__restrict__ e
 
 constexpr int W2B_TILE_U4 = 4 * 3 * 64;  // uint4 per 32-column tile of W2B: [q(4)][term(3)][lane]
 
-__global__ __launch_bounds__(256) void radial_mlp_fwd_split_kernel(const float *__restrict__ emb, int64_t E, int nb,
+__global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_kernel(const float *__restrict__ emb, int64_t E, int nb,
                                                                    int wn, const float *__restrict__ W0,
-                                                                   const uint4 *__restrict__ W1A,
-                                                                   const uint4 *__restrict__ W2B, int act, float cst,
+                                                                   const u32x4 *__restrict__ W1A,
+                                                                   const u32x4 *__restrict__ W2B, int act, float cst,
                                                                    float *__restrict__ w_out) {
   // W2 fragments are shared by the 4 waves: one 12-KB slab per 32-column tile, double buffered
   // (cuts the L2 -> CU fragment traffic 4x relative to per-wave loads)
-  __shared__ uint4 slab[2][W2B_TILE_U4];
+  __shared__ u32x4 slab[2][W2B_TILE_U4];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, li = lane & 31;
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256) void radial_mlp_fwd_split_kernel(const float *
   const int64_t e_lane = e0 + li;
   const bool e_ok = wave_ok && e_lane < E;
   const int n_tiles = (wn + 31) >> 5;
-  uint4 st[3];
+  u32x4 st[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) slab[0][tid + 256 * i] = W2B[tid + 256 * i];
   __syncthreads();
@@ -483,10 +484,10 @@ constexpr int SLAB_U4 = 2 * 2 * 3 * 64;     // uint4 per 32-channel slab of W2A:
 
 __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(
     const float *__restrict__ emb, const float *__restrict__ g_w, int64_t E, int nb, int wn,
-    const float *__restrict__ W0, const uint4 *__restrict__ W1A, const uint4 *__restrict__ W2A,
-    const uint4 *__restrict__ W1A2, const uint4 *__restrict__ W0A, int act, float cst, float *__restrict__ g_emb) {
+    const float *__restrict__ W0, const u32x4 *__restrict__ W1A, const u32x4 *__restrict__ W2A,
+    const u32x4 *__restrict__ W1A2, const u32x4 *__restrict__ W0A, int act, float cst, float *__restrict__ g_emb) {
   __shared__ float gws[4 * GS_TILE];
-  __shared__ uint4 slab[2][SLAB_U4];
+  __shared__ u32x4 slab[2][SLAB_U4];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, li = lane & 31;
@@ -500,18 +501,18 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(
   const int n_chunks = (wn + CH - 1) / CH;
 
   // two chunks in flight in registers (HBM latency exceeds one 24-MFMA chunk): stage[ck & 1]
-  float4 st_g[2][4];
-  uint4 st_w[2][3];
+  f32x4 st_g[2][4];
+  u32x4 st_w[2][3];
   auto load_chunk = [&](int ck, int sl) {
     const int c0 = ck * CH;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t e = e0 + 8 * i + srow;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      f32x4 q = {0.f, 0.f, 0.f, 0.f};
       if (wave_ok && e < E && c0 + scol < wn) {
         const float *p = g_w + e * wn + c0 + scol;
         if (vec_ok && c0 + scol + 3 < wn) {
-          q = *reinterpret_cast<const float4 *>(p);
+          q = *reinterpret_cast<const f32x4 *>(p);
         } else {
           q.x = p[0];
           if (c0 + scol + 1 < wn) q.y = p[1];
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(
   auto store_chunk = [&](int buf, int sl) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4 *>(tile + (8 * i + srow) * GS_STRIDE + scol) = st_g[sl][i];
+      *reinterpret_cast<f32x4 *>(tile + (8 * i + srow) * GS_STRIDE + scol) = st_g[sl][i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) slab[buf][tid + 256 * i] = st_w[sl][i];
   };
@@ -546,31 +547,31 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(
   ga2[1] = zero16();
   // iteration ck: (start) refill the register stage that held chunk ck with chunk ck+2;
   // (end) move chunk ck+1 from its stage into the LDS tile / the other slab buffer.
-  auto chunk_body = [&](int ck, int par) {  // par = ck & 1, passed as a literal so stages are static
-    if (ck + 2 < n_chunks) load_chunk(ck + 2, par);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float v[8];
-      const float4 lo4 = *reinterpret_cast<const float4 *>(tile + li * GS_STRIDE + 16 * s + 8 * half);
-      const float4 hi4 = *reinterpret_cast<const float4 *>(tile + li * GS_STRIDE + 16 * s + 8 * half + 4);
-      v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w;
-      v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
-      const Split3 b = split8(v);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        bf16x8 a[3];
-#pragma unroll
-        for (int tm = 0; tm < 3; ++tm) a[tm] = as_bf16x8(slab[par][((s * 2 + t) * 3 + tm) * 64 + lane]);
-        ga2[t] = mfma6(a, b, ga2[t]);
-      }
-    }
-    if (ck + 1 < n_chunks) store_chunk(par ^ 1, par ^ 1);
-    __syncthreads();
-  };
-  for (int ck = 0; ck < n_chunks; ck += 2) {
-    chunk_body(ck, 0);
-    if (ck + 1 < n_chunks) chunk_body(ck + 1, 1);
+#define SNET_CHUNK_BODY(ck, PAR) /* PAR = ck & 1 as a literal: register stages stay statically indexed */   \
+  {                                                                                                          \
+    if ((ck) + 2 < n_chunks) load_chunk((ck) + 2, PAR);                                                      \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                          \
+      float v[8];                                                                                            \
+      const f32x4 lo4 = *reinterpret_cast<const f32x4 *>(tile + li * GS_STRIDE + 16 * s + 8 * half);       \
+      const f32x4 hi4 = *reinterpret_cast<const f32x4 *>(tile + li * GS_STRIDE + 16 * s + 8 * half + 4);   \
+      v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w;                                                \
+      v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;                                                \
+      const Split3 b = split8(v);                                                                            \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                        \
+        bf16x8 a[3];                                                                                         \
+        _Pragma("unroll") for (int tm = 0; tm < 3; ++tm)                                                     \
+            a[tm] = as_bf16x8(slab[PAR][((s * 2 + t) * 3 + tm) * 64 + lane]);                                \
+        ga2[t] = mfma6(a, b, ga2[t]);                                                                        \
+      }                                                                                                      \
+    }                                                                                                        \
+    if ((ck) + 1 < n_chunks) store_chunk((PAR) ^ 1, (PAR) ^ 1);                                              \
+    __syncthreads();                                                                                         \
   }
+  for (int ck = 0; ck < n_chunks; ck += 2) {
+    SNET_CHUNK_BODY(ck, 0)
+    if (ck + 1 < n_chunks) SNET_CHUNK_BODY(ck + 1, 1)
+  }
+#undef SNET_CHUNK_BODY
   // g_z2, then G_a1^T[h, e] = sum_h' W1'[h][h'] g_z2[e][h']
   f32x16 ga1[2];
   ga1[0] = zero16();
@@ -622,7 +623,7 @@ struct snet_mlp_plan {
   int nb, wn, act, mode;
   float cst;
   float *W0 = nullptr, *W1 = nullptr, *W2 = nullptr, *W2T = nullptr;               // fp32 mode
-  uint4 *W1A = nullptr, *W2B = nullptr, *W2A = nullptr, *W1A2 = nullptr, *W0A = nullptr;  // split mode
+  u32x4 *W1A = nullptr, *W2B = nullptr, *W2A = nullptr, *W1A2 = nullptr, *W0A = nullptr;  // split mode
 };
 
 namespace {
