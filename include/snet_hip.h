@@ -116,23 +116,30 @@ int snet_conv_plan_dims(const snet_conv_plan *plan, int32_t *dx, int32_t *dout, 
 int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
                   const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, float *out,
                   void *stream);
-/* per-edge gradients: g_w[E,wn] (overwritten) and g_sh[E,nsh] (ACCUMULATED, so
- * one buffer collects all layers) given g_out[n_dst,dout]                    */
+/* per-edge gradients given g_out[n_dst,dout]: g_w[E,wn] (overwritten), g_sh[E,nsh] (ACCUMULATED,
+ * so one buffer collects all layers) and, if g_xe != NULL, this edge's contribution to the gradient
+ * of its source row, g_xe[E,dx] (overwritten; sum it per source node with snet_segment_sum_rows --
+ * 1.9 KB/edge written once instead of the 12.5 KB/edge g_out gathers of snet_conv_bwd_node).    */
 int snet_conv_bwd_edge(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
                        const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
-                       const float *g_out, float *g_w, float *g_sh, void *stream);
+                       const float *g_out, float *g_w, float *g_xe, float *g_sh, void *stream);
 /* same, but the spherical-harmonic gradient is contracted with dsh[E,nsh,3] (snet_edge_embed_fwd)
  * inside the kernel and ACCUMULATED into g_vec[E,3]: 3 instead of nsh values per edge cross the
  * wavefront reduction.  This is the variant the whole-model engine uses. */
 int snet_conv_bwd_edge_vec(const snet_conv_plan *plan, const float *x, const float *sh, const float *dsh,
                            const float *w, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
-                           const float *g_out, float *g_w, float *g_vec, void *stream);
+                           const float *g_out, float *g_w, float *g_xe, float *g_vec, void *stream);
 /* source-node gradient g_x[n_src,dx] (overwritten) via the source-sorted edge
  * permutation: col_ptr[n_src+1], eperm[E] (edge ids grouped by source), dst[E].
  * Deterministic replacement of the scatter-add autograd performs for x[src]. */
 int snet_conv_bwd_node(const snet_conv_plan *plan, const float *sh, const float *w, const int32_t *col_ptr,
                        const int32_t *eperm, const int32_t *dst, int64_t n_src, float scale,
                        const float *g_out, float *g_x, void *stream);
+
+/* out[s,:] = sum_{k in [seg_ptr[s], seg_ptr[s+1])} x[perm[k],:]  (deterministic segmented row sum;
+ * with col_ptr/eperm it turns g_xe[E,dx] into g_x[n_src,dx], the reverse of the x[src] gather) */
+int snet_segment_sum_rows(const float *x, const int32_t *seg_ptr, const int32_t *perm, int64_t n_seg, int32_t dim,
+                          float *out, void *stream);
 
 /* ---- a5: equivariant gate ------------------------------------------------
  * replaces EquivariantGate.forward, sevenn/nn/equivariant_gate.py:57-59     */

@@ -112,7 +112,7 @@ class _UvuConvFn(torch.autograd.Function):
         g_w_s = torch.empty(E, mod.wn, dtype=torch.float32, device=dev)
         g_sh_s = torch.zeros(E, mod.nsh, dtype=torch.float32, device=dev)
         _lib.check(lib.snet_conv_bwd_edge(mod.plan, _p(x_im), _p(sh_s), _p(w_s), _p(row_ptr), _p(src_s), N, 1.0,
-                                          _p(g_im), _p(g_w_s), _p(g_sh_s), _st()), 'snet_conv_bwd_edge')
+                                          _p(g_im), _p(g_w_s), None, _p(g_sh_s), _st()), 'snet_conv_bwd_edge')
         col_ptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
         col_ptr[1:] = torch.cumsum(torch.bincount(src_s.long(), minlength=N), 0)
         eperm = torch.sort(src_s.long(), stable=True).indices.to(torch.int32)

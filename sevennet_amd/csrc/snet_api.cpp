@@ -86,21 +86,21 @@ int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, c
 }
 int snet_conv_bwd_edge(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
                        const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, const float *g_out,
-                       float *g_w, float *g_sh, void *stream) {
+                       float *g_w, float *g_xe, float *g_sh, void *stream) {
   SNET_REQUIRE(plan != nullptr, "snet_conv_bwd_edge: null plan");
   SNET_REQUIRE(n_dst < (1ll << 31), "snet_conv_bwd_edge: too many nodes");
   if (n_dst <= 0) return 0;
-  plan->k->bwd_edge(x, sh, w, row_ptr, src, n_dst, scale, g_out, g_w, g_sh, static_cast<hipStream_t>(stream));
+  plan->k->bwd_edge(x, sh, w, row_ptr, src, n_dst, scale, g_out, g_w, g_xe, g_sh, static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_conv_bwd_edge");
   return 0;
 }
 int snet_conv_bwd_edge_vec(const snet_conv_plan *plan, const float *x, const float *sh, const float *dsh,
                            const float *w, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
-                           const float *g_out, float *g_w, float *g_vec, void *stream) {
+                           const float *g_out, float *g_w, float *g_xe, float *g_vec, void *stream) {
   SNET_REQUIRE(plan != nullptr, "snet_conv_bwd_edge_vec: null plan");
   SNET_REQUIRE(n_dst < (1ll << 31), "snet_conv_bwd_edge_vec: too many nodes");
   if (n_dst <= 0) return 0;
-  plan->k->bwd_edge_vec(x, sh, dsh, w, row_ptr, src, n_dst, scale, g_out, g_w, g_vec,
+  plan->k->bwd_edge_vec(x, sh, dsh, w, row_ptr, src, n_dst, scale, g_out, g_w, g_xe, g_vec,
                         static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_conv_bwd_edge_vec");
   return 0;

@@ -133,6 +133,26 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *__re
   }
 }
 
+// out[s, c] = sum over the segment's rows; lanes over columns (coalesced row reads), 4 rows in flight
+__global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__restrict__ x, const int32_t *__restrict__ seg,
+                                                               const int32_t *__restrict__ perm, int dim,
+                                                               float *__restrict__ out) {
+  const int s = blockIdx.x;
+  const int k0 = seg[s], k1 = seg[s + 1];
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int k = k0;
+    for (; k + 3 < k1; k += 4) {
+      a0 += x[(size_t)perm[k] * dim + c];
+      a1 += x[(size_t)perm[k + 1] * dim + c];
+      a2 += x[(size_t)perm[k + 2] * dim + c];
+      a3 += x[(size_t)perm[k + 3] * dim + c];
+    }
+    for (; k < k1; ++k) a0 += x[(size_t)perm[k] * dim + c];
+    out[(size_t)s * dim + c] = (a0 + a1) + (a2 + a3);
+  }
+}
+
 // e_atom = e*scale[t]+shift[t]; deterministic two-stage sum (double)
 constexpr int RED_BLOCKS = 256;
 __global__ __launch_bounds__(256) void rescale_partial_kernel(const float *__restrict__ e, const int32_t *__restrict__ types,
@@ -248,6 +268,15 @@ extern "C" int snet_scatter_add_rows(const float *x, const int32_t *idx, float *
   if (n <= 0) return 0;
   scatter_add_rows_kernel<<<grid_for(n * dim), 256, 0, static_cast<hipStream_t>(stream)>>>(x, idx, y, n, dim);
   SNET_CHECK_LAUNCH("snet_scatter_add_rows");
+  return 0;
+}
+extern "C" int snet_segment_sum_rows(const float *x, const int32_t *seg_ptr, const int32_t *perm, int64_t n_seg,
+                                     int32_t dim, float *out, void *stream) {
+  SNET_REQUIRE(dim >= 1 && n_seg < (1ll << 31), "snet_segment_sum_rows: bad shape");
+  if (n_seg <= 0) return 0;
+  const int threads = dim >= 256 ? 256 : (dim > 128 ? 256 : (dim > 64 ? 128 : 64));
+  segment_sum_rows_kernel<<<(unsigned)n_seg, threads, 0, static_cast<hipStream_t>(stream)>>>(x, seg_ptr, perm, dim, out);
+  SNET_CHECK_LAUNCH("snet_segment_sum_rows");
   return 0;
 }
 extern "C" int snet_rescale_reduce(const float *e_scaled, const int32_t *types, const float *scale,

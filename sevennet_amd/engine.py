@@ -395,19 +395,22 @@ class HipForceEngine:
                 with _Span(self, 'node_linear_bwd'):
                     g_m = self._linear_T(L.si2, g_y, N, g)
                 g_w = self._new(E, ls.conv.weight_numel)
+                # layer 0: inputs depend on species only -> no source-row gradient needed
+                g_xe = self._new(E, ls.si1.dim_out) if t > 0 else None
                 with _Span(self, f'conv_bwd_edge[{ls.conv.tag}]'):
                     _lib.check(lib.snet_conv_bwd_edge_vec(L.plan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(w), _ptr(g.row_ptr),
-                                                          _ptr(g.src), N, L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_vec), st),
-                               'snet_conv_bwd_edge_vec')
+                                                          _ptr(g.src), N, L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_xe),
+                                                          _ptr(g_vec), st), 'snet_conv_bwd_edge_vec')
                 with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]'):
                     self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
                 del g_w
                 if t == 0:
-                    break  # layer-0 inputs depend on species only: nothing upstream needs a gradient
+                    break
                 g_h = self._new(NT, ls.si1.dim_out)
-                with _Span(self, f'conv_bwd_node[{ls.conv.tag}]'):
-                    _lib.check(lib.snet_conv_bwd_node(L.plan, _ptr(sh), _ptr(w), _ptr(g.col_ptr), _ptr(g.eperm),
-                                                      _ptr(g.center), NT, L.scale, _ptr(g_m), _ptr(g_h), st), 'snet_conv_bwd_node')
+                with _Span(self, 'conv_bwd_node[segment_sum]'):
+                    _lib.check(lib.snet_segment_sum_rows(_ptr(g_xe), _ptr(g.col_ptr), _ptr(g.eperm), NT, ls.si1.dim_out,
+                                                         _ptr(g_h), st), 'snet_segment_sum_rows')
+                del g_xe
                 if halo is not None:
                     with _Span(self, 'halo_rev'):
                         halo.reverse(g_h, N)

@@ -171,6 +171,24 @@ def test_conv_plugin_vs_oracle_autograd(cfg_name):
         assert err < 3e-5 * max(1.0, b.abs().max().item()), (name, err)
 
 
+def test_segment_sum_rows():
+    L, lib = _lib()
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(6)
+    E, N, dim = 999, 57, 480
+    x = torch.randn(E, dim, generator=g).to(dev)
+    src = torch.randint(0, N, (E,), generator=g)
+    perm = torch.sort(src, stable=True).indices.to(torch.int32).to(dev)
+    ptr = torch.zeros(N + 1, dtype=torch.int64)
+    ptr[1:] = torch.cumsum(torch.bincount(src, minlength=N), 0)
+    ptr = ptr.to(torch.int32).to(dev)
+    out = torch.empty(N, dim, device=dev)
+    L.check(lib.snet_segment_sum_rows(_p(x), _p(ptr), _p(perm), N, dim, _p(out), None))
+    torch.cuda.synchronize()
+    ref = torch.zeros(N, dim, dtype=torch.float64).index_add_(0, src, x.cpu().double())
+    assert (out.cpu().double() - ref).abs().max() < 1e-5
+
+
 def _mid_index(spec):
     """index of each path's block inside irreps_mid (sorted, one block per path)"""
     offs = {}
