@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--model', default='sevennet_0')
     ap.add_argument('--mlp-mode', default='bf16x6')
+    ap.add_argument('--only', default='', help='substring filter on kernel names')
     a = ap.parse_args()
     from bench import kernel_model, model_config
     from sevennet_amd import _lib
@@ -65,6 +66,8 @@ def main():
     }
     print(f'lib={_lib.LIB_PATH} N={N} E={E} layer={a.layer} dx={dx} dmid={dmid} wn={wn}')
     for name, fn in ops.items():
+        if a.only and a.only not in name:
+            continue
         fn()
         torch.cuda.synchronize()
         ts = []
