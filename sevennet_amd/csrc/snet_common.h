@@ -91,6 +91,14 @@ __device__ __forceinline__ float lane_xor(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false));                            // quad_perm [1,0,3,2]
 }
 
+// broadcast of lane K's value as a wave-uniform scalar (v_readlane_b32 -> SGPR operand).  Per-edge
+// constants (spherical harmonics, their Jacobian) are fetched by ONE coalesced vector load -- lane k
+// holds element k -- and read back through this, instead of one broadcast load per element.
+template <int K>
+__device__ __forceinline__ float lane_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), K));
+}
+
 __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == 0) return z / (1.0f + expf(-z));  // silu
   return tanhf(z);
