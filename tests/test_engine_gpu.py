@@ -197,3 +197,36 @@ def test_calculator_surface_matches_reference_results():
     assert res['stresses'].shape == (len(numbers), 6)
     with pytest.raises(ValueError, match='do not know atomic number'):
         calc.compute(np.array([14]), np.zeros((1, 3)), d['cell'], [True] * 3)
+
+
+def test_rccl_backend_halo_exchange_world1():
+    """The torch.distributed (backend 'nccl' = RCCL) exchange path on device tensors.  One GPU is
+    all this box has, so world_size = 1 with a self-exchange: rank 0 'sends' rows to itself, which
+    exercises init_process_group, uneven-split all_to_all_single on a tensor view and the HIP
+    pack / unpack kernels exactly as the N-GPU bench does."""
+    import os
+    import torch.distributed as dist
+    from sevennet_amd.parallel import HaloExchange
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    try:
+        n_local, dim = 50, 96
+        send = np.array([3, 7, 7 + 1, 20, 49])  # rows this rank exports (here: to itself)
+        halo = HaloExchange([send], [len(send)], 'cuda:0')
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(n_local + len(send), dim, generator=g).to('cuda:0')
+        ref = x.clone()
+        halo.forward(x, n_local)
+        torch.cuda.synchronize()
+        assert torch.equal(x[n_local:], ref[send]) and torch.equal(x[:n_local], ref[:n_local])
+        gx = torch.randn(n_local + len(send), dim, generator=g).to('cuda:0')
+        gref = gx.clone()
+        halo.reverse(gx, n_local)
+        torch.cuda.synchronize()
+        exp = gref[:n_local].clone()
+        exp[send] += gref[n_local:]
+        assert torch.allclose(gx[:n_local], exp)
+    finally:
+        dist.destroy_process_group()
