@@ -164,6 +164,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
+    t_enq = time.perf_counter() - t0  # host time to enqueue K steps (kernels run asynchronously)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -220,6 +221,7 @@ def main():
                        'atoms': n_atoms, 'edges': n_edges_total,
                        'parallelism': 'single GPU' if world == 1 else f'spatial decomposition x{world}, RCCL halo',
                        'graph_build_s': round(t_graph, 3),
+                       'host_enqueue_ms_per_step': round(t_enq / a.steps * 1e3, 3),
                        'energy': float(out['energy'].cpu())},
             'roofline': roof,
         }
