@@ -76,6 +76,18 @@ int snet_gemm(const float *A, const float *B, float *C, int64_t n_nodes, int32_t
               int64_t a_node_stride, int64_t a_off, int64_t c_node_stride, int64_t c_off,
               const int32_t *row_idx, int32_t accumulate, void *stream);
 
+/* All per-irrep GEMMs of ONE equivariant linear in a single launch (same A, C, node strides, row
+ * list; blocks writing the same output block must not be grouped unless the later ones accumulate
+ * into distinct rows -- the host keeps accumulating blocks in separate launches).             */
+typedef struct snet_gemm_desc {
+  const float *B;     /* device [K,N] row-major */
+  int64_t a_off, c_off;
+  int32_t d, K, N, accumulate;
+} snet_gemm_desc;
+#define SNET_MAX_GEMM_GROUP 8
+int snet_gemm_grouped(const snet_gemm_desc *descs_host, int32_t n_desc, const float *A, float *C, int64_t n_nodes,
+                      int64_t a_node_stride, int64_t c_node_stride, const int32_t *row_idx, void *stream);
+
 /* Fused radial MLP, e3nn FullyConnectedNet([nb,h1,h2,wn], act) (convolution.py:93-95,121):
  *   fwd  w[E,wn] = (act(act(emb W0) cst W1) cst) W2          W0[nb,h1] W1[h1,h2] W2[h2,wn]
  *   bwd  g_emb[E,nb] += d<g_w,w>/d emb

@@ -19,19 +19,16 @@ constexpr int BK = 32;
 constexpr int AS_STRIDE = BM + 1;
 
 template <int NT>  // number of 32-wide column tiles per block
-__global__ __launch_bounds__(256) void gemm_kernel(
+__device__ __forceinline__ void gemm_body(float *As, float *Bs, int bx, int by,
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int64_t n_rows, int d, int K,
     int N, int64_t a_node_stride, int64_t a_off, int64_t c_node_stride, int64_t c_off,
     const int32_t *__restrict__ row_idx, int accumulate) {
   constexpr int BN = 32 * NT;
-  __shared__ float As[BK * AS_STRIDE];
-  __shared__ float Bs[BK * BN];
-
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int64_t row0 = (int64_t)blockIdx.x * BM;
-  const int col0 = blockIdx.y * BN;
+  const int64_t row0 = (int64_t)bx * BM;
+  const int col0 = by * BN;
 
   // each thread stages 4 A rows: r = tid/8 + 32*i, k-quad = tid%8
   const int lr = tid >> 3;
@@ -126,7 +123,80 @@ __global__ __launch_bounds__(256) void gemm_kernel(
   }
 }
 
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_kernel(
+    const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int64_t n_rows, int d, int K,
+    int N, int64_t a_node_stride, int64_t a_off, int64_t c_node_stride, int64_t c_off,
+    const int32_t *__restrict__ row_idx, int accumulate) {
+  __shared__ float As[BK * AS_STRIDE];
+  __shared__ float Bs[BK * 32 * NT];
+  gemm_body<NT>(As, Bs, blockIdx.x, blockIdx.y, A, B, C, n_rows, d, K, N, a_node_stride, a_off, c_node_stride, c_off,
+                row_idx, accumulate);
+}
+
+// Grouped launch: all per-irrep GEMMs of one equivariant linear in ONE grid (they share A, C, the node
+// strides and the row list).  At MD sizes of ~10^4 atoms per GPU the separate launches (3 per linear,
+// ~90 per step, each only a few hundred workgroups) were launch/tail bound: 24 % of the step.
+struct GroupArgs {
+  int n;
+  int first_block[SNET_MAX_GEMM_GROUP + 1];  // prefix of workgroups per problem
+  int nbx[SNET_MAX_GEMM_GROUP];
+  snet_gemm_desc p[SNET_MAX_GEMM_GROUP];
+};
+
+__global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupArgs G, const float *__restrict__ A,
+                                                           float *__restrict__ C, int64_t n_nodes,
+                                                           int64_t a_node_stride, int64_t c_node_stride,
+                                                           const int32_t *__restrict__ row_idx) {
+  __shared__ float As[BK * AS_STRIDE];
+  __shared__ float Bs[BK * 128];
+  int q = 0;
+  while (q + 1 < G.n && (int)blockIdx.x >= G.first_block[q + 1]) ++q;
+  const snet_gemm_desc P = G.p[q];
+  const int b = blockIdx.x - G.first_block[q];
+  const int bx = b % G.nbx[q], by = b / G.nbx[q];
+  const int64_t n_rows = n_nodes * P.d;
+  if (P.N > 64)
+    gemm_body<4>(As, Bs, bx, by, A, P.B, C, n_rows, P.d, P.K, P.N, a_node_stride, P.a_off, c_node_stride, P.c_off,
+                 row_idx, P.accumulate);
+  else if (P.N > 32)
+    gemm_body<2>(As, Bs, bx, by, A, P.B, C, n_rows, P.d, P.K, P.N, a_node_stride, P.a_off, c_node_stride, P.c_off,
+                 row_idx, P.accumulate);
+  else
+    gemm_body<1>(As, Bs, bx, by, A, P.B, C, n_rows, P.d, P.K, P.N, a_node_stride, P.a_off, c_node_stride, P.c_off,
+                 row_idx, P.accumulate);
+}
+
 }  // namespace
+
+extern "C" int snet_gemm_grouped(const snet_gemm_desc *descs_host, int32_t n_desc, const float *A, float *C,
+                                 int64_t n_nodes, int64_t a_node_stride, int64_t c_node_stride,
+                                 const int32_t *row_idx, void *stream) {
+  SNET_REQUIRE(descs_host != nullptr && n_desc >= 1 && n_desc <= SNET_MAX_GEMM_GROUP,
+               "snet_gemm_grouped: 1..8 problems required");
+  if (n_nodes <= 0) return 0;
+  GroupArgs G;
+  G.n = n_desc;
+  int64_t total = 0;
+  for (int i = 0; i < n_desc; ++i) {
+    const snet_gemm_desc &p = descs_host[i];
+    SNET_REQUIRE(p.d >= 1 && p.K >= 1 && p.N >= 1 && p.B != nullptr, "snet_gemm_grouped: bad problem");
+    const int bn = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
+    const int64_t nbx = (n_nodes * p.d + BM - 1) / BM;
+    const int64_t nby = (p.N + bn - 1) / bn;
+    SNET_REQUIRE(nbx < (1ll << 30), "snet_gemm_grouped: too many rows");
+    G.p[i] = p;
+    G.nbx[i] = (int)nbx;
+    G.first_block[i] = (int)total;
+    total += nbx * nby;
+  }
+  G.first_block[n_desc] = (int)total;
+  SNET_REQUIRE(total < (1ll << 31), "snet_gemm_grouped: grid too large");
+  gemm_grouped_kernel<<<(unsigned)total, 256, 0, static_cast<hipStream_t>(stream)>>>(G, A, C, n_nodes, a_node_stride,
+                                                                                     c_node_stride, row_idx);
+  SNET_CHECK_LAUNCH("snet_gemm_grouped");
+  return 0;
+}
 
 extern "C" int snet_gemm(const float *A, const float *B, float *C, int64_t n_nodes, int32_t d, int32_t K,
                          int32_t N, int64_t a_node_stride, int64_t a_off, int64_t c_node_stride, int64_t c_off,

@@ -94,13 +94,44 @@ def build_graph(types, edge_index, edge_vec, n_local: Optional[int] = None, devi
 
 # --------------------------------------------------------------------------- #
 class _Linear:
-    """Device weights of one LinearSpec (per-GEMM [K,N] and [N,K] copies)."""
+    """Device weights of one LinearSpec (per-GEMM [K,N] and [N,K] copies) and its launch plan:
+    per-irrep GEMMs that write distinct output blocks are grouped into one launch."""
 
     def __init__(self, spec: LinearSpec, flat: np.ndarray, dev):
         self.spec = spec
         mats = linear_weight_matrices(spec, flat)
         self.w = [torch.from_numpy(m).to(dev) for m in mats]
         self.wt = [torch.from_numpy(np.ascontiguousarray(m.T)).to(dev) for m in mats]
+        self.groups_fwd = self._plan(transpose=False)
+        self.groups_T = self._plan(transpose=True)
+
+    def _plan(self, transpose: bool):
+        """-> list of (species, GemmDesc array, n, first_use_accumulates[list of target offsets])"""
+        sp = self.spec
+        groups = []          # [species, [descs], set(targets)]
+        written = set()      # targets already written by an earlier launch (-> accumulate)
+        pair_seen = {}       # transposed FCTP: species slices of one (in,out) pair hit disjoint rows
+        for b, w, wt in zip(sp.blocks, self.w, self.wt):
+            if transpose:
+                tgt, a_off, c_off, K, N, B = b.in_off, b.out_off, b.in_off, b.mul_out, b.mul_in, wt
+            else:
+                tgt, a_off, c_off, K, N, B = b.out_off, b.in_off, b.out_off, b.mul_in, b.mul_out, w
+            key = (tgt, b.species)
+            acc = key in written
+            desc = _lib.GemmDesc(B.data_ptr(), a_off, c_off, 2 * b.l + 1, K, N, int(acc))
+            placed = False
+            if groups and groups[-1][0] == b.species and len(groups[-1][1]) < 8 and tgt not in groups[-1][2]:
+                groups[-1][1].append(desc)
+                groups[-1][2].add(tgt)
+                placed = True
+            if not placed:
+                groups.append([b.species, [desc], {tgt}])
+            written.add(key)
+        out = []
+        for species, descs, _ in groups:
+            arr = (_lib.GemmDesc * len(descs))(*descs)
+            out.append((species, arr, len(descs)))
+        return out
 
 
 class _Span:
@@ -224,24 +255,27 @@ class HipForceEngine:
         _lib.check(self.lib.snet_gemm(_ptr(A), _ptr(B), _ptr(Cm), n_nodes, d, K, N, a_stride, a_off, c_stride,
                                       c_off, _ptr(rows), int(acc), _stream()), 'snet_gemm')
 
+    def _run_groups(self, groups, A, Cm, n, a_stride, c_stride, g: Graph, force_acc=False):
+        for species, arr, cnt in groups:
+            rows, m = None, n
+            if species >= 0:
+                rows = g.species_rows[species]
+                m = rows.numel()
+                if m == 0:
+                    continue
+            if force_acc:
+                arr2 = (_lib.GemmDesc * cnt)(*[_lib.GemmDesc(d.B, d.a_off, d.c_off, d.d, d.K, d.N, 1) for d in arr[:cnt]])
+                arr = arr2
+            _lib.check(self.lib.snet_gemm_grouped(arr, cnt, _ptr(A), _ptr(Cm), m, a_stride, c_stride, _ptr(rows),
+                                                  _stream()), 'snet_gemm_grouped')
+
     def _linear(self, lin: _Linear, x, n, g: Graph, out=None):
         """y[:n] = Linear(x[:n]) on ir_mul rows."""
         sp = lin.spec
         y = self._new(max(n, 0), sp.dim_out) if out is None else out
         for off, ln in sp.zero_out:
             y[:, off:off + ln].zero_()
-        for b, w in zip(sp.blocks, lin.w):
-            if b.species >= 0:
-                rows = g.species_rows[b.species]
-                if rows.numel() == 0:
-                    continue
-                # a species' rows only ever see that species' matrix: the first species writes,
-                # accumulation across in-blocks follows b.accumulate
-                self._gemm(x, w, y, rows.numel(), 2 * b.l + 1, b.mul_in, b.mul_out, sp.dim_in, b.in_off,
-                           sp.dim_out, b.out_off, rows, b.accumulate)
-            else:
-                self._gemm(x, w, y, n, 2 * b.l + 1, b.mul_in, b.mul_out, sp.dim_in, b.in_off, sp.dim_out,
-                           b.out_off, None, b.accumulate)
+        self._run_groups(lin.groups_fwd, x, y, n, sp.dim_in, sp.dim_out, g)
         return y
 
     def _linear_T(self, lin: _Linear, gy, n, g: Graph, out=None, accumulate=False):
@@ -254,22 +288,7 @@ class HipForceEngine:
             for off, (m, l, _) in zip(sp.irreps_in.offsets(), sp.irreps_in):
                 if off not in fed:
                     gx[:, off:off + m * (2 * l + 1)].zero_()
-        done_in, cur_pair = set(), None
-        for b, wt in zip(sp.blocks, lin.wt):
-            pair = (b.in_off, b.out_off)
-            if pair != cur_pair:
-                if cur_pair is not None:
-                    done_in.add(cur_pair[0])
-                cur_pair = pair
-            acc = accumulate or (b.in_off in done_in)
-            rows, cnt = None, n
-            if b.species >= 0:
-                rows = g.species_rows[b.species]
-                cnt = rows.numel()
-                if cnt == 0:
-                    continue
-            self._gemm(gy, wt, gx, cnt, 2 * b.l + 1, b.mul_out, b.mul_in, sp.dim_out, b.out_off, sp.dim_in,
-                       b.in_off, rows, acc)
+        self._run_groups(lin.groups_T, gy, gx, n, sp.dim_out, sp.dim_in, g, force_acc=accumulate)
         return gx
 
     def _mlp_fwd(self, L, emb, E):

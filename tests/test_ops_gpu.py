@@ -51,6 +51,27 @@ def test_gemm_vs_torch(shape):
     assert C2[mask].abs().max() == 0
 
 
+def test_gemm_grouped_matches_separate_launches():
+    L, lib = _lib()
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(8)
+    n, din, dout = 1234, 480, 576
+    # SevenNet-0 self-connection shapes: 128x0e->224x0e, 64x1e->64x1e, 32x2e->32x2e
+    probs = [(1, 128, 224, 0, 0), (3, 64, 64, 128, 224), (5, 32, 32, 320, 416)]
+    A = torch.randn(n, din, generator=g).to(dev)
+    Bs = [torch.randn(K, N, generator=g).to(dev) for (_, K, N, _, _) in probs]
+    C1 = torch.zeros(n, dout, device=dev)
+    C2 = torch.zeros(n, dout, device=dev)
+    for (d, K, N, ao, co), B in zip(probs, Bs):
+        L.check(lib.snet_gemm(_p(A), _p(B), _p(C1), n, d, K, N, din, ao, dout, co, None, 0, None))
+    descs = (L.GemmDesc * 3)(*[L.GemmDesc(B.data_ptr(), ao, co, d, K, N, 0) for (d, K, N, ao, co), B in zip(probs, Bs)])
+    L.check(lib.snet_gemm_grouped(descs, 3, _p(A), _p(C2), n, din, dout, None, None))
+    torch.cuda.synchronize()
+    assert torch.equal(C1, C2)
+    ref = (A[:, :128].double() @ Bs[0].double())
+    assert (C2[:, :224].double() - ref).abs().max() < 1e-3
+
+
 @pytest.mark.parametrize('mode', [0, 1])
 @pytest.mark.parametrize('nb,wn,E', [(8, 960, 5000), (8, 224, 333), (8, 12, 100), (12, 60, 257), (8, 384, 128)])
 def test_fused_radial_mlp_vs_torch(nb, wn, E, mode):
