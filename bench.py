@@ -201,8 +201,11 @@ def main():
             tr = json.load(f)
         key = dominant.replace('conv_bwd_edge[', 'conv_bwd_edge_vec_').replace('conv_fwd[', 'conv_fwd_') \
             .replace('conv_bwd_node[', 'conv_bwd_node_').rstrip(']')
-        if world == 1 and a.reps == 23 and key in tr:
-            roof['traffic'] = tr[key]['hbm_bytes_per_launch']
+        # a kernel class may be several kernels (one per x irrep block: <name>_k0, _k1, ...)
+        parts = [v for k, v in tr.items() if k == key or k.startswith(key + '_k')]
+        if world == 1 and a.reps == 23 and parts:
+            roof['traffic'] = sum(v['hbm_bytes_per_launch'] for v in parts)
+            roof['traffic_frac_of_peak'] = roof['traffic'] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             roof['traffic_source'] = os.path.basename(pmc) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)'
     except Exception:  # noqa: BLE001
         pass
