@@ -46,6 +46,8 @@ def aot_configs() -> Dict[str, dict]:
         'ts_example': TS_EXAMPLE_CONFIG,
         'unit_o3_l2': unit_test_config(),
         'unit_o3_l3': unit_test_config(lmax=3),
+        # instruction order of checkpoints older than 0.11 (tests/data/checkpoints/cp_0.pth is 0.10.0)
+        'unit_o3_l2_v010': unit_test_config(version='0.10.0'),
         'unit_so3_l2_linear': unit_test_config(is_parity=False, self_connection_type='linear'),
         'mini_7net0': mini_sevennet_0_config(),
         'sevennet_0': sevennet_0_config(),

@@ -230,3 +230,21 @@ def test_rccl_backend_halo_exchange_world1():
         assert torch.allclose(gx[:n_local], exp)
     finally:
         dist.destroy_process_group()
+
+
+def test_reference_checkpoint_weights_cp0():
+    """The reference's own test checkpoint (tests/data/checkpoints/cp_0.pth: trained Hf/O model,
+    channel 4, lmax 2, O(3) parity, 3 layers) fed unchanged (config + state_dict names) to the
+    engine; the oracle runs the same tensors in fp64."""
+    import json
+    from helpers import GOLDEN
+    d = np.load(f'{GOLDEN}/cp0_state.npz')
+    cfg = json.loads(str(d['__config__']))
+    sd = {k: d[k] for k in d.files if not k.startswith('__')}
+    g = np.load(f'{GOLDEN}/ts_oracle_hfo2_96.npz')  # 96-atom HfO2 structure shipped with the reference
+    from sevennet_amd.neighbor import neighbor_list
+    ei, ev, _ = neighbor_list(g['pos'], g['cell'], [True] * 3, cfg['cutoff'])
+    eng, out = _run(cfg, sd, g['types'], ei, ev, keep=True)
+    ref = oracle_model(cfg, sd).forward(g['types'], ei, ev, keep=True)
+    _compare(eng, out, ref, len(g['types']))
+    assert ref['forces'].abs().max().item() > 1e-2  # non-trivial forces
