@@ -214,7 +214,8 @@ def main():
 
     if rank == 0:
         res = {
-            'metric': 'atom-steps/sec (energy+forces), SevenNet-0 100k-atom cell, 1/2/4/8 MI355X',
+            'metric': 'atom-steps/sec (energy+forces), SevenNet-0 100k-atom cell, 1/2/4/8 MI355X' if a.model == 'sevennet_0'
+            else f'atom-steps/sec (energy+forces), {a.model} shape',
             'value': n_atoms * a.steps / dt, 'unit': 'atom-steps/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': step_ms, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

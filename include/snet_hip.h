@@ -209,6 +209,24 @@ int snet_gather_rows(const float *x, const int32_t *idx, float *out, int64_t n_i
 int snet_scatter_add_rows(const float *x, const int32_t *idx, float *y, int64_t n_idx, int32_t dim,
                           void *stream);
 
+/* ---- f1: neighbor list on the GPU (fully periodic cells) ---------------------
+ * replaces the host graph build unlabeled_atoms_to_graph / _graph_build_{ase,matscipy}
+ * (sevenn/train/dataload.py:32-129) and yields the CSR-by-center edge layout directly.
+ * cell_host[9] row-major lattice vectors (HOST), positions / wrapped positions fp64 (device).
+ * Every cell height must be >= cutoff (rc 4 otherwise: use a host list for such tiny cells).
+ * Sequence: snet_nl_grid (bins per axis) -> snet_nl_bin (wrapped positions, image index, bin id)
+ * -> [caller sorts atoms by bin id: order[], bin_start[]] -> snet_nl_count -> [exclusive scan:
+ * row_ptr] -> snet_nl_fill (src, center, edge_vec fp32, optional image shifts).              */
+int snet_nl_grid(const double *cell_host, double cutoff, int32_t *nbins_host);
+int snet_nl_bin(const double *cell_host, double cutoff, const double *pos, int64_t n_atoms, double *wpos,
+                int32_t *wrap, int32_t *cell_id, void *stream);
+int snet_nl_count(const double *cell_host, double cutoff, const double *wpos, const int32_t *cell_id,
+                  const int32_t *order, const int32_t *bin_start, int64_t n_atoms, int32_t *count, void *stream);
+int snet_nl_fill(const double *cell_host, double cutoff, const double *wpos, const int32_t *wrap,
+                 const int32_t *cell_id, const int32_t *order, const int32_t *bin_start, int64_t n_atoms,
+                 const int32_t *row_ptr, int32_t *src, int32_t *center, float *edge_vec, int32_t *shifts,
+                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,13 @@ SIGNATURES = {
                                       c_stream]),
     'snet_edge_force': (C.c_int, [c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_int64, c_f32p, c_f32p,
                                   c_f64p, c_stream]),
+    'snet_nl_grid': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int32)]),
+    'snet_nl_bin': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.c_void_p, C.c_int64, C.c_void_p, c_i32p, c_i32p,
+                              c_stream]),
+    'snet_nl_count': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.c_void_p, c_i32p, c_i32p, c_i32p, C.c_int64,
+                                c_i32p, c_stream]),
+    'snet_nl_fill': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.c_void_p, c_i32p, c_i32p, c_i32p, c_i32p,
+                               C.c_int64, c_i32p, c_i32p, c_i32p, c_f32p, c_i32p, c_stream]),
     'snet_gather_rows': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
     'snet_scatter_add_rows': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
 }

@@ -25,6 +25,7 @@ import torch
 
 from .engine import HipForceEngine, build_graph
 from .neighbor import neighbor_list
+from .neighbor_gpu import build_graph_gpu, gpu_neighbor_supported
 
 try:  # ASE is not a hard dependency of the engine
     from ase.calculators.calculator import Calculator, all_changes
@@ -131,8 +132,14 @@ class SevenNetCalculator(Calculator):
             bad = sorted(set(numbers[types < 0].tolist()))
             raise ValueError(f'Model do not know atomic number: {bad[0]}, (knows: {list(self.type_map.keys())})')
         cell = np.asarray(cell, np.float64).reshape(3, 3)
-        ei, ev, _ = neighbor_list(positions, cell, pbc, self.cutoff)
-        g = build_graph(types, ei, ev, device=str(self.device), num_species=self.model.spec.num_species)
+        ns = self.model.spec.num_species
+        if gpu_neighbor_supported(cell, pbc, self.cutoff):  # bulk periodic cell: cell list on the GPU
+            g = build_graph_gpu(types, positions, cell, self.cutoff, device=str(self.device), num_species=ns)
+            n_edges = g.n_edges
+        else:  # molecules, slabs, cells smaller than the cutoff: host KD-tree
+            ei, ev, _ = neighbor_list(positions, cell, pbc, self.cutoff)
+            g = build_graph(types, ei, ev, device=str(self.device), num_species=ns)
+            n_edges = int(ei.shape[1])
         out = self.model.compute(g, want_atomic_virial=self.compute_atomic_virial)
         energy = float(out['energy'].cpu())
         vol = abs(float(np.linalg.det(cell)))
@@ -142,7 +149,7 @@ class SevenNetCalculator(Calculator):
             'free_energy': energy, 'energy': energy,
             'energies': out['atomic_energy'].cpu().numpy().astype(np.float64),
             'forces': out['forces'].cpu().numpy().astype(np.float64),
-            'stress': stress, 'num_edges': int(ei.shape[1]),
+            'stress': stress, 'num_edges': n_edges,
         }
         if self.compute_atomic_virial:
             res['stresses'] = out['atomic_virial'].cpu().numpy()

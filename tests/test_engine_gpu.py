@@ -248,3 +248,48 @@ def test_reference_checkpoint_weights_cp0():
     ref = oracle_model(cfg, sd).forward(g['types'], ei, ev, keep=True)
     _compare(eng, out, ref, len(g['types']))
     assert ref['forces'].abs().max().item() > 1e-2  # non-trivial forces
+
+
+@pytest.mark.parametrize('case', ['si_444', 'si_222', 'si_111', 'hfo2_triclinic'])
+def test_gpu_neighbor_list_matches_host(case):
+    """f1: device cell-list graph build == host KD-tree build (same edge multiset, incl. the
+    multi-image cases nb = 1, 2 bins per axis and a triclinic cell); engine results agree."""
+    from sevennet_amd.neighbor import diamond_cubic, neighbor_list
+    from sevennet_amd.neighbor_gpu import build_graph_gpu, gpu_neighbor_supported
+    if case.startswith('si_'):
+        r = int(case[3])
+        pos, cell = diamond_cubic(5.431, (r, r, r), 0.1, 7)
+        pos = pos + 3.7  # some atoms outside the cell: wrapping must not change edge vectors
+        cutoff, types = 5.0, np.zeros(len(pos), np.int64)
+    else:
+        g = np.load(f'{__import__("helpers").GOLDEN}/ts_oracle_hfo2_96.npz')
+        pos, cell, cutoff, types = g['pos'], g['cell'], 4.0, g['types']
+    assert gpu_neighbor_supported(cell, [True] * 3, cutoff)
+    ei, ev, S = neighbor_list(pos, cell, [True] * 3, cutoff)
+    gg = build_graph_gpu(types, pos, cell, cutoff, with_shifts=True)
+    torch.cuda.synchronize()
+    assert gg.n_edges == ei.shape[1]
+    c, s, v, sh = gg.center.cpu().numpy(), gg.src.cpu().numpy(), gg.edge_vec.cpu().numpy(), gg.shifts.cpu().numpy()
+    assert (np.diff(c) >= 0).all() and (np.bincount(c, minlength=len(pos)) == np.diff(gg.row_ptr.cpu().numpy())).all()
+
+    def canon(i, j, S_, vec):
+        key = np.lexsort((S_[:, 2], S_[:, 1], S_[:, 0], j, i))
+        return i[key], j[key], S_[key], vec[key]
+    a = canon(ei[0], ei[1], S, ev)
+    b = canon(c.astype(np.int64), s.astype(np.int64), sh.astype(np.int64), v.astype(np.float64))
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+    assert np.abs(a[3] - b[3]).max() < 2e-6
+    assert not gpu_neighbor_supported(cell, [True, True, False], cutoff)
+    assert not gpu_neighbor_supported(cell * 0.3, [True] * 3, cutoff)
+
+
+def test_sevennet_l3i5_shape_vs_oracle_small_cell():
+    """BASELINE config 4 shape (lmax 3, 34 paths per middle layer) on a small cell, fp32 GPU vs fp64 oracle"""
+    from sevennet_amd.model_spec import sevennet_l3i5_config
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = sevennet_l3i5_config()
+    sd = random_state_dict(cfg, seed=1)
+    types, pos, cell, ei, ev = synthetic_system((1, 1, 2), sigma=0.3, seed=3, cutoff=5.0)
+    eng, out = _run(cfg, sd, types, ei, ev, keep=True)
+    ref = oracle_model(cfg, sd).forward(types, ei, ev, keep=True)
+    _compare(eng, out, ref, len(types), rel=1e-4)
