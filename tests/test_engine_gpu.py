@@ -280,7 +280,8 @@ def test_gpu_neighbor_list_matches_host(case):
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
     assert np.abs(a[3] - b[3]).max() < 2e-6
     assert not gpu_neighbor_supported(cell, [True, True, False], cutoff)
-    assert not gpu_neighbor_supported(cell * 0.3, [True] * 3, cutoff)
+    small = np.eye(3) * (0.9 * cutoff)
+    assert not gpu_neighbor_supported(small, [True] * 3, cutoff)  # a height below the cutoff: host builder
 
 
 def test_sevennet_l3i5_shape_vs_oracle_small_cell():
