@@ -122,35 +122,34 @@ def build_brick_graph(pos, cell, types, cutoff: float, world: int, rank: int, gr
 
 
 # --------------------------------------------------------------------------- #
-# row pack / unpack: HIP kernels for device tensors
+# row pack / unpack: HIP kernels (device tensors only -- there is no host implementation in the
+# product; the gloo tests of the exchange plan subclass HaloExchange with torch index ops)
 # --------------------------------------------------------------------------- #
 def _gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    if not x.is_cuda:
+        raise RuntimeError('halo pack needs ROCm tensors (libsnet_hip.so kernels); no host path exists')
     out = torch.empty(idx.numel(), x.shape[1], dtype=x.dtype, device=x.device)
     if idx.numel() == 0:
         return out
-    if x.is_cuda:
-        from . import _lib
-        lib = _lib.load()
-        _lib.check(lib.snet_gather_rows(C.c_void_p(x.data_ptr()), C.c_void_p(idx.data_ptr()), C.c_void_p(out.data_ptr()),
-                                        idx.numel(), x.shape[1], C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                   'snet_gather_rows')
-    else:  # host tensors (gloo tests of the exchange plan)
-        torch.index_select(x, 0, idx.long(), out=out)
+    from . import _lib
+    lib = _lib.load()
+    _lib.check(lib.snet_gather_rows(C.c_void_p(x.data_ptr()), C.c_void_p(idx.data_ptr()), C.c_void_p(out.data_ptr()),
+                                    idx.numel(), x.shape[1], C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               'snet_gather_rows')
     return out
 
 
 def _scatter_add_rows(y: torch.Tensor, idx: torch.Tensor, x: torch.Tensor):
     """y[idx[i]] += x[i]; idx unique within one call (one peer's list)."""
+    if not y.is_cuda:
+        raise RuntimeError('halo unpack needs ROCm tensors (libsnet_hip.so kernels); no host path exists')
     if idx.numel() == 0:
         return
-    if y.is_cuda:
-        from . import _lib
-        lib = _lib.load()
-        _lib.check(lib.snet_scatter_add_rows(C.c_void_p(x.data_ptr()), C.c_void_p(idx.data_ptr()), C.c_void_p(y.data_ptr()),
-                                             idx.numel(), y.shape[1], C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                   'snet_scatter_add_rows')
-    else:
-        y.index_add_(0, idx.long(), x)
+    from . import _lib
+    lib = _lib.load()
+    _lib.check(lib.snet_scatter_add_rows(C.c_void_p(x.data_ptr()), C.c_void_p(idx.data_ptr()), C.c_void_p(y.data_ptr()),
+                                         idx.numel(), y.shape[1], C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               'snet_scatter_add_rows')
 
 
 class HaloExchange:
@@ -168,10 +167,17 @@ class HaloExchange:
         self.peer_idx = [torch.as_tensor(np.asarray(s), dtype=torch.int32, device=self.dev) for s in send_lists]
         self.n_ghost = sum(self.recv_counts)
 
+    # pack / unpack primitives (overridable: the CPU tests of the exchange plan use host tensors)
+    def _pack(self, x, idx):
+        return _gather_rows(x, idx)
+
+    def _unpack_add(self, y, idx, rows):
+        _scatter_add_rows(y, idx, rows)
+
     def forward(self, x: torch.Tensor, n_local: int):
         """Fill ghost rows x[n_local:] with the owners' rows."""
         assert x.shape[0] == n_local + self.n_ghost and x.is_contiguous()
-        send = _gather_rows(x, self.send_idx)
+        send = self._pack(x, self.send_idx)
         self.dist.all_to_all_single(x[n_local:], send, self.recv_counts, self.send_counts, group=self.group)
 
     def reverse(self, gx: torch.Tensor, n_local: int):
@@ -182,7 +188,7 @@ class HaloExchange:
         self.dist.all_to_all_single(recv, gx[n_local:].contiguous(), self.send_counts, self.recv_counts, group=self.group)
         o = 0
         for idx, c in zip(self.peer_idx, self.send_counts):  # one peer at a time: deterministic sums
-            _scatter_add_rows(gx, idx, recv[o:o + c])
+            self._unpack_add(gx, idx, recv[o:o + c])
             o += c
 
 

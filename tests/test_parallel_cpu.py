@@ -30,6 +30,21 @@ def _make_case():
     return cfg, sd, types, pos, cell, ei, ev
 
 
+def _host_halo(send_lists, recv_counts):
+    """The product HaloExchange packs with HIP kernels only; for the CPU/gloo test of the exchange PLAN
+    the two row primitives are replaced by torch index ops on host tensors."""
+    from sevennet_amd.parallel import HaloExchange
+
+    class HostHalo(HaloExchange):
+        def _pack(self, x, idx):
+            return x.index_select(0, idx.long())
+
+        def _unpack_add(self, y, idx, rows):
+            y.index_add_(0, idx.long(), rows)
+
+    return HostHalo(send_lists, recv_counts, 'cpu')
+
+
 class _Exchange(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h_local, halo, n_local, n_total):
@@ -51,11 +66,11 @@ def _worker(rank, world, port, q):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from sevennet_amd.parallel import HaloExchange, build_brick_graph
+        from sevennet_amd.parallel import build_brick_graph
         torch.set_num_threads(1)
         cfg, sd, types, pos, cell, ei, ev = _make_case()
         bg = build_brick_graph(pos, cell, types, cfg['cutoff'], world, rank)
-        halo = HaloExchange(bg.send_lists, bg.recv_counts, 'cpu')
+        halo = _host_halo(bg.send_lists, bg.recv_counts)
         m = oracle_model(cfg, sd)
         nt = len(bg.types)
         out = m.forward_brick(bg.types, bg.edge_index, bg.edge_vec, bg.n_local,
