@@ -227,6 +227,41 @@ int snet_nl_fill(const double *cell_host, double cutoff, const double *wpos, con
                  const int32_t *row_ptr, int32_t *src, int32_t *center, float *edge_vec, int32_t *shifts,
                  void *stream);
 
+/* ---- whole-model sequencer ------------------------------------------------------------------
+ * replaces, for a native (C++) host, `model.forward(input_dict)` + `torch::autograd::grad(...)` of
+ * the LAMMPS pair styles (sevenn/pair_e3gnn/pair_e3gnn.cpp:200-207, pair_e3gnn_parallel.cpp:424-503)
+ * and the TorchScript archive they load (`torch::jit::load`, pair_e3gnn.cpp:356).  The model comes
+ * from a `.snet` file written by sevennet_amd.model_file.write_model_file (the analogue of
+ * `sevenn get_model`, sevenn/scripts/deploy.py:16-76).  One evaluation runs the op sequence above on
+ * the caller's stream out of a grow-only device arena owned by the model: no per-step allocation
+ * once the largest system has been seen.                                                        */
+typedef struct snet_model snet_model;
+int snet_model_load(const char *path, snet_model **model);
+int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_model **model);
+void snet_model_destroy(snet_model *model);
+/* cutoff, species count, number of interaction layers and (comm_dims[t], t < max_layers) the row
+ * width of the ghost exchange before layer t -- what pair_e3gnn_parallel.cpp:571-660 reads from the
+ * archive's extra files ("cutoff", "comm_size", ...).  Any output pointer may be NULL. */
+int snet_model_info(const snet_model *model, float *cutoff, int32_t *n_species, int32_t *n_layers,
+                    int32_t *comm_dims, int32_t max_layers);
+/* Ghost exchange hooks (pair_e3gnn_parallel.cpp:369,435; comm_brick.cpp:1057-1123):
+ *   forward(user, x[n_total,dim], ...)  fill rows n_local.. with their owners' rows
+ *   reverse(user, gx[n_total,dim], ...) add rows n_local.. into their owners' rows
+ * x is a DEVICE pointer, work must be ordered on `stream`; return non-zero to abort the evaluation.
+ * Needed iff an evaluation has n_total > n_local. */
+typedef int (*snet_halo_fn)(void *user, float *x, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
+int snet_model_set_halo(snet_model *model, snet_halo_fn forward, snet_halo_fn reverse, void *user);
+/* One energy/force evaluation.  Device inputs: types[n_total] species index, row_ptr[n_local+1] /
+ * src[E] edges sorted by center (CSR), col_ptr[n_total+1] / eperm[E] the same edges grouped by source,
+ * edge_vec[E,3] = r_src - r_center.  types_host[n_local] (HOST, may be NULL for models without a
+ * per-species self-connection).  Device outputs, each nullable: energy (double), e_atom[n_local],
+ * dE_dr[E,3], forces[n_total,3] (ghost rows folded into owners when halo hooks are set),
+ * virial[6] (double, xx yy zz xy yz zx = -sum r (x) dE/dr), virial_atom[n_total,6].             */
+int snet_model_eval(snet_model *model, int64_t n_total, int64_t n_local, int64_t n_edges, const int32_t *types,
+                    const int32_t *types_host, const int32_t *row_ptr, const int32_t *src, const int32_t *col_ptr,
+                    const int32_t *eperm, const float *edge_vec, double *energy, float *e_atom, float *dE_dr,
+                    float *forces, double *virial, float *virial_atom, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,7 +89,17 @@ SIGNATURES = {
                                C.c_int64, c_i32p, c_i32p, c_i32p, c_f32p, c_i32p, c_stream]),
     'snet_gather_rows': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
     'snet_scatter_add_rows': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
+    'snet_model_load': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    'snet_model_load_memory': (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
+    'snet_model_destroy': (None, [C.c_void_p]),
+    'snet_model_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32), C.c_int32]),
+    'snet_model_set_halo': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'snet_model_eval': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p,
+                                  c_i32p, c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, c_stream]),
 }
+
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p)
 
 _lib = None
 

@@ -1,0 +1,501 @@
+// Native whole-model sequencer: loads a `.snet` model file (sevennet_amd/model_file.py) and runs one
+// energy + force evaluation entirely through this library's kernels -- the engine a C++ host (the
+// LAMMPS pair styles, sevenn/pair_e3gnn/pair_e3gnn.cpp:74-289 and pair_e3gnn_parallel.cpp:194-528)
+// calls instead of `model.forward` + `torch::autograd::grad`.  Same op sequence as the Python host
+// (sevennet_amd/engine.py), no torch, no Python.  Ghost-feature exchange is left to the host through
+// two callbacks invoked at the reference's exchange points (pair_e3gnn_parallel.cpp:369,435).
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "snet_common.h"
+
+namespace {
+
+struct Reader {
+  const unsigned char *p, *end;
+  bool ok = true;
+  void get(void *dst, size_t n) {
+    if (!ok || (size_t)(end - p) < n) {
+      ok = false;
+      return;
+    }
+    memcpy(dst, p, n);
+    p += n;
+  }
+  int32_t i32() {
+    int32_t v = 0;
+    get(&v, 4);
+    return v;
+  }
+  float f32() {
+    float v = 0;
+    get(&v, 4);
+    return v;
+  }
+  std::vector<float> farr(size_t n) {
+    std::vector<float> v(ok ? n : 0);
+    if (n) get(v.data(), 4 * n);
+    return v;
+  }
+};
+
+struct Block {
+  int l, in_off, mul_in, out_off, mul_out, species, accumulate;
+  float *W = nullptr, *WT = nullptr;  // device [K,N] and [N,K]
+};
+struct Linear {
+  int dim_in = 0, dim_out = 0, n_species = 0;
+  std::vector<Block> blocks;
+  std::vector<std::pair<int, int>> zero, zero_in;  // output / input column ranges no block touches
+  struct Group {
+    int species;
+    std::vector<snet_gemm_desc> descs;
+  };
+  std::vector<Group> fwd, rev;  // launch plans: per-irrep GEMMs with distinct targets share a launch
+  bool present() const { return dim_out > 0; }
+};
+
+// Same grouping rule as the Python host (engine.py::_Linear._plan): a block joins the previous launch
+// when it has the same row list and a target no member of that launch writes; a target written by an
+// earlier launch with the same row list accumulates.
+void plan_groups(Linear &L, bool transpose) {
+  auto &groups = transpose ? L.rev : L.fwd;
+  std::vector<std::pair<int, int>> written;
+  std::vector<std::vector<int>> targets;
+  for (const Block &b : L.blocks) {
+    const int tgt = transpose ? b.in_off : b.out_off;
+    bool acc = false;
+    for (auto &w : written) acc |= (w.first == tgt && w.second == b.species);
+    snet_gemm_desc d;
+    d.B = transpose ? b.WT : b.W;
+    d.a_off = transpose ? b.out_off : b.in_off;
+    d.c_off = tgt;
+    d.d = 2 * b.l + 1;
+    d.K = transpose ? b.mul_out : b.mul_in;
+    d.N = transpose ? b.mul_in : b.mul_out;
+    d.accumulate = acc;
+    bool placed = false;
+    if (!groups.empty() && groups.back().species == b.species && groups.back().descs.size() < SNET_MAX_GEMM_GROUP) {
+      bool clash = false;
+      for (int t : targets.back()) clash |= (t == tgt);
+      if (!clash) {
+        groups.back().descs.push_back(d);
+        targets.back().push_back(tgt);
+        placed = true;
+      }
+    }
+    if (!placed) {
+      groups.push_back({b.species, {d}});
+      targets.push_back({tgt});
+    }
+    written.push_back({tgt, b.species});
+  }
+}
+struct Layer {
+  int dx, dmid, gin, dout, wn;
+  char tag[13];
+  float conv_scale;
+  int mlp[4];
+  snet_conv_plan *conv = nullptr;
+  snet_mlp_plan *mlp_plan = nullptr;
+  Linear sc, si1, si2;
+  std::vector<snet_gate_seg> segs;
+};
+
+bool dev_upload(const std::vector<float> &h, float **d) {
+  if (h.empty()) {
+    *d = nullptr;
+    return true;
+  }
+  if (hipMalloc((void **)d, h.size() * 4) != hipSuccess) return false;
+  return hipMemcpy(*d, h.data(), h.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+}
+
+bool read_linear(Reader &r, Linear &L) {
+  L.dim_in = r.i32();
+  L.dim_out = r.i32();
+  L.n_species = r.i32();
+  const int nb = r.i32(), nz = r.i32(), nzi = r.i32();
+  if (!r.ok || nb < 0 || nb > 4096 || nz < 0 || nz > 4096 || nzi < 0 || nzi > 4096) return false;
+  L.blocks.resize(nb);
+  for (auto &b : L.blocks) {
+    b.l = r.i32(); b.in_off = r.i32(); b.mul_in = r.i32(); b.out_off = r.i32(); b.mul_out = r.i32();
+    b.species = r.i32(); b.accumulate = r.i32();
+  }
+  for (int i = 0; i < nz; ++i) {
+    const int off = r.i32(), len = r.i32();
+    L.zero.push_back({off, len});
+  }
+  for (int i = 0; i < nzi; ++i) {
+    const int off = r.i32(), len = r.i32();
+    L.zero_in.push_back({off, len});
+  }
+  for (auto &b : L.blocks) {
+    std::vector<float> w = r.farr((size_t)b.mul_in * b.mul_out);
+    if (!r.ok) return false;
+    std::vector<float> wt(w.size());
+    for (int k = 0; k < b.mul_in; ++k)
+      for (int n = 0; n < b.mul_out; ++n) wt[(size_t)n * b.mul_in + k] = w[(size_t)k * b.mul_out + n];
+    if (!dev_upload(w, &b.W) || !dev_upload(wt, &b.WT)) return false;
+  }
+  plan_groups(L, false);
+  plan_groups(L, true);
+  return r.ok;
+}
+
+// bump allocator over one device arena (grown on demand between evaluations)
+struct Arena {
+  char *base = nullptr;
+  size_t cap = 0, off = 0;
+  float *f(size_t n) {
+    const size_t bytes = ((n * 4 + 255) / 256) * 256;
+    float *p = reinterpret_cast<float *>(base + off);
+    off += bytes;
+    return p;
+  }
+};
+
+}  // namespace
+
+struct snet_model {
+  int n_species, n_layers, lmax, normalize, n_basis, cutoff_kind, poly_p, act_radial, n_scale, d0;
+  float cutoff, cutoff_on, act_cst;
+  std::vector<float> coeffs;
+  float *embed = nullptr, *scale = nullptr, *shift = nullptr;
+  float scale0 = 1.f;
+  std::vector<Layer> layers;
+  Linear ro1, ro2;
+  Arena arena;
+  snet_halo_fn halo_fwd = nullptr, halo_rev = nullptr;
+  void *halo_user = nullptr;
+  std::vector<std::vector<int32_t>> species_rows_host;  // scratch
+  int32_t *species_rows = nullptr;                       // device, concatenated
+  size_t species_rows_cap = 0;
+  std::vector<int64_t> species_off, species_cnt;
+};
+
+namespace {
+
+int run_linear(snet_model *m, const Linear &L, const float *x, float *y, int64_t n, bool transpose, bool accumulate_all,
+               hipStream_t st) {
+  if (n <= 0) return 0;
+  const int64_t a_stride = transpose ? L.dim_out : L.dim_in, c_stride = transpose ? L.dim_in : L.dim_out;
+  if (!accumulate_all)  // column ranges no launch writes
+    for (auto &z : transpose ? L.zero_in : L.zero)
+      if (hipMemset2DAsync(y + z.first, (size_t)c_stride * 4, 0, (size_t)z.second * 4, (size_t)n, st) != hipSuccess) {
+        snet::set_error("snet_model_eval: memset failed");
+        return 1;
+      }
+  for (const Linear::Group &g : transpose ? L.rev : L.fwd) {
+    const int32_t *rows = nullptr;
+    int64_t cnt = n;
+    if (g.species >= 0) {
+      cnt = m->species_cnt[g.species];
+      rows = m->species_rows + m->species_off[g.species];
+      if (cnt == 0) continue;
+    }
+    int rc;
+    if (accumulate_all) {
+      snet_gemm_desc tmp[SNET_MAX_GEMM_GROUP];
+      for (size_t i = 0; i < g.descs.size(); ++i) {
+        tmp[i] = g.descs[i];
+        tmp[i].accumulate = 1;
+      }
+      rc = snet_gemm_grouped(tmp, (int)g.descs.size(), x, y, cnt, a_stride, c_stride, rows, st);
+    } else {
+      rc = snet_gemm_grouped(g.descs.data(), (int)g.descs.size(), x, y, cnt, a_stride, c_stride, rows, st);
+    }
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_model **out) {
+  SNET_REQUIRE(blob != nullptr && out != nullptr && n_bytes > 8, "snet_model_load: null / empty model");
+  Reader r{static_cast<const unsigned char *>(blob), static_cast<const unsigned char *>(blob) + n_bytes};
+  char magic[8];
+  r.get(magic, 8);
+  SNET_REQUIRE(r.ok && memcmp(magic, "SNETMDL1", 8) == 0, "snet_model_load: not a .snet model file");
+  auto *m = new snet_model;
+  m->n_species = r.i32(); m->n_layers = r.i32(); m->lmax = r.i32(); m->normalize = r.i32(); m->n_basis = r.i32();
+  m->cutoff_kind = r.i32(); m->poly_p = r.i32(); m->act_radial = r.i32(); m->n_scale = r.i32(); m->d0 = r.i32();
+  m->cutoff = r.f32(); m->cutoff_on = r.f32(); m->act_cst = r.f32();
+  bool good = r.ok && m->n_layers > 0 && m->n_layers < 64 && m->n_basis > 0 && m->n_basis <= 16 && m->n_species > 0;
+  if (good) {
+    m->coeffs = r.farr(m->n_basis);
+    std::vector<float> emb = r.farr((size_t)m->n_species * m->d0), sc = r.farr(m->n_scale), sh = r.farr(m->n_scale);
+    good = r.ok && dev_upload(emb, &m->embed) && dev_upload(sc, &m->scale) && dev_upload(sh, &m->shift);
+    if (good) m->scale0 = sc[0];
+  }
+  for (int t = 0; good && t < m->n_layers; ++t) {
+    Layer L;
+    L.dx = r.i32(); L.dmid = r.i32(); L.gin = r.i32(); L.dout = r.i32(); L.wn = r.i32();
+    r.get(L.tag, 12);
+    L.tag[12] = 0;
+    L.conv_scale = r.f32();
+    for (int i = 0; i < 4; ++i) L.mlp[i] = r.i32();
+    if (!r.ok) { good = false; break; }
+    std::vector<float> w0 = r.farr((size_t)L.mlp[0] * L.mlp[1]), w1 = r.farr((size_t)L.mlp[1] * L.mlp[2]),
+                       w2 = r.farr((size_t)L.mlp[2] * L.mlp[3]);
+    good = r.ok && L.mlp[3] == L.wn;
+    if (good && snet_radial_mlp_plan_create(L.mlp[0], L.mlp[1], L.mlp[2], L.mlp[3], w0.data(), w1.data(), w2.data(),
+                                            m->act_radial, m->act_cst, 1, &L.mlp_plan)) good = false;
+    if (good && snet_conv_plan_create(L.tag, &L.conv)) good = false;
+    good = good && read_linear(r, L.sc) && read_linear(r, L.si1) && read_linear(r, L.si2);
+    if (good) {
+      const int ns = r.i32();
+      good = r.ok && ns >= 1 && ns <= SNET_MAX_GATE_SEGS;
+      for (int i = 0; good && i < ns; ++i) {
+        snet_gate_seg s;
+        s.kind = r.i32(); s.in_off = r.i32(); s.out_off = r.i32(); s.mul = r.i32(); s.l = r.i32();
+        s.gate_off = r.i32(); s.act = r.i32(); s.cst = r.f32();
+        L.segs.push_back(s);
+      }
+      good = good && r.ok;
+    }
+    m->layers.push_back(L);
+  }
+  good = good && read_linear(r, m->ro1) && read_linear(r, m->ro2) && r.p == r.end;
+  if (!good) {
+    const std::string prev = snet_last_error();
+    snet::set_error("snet_model_load: malformed model file or device upload failed" +
+                    (prev.empty() ? std::string() : " (" + prev + ")"));
+    delete m;
+    return 1;
+  }
+  *out = m;
+  return 0;
+}
+
+extern "C" int snet_model_load(const char *path, snet_model **out) {
+  SNET_REQUIRE(path != nullptr, "snet_model_load: null path");
+  FILE *f = fopen(path, "rb");
+  if (!f) {
+    snet::set_error(std::string("snet_model_load: cannot open ") + path);
+    return 1;
+  }
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  std::vector<unsigned char> buf(n > 0 ? n : 0);
+  const size_t got = n > 0 ? fread(buf.data(), 1, n, f) : 0;
+  fclose(f);
+  SNET_REQUIRE((long)got == n && n > 0, "snet_model_load: short read");
+  return snet_model_load_memory(buf.data(), n, out);
+}
+
+extern "C" void snet_model_destroy(snet_model *m) {
+  if (!m) return;
+  auto free_lin = [](Linear &L) {
+    for (auto &b : L.blocks) {
+      if (b.W) (void)hipFree(b.W);
+      if (b.WT) (void)hipFree(b.WT);
+    }
+  };
+  for (auto &L : m->layers) {
+    snet_conv_plan_destroy(L.conv);
+    snet_radial_mlp_plan_destroy(L.mlp_plan);
+    free_lin(L.sc); free_lin(L.si1); free_lin(L.si2);
+  }
+  free_lin(m->ro1); free_lin(m->ro2);
+  for (void *d : {(void *)m->embed, (void *)m->scale, (void *)m->shift, (void *)m->arena.base, (void *)m->species_rows})
+    if (d) (void)hipFree(d);
+  delete m;
+}
+
+extern "C" int snet_model_info(const snet_model *m, float *cutoff, int32_t *n_species, int32_t *n_layers,
+                               int32_t *comm_dims, int32_t max_layers) {
+  SNET_REQUIRE(m != nullptr, "snet_model_info: null model");
+  if (cutoff) *cutoff = m->cutoff;
+  if (n_species) *n_species = m->n_species;
+  if (n_layers) *n_layers = m->n_layers;
+  if (comm_dims)
+    for (int t = 0; t < m->n_layers && t < max_layers; ++t) comm_dims[t] = m->layers[t].dx;
+  return 0;
+}
+
+extern "C" int snet_model_set_halo(snet_model *m, snet_halo_fn forward, snet_halo_fn reverse, void *user) {
+  SNET_REQUIRE(m != nullptr, "snet_model_set_halo: null model");
+  m->halo_fwd = forward;
+  m->halo_rev = reverse;
+  m->halo_user = user;
+  return 0;
+}
+
+extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, const int32_t *types,
+                               const int32_t *types_host, const int32_t *row_ptr, const int32_t *src,
+                               const int32_t *col_ptr, const int32_t *eperm, const float *edge_vec, double *energy,
+                               float *e_atom, float *dE_dr, float *forces, double *virial, float *virial_atom,
+                               void *stream) {
+  SNET_REQUIRE(m != nullptr, "snet_model_eval: null model");
+  SNET_REQUIRE(NT >= N && N > 0 && E >= 0, "snet_model_eval: need n_total >= n_local > 0 and n_edges >= 0");
+  SNET_REQUIRE(NT == N || (m->halo_fwd && m->halo_rev), "snet_model_eval: ghost atoms need halo callbacks");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nb = m->n_basis, nsh = (m->lmax + 1) * (m->lmax + 1);
+  const int Lc = m->n_layers;
+
+  // ---- per-species row lists (FCTP self-connection only)
+  bool need_rows = false;
+  for (auto &L : m->layers) need_rows |= L.sc.n_species > 0;
+  if (need_rows) {
+    SNET_REQUIRE(types_host != nullptr, "snet_model_eval: this model needs types_host (per-species self-connection)");
+    m->species_rows_host.assign(m->n_species, {});
+    for (int64_t i = 0; i < N; ++i) {
+      SNET_REQUIRE(types_host[i] >= 0 && types_host[i] < m->n_species, "snet_model_eval: species index out of range");
+      m->species_rows_host[types_host[i]].push_back((int32_t)i);
+    }
+    if (m->species_rows_cap < (size_t)N) {
+      if (m->species_rows) (void)hipFree(m->species_rows);
+      SNET_REQUIRE(hipMalloc((void **)&m->species_rows, (size_t)(N + 1) * 4) == hipSuccess, "snet_model_eval: alloc");
+      m->species_rows_cap = N;
+    }
+    m->species_off.assign(m->n_species, 0);
+    m->species_cnt.assign(m->n_species, 0);
+    int64_t o = 0;
+    for (int s = 0; s < m->n_species; ++s) {
+      auto &v = m->species_rows_host[s];
+      m->species_off[s] = o;
+      m->species_cnt[s] = (int64_t)v.size();
+      if (!v.empty())
+        SNET_REQUIRE(hipMemcpyAsync(m->species_rows + o, v.data(), v.size() * 4, hipMemcpyHostToDevice, st) == hipSuccess,
+                     "snet_model_eval: upload of species rows failed");
+      o += (int64_t)v.size();
+    }
+    SNET_REQUIRE(hipStreamSynchronize(st) == hipSuccess, "snet_model_eval: sync");  // host vectors are reused
+  }
+
+  // ---- arena sizing
+  size_t need = 0;
+  auto add = [&](size_t n) { need += ((n * 4 + 255) / 256) * 256; };
+  size_t dmax = (size_t)m->d0, trans = 0;
+  add((size_t)E * nb); add((size_t)E * nsh); add((size_t)E * nsh * 3); add((size_t)E * 3); add((size_t)E * nb);
+  for (auto &L : m->layers) {
+    dmax = dmax > (size_t)L.dout ? dmax : (size_t)L.dout;
+    add((size_t)NT * L.dx); add((size_t)E * L.wn); add((size_t)N * L.gin);  // saved h, w, y
+    const size_t t = ((size_t)N * L.gin + 64) * 2 + (size_t)N * L.dmid * 2 + (size_t)E * L.wn + (size_t)E * L.dx +
+                     (size_t)NT * L.dx * 2 + (size_t)N * L.dout + 4096;
+    trans = trans > t ? trans : t;
+  }
+  add((size_t)NT * dmax * 2 + 256); add((size_t)N * (m->ro1.dim_out + 8) * 2); add(trans + 64 * 1024);
+  need += 1 << 20;
+  if (m->arena.cap < need) {
+    if (m->arena.base) (void)hipFree(m->arena.base);
+    m->arena.base = nullptr;
+    m->arena.cap = 0;
+    SNET_REQUIRE(hipMalloc((void **)&m->arena.base, need) == hipSuccess, "snet_model_eval: arena allocation failed");
+    m->arena.cap = need;
+  }
+  Arena &A = m->arena;
+  A.off = 0;
+
+  snet_edge_params ep{m->cutoff, m->n_basis, m->cutoff_kind, m->poly_p, m->cutoff_on, m->lmax, m->normalize};
+  float *emb = A.f((size_t)E * nb), *sh = A.f((size_t)E * nsh), *dsh = A.f((size_t)E * nsh * 3);
+  float *g_vec = dE_dr ? dE_dr : A.f((size_t)E * 3), *g_emb = A.f((size_t)E * nb);
+  int rc;
+  if ((rc = snet_edge_embed_fwd(&ep, m->coeffs.data(), edge_vec, E, emb, sh, dsh, st))) return rc;
+  float *x = A.f((size_t)NT * dmax), *x2 = A.f((size_t)NT * dmax);
+  if ((rc = snet_embed_rows(m->embed, types, x, NT, m->d0, st))) return rc;
+
+  struct Saved { float *h, *w, *y; };
+  std::vector<Saved> saved(Lc);
+  for (int t = 0; t < Lc; ++t) {
+    saved[t].h = A.f((size_t)NT * m->layers[t].dx);
+    saved[t].w = A.f((size_t)E * m->layers[t].wn);
+    saved[t].y = A.f((size_t)N * m->layers[t].gin);
+  }
+  const size_t mark = A.off;  // transient region starts here
+
+  // ---------------- forward
+  for (int t = 0; t < Lc; ++t) {
+    Layer &L = m->layers[t];
+    A.off = mark;
+    float *sc = nullptr;
+    if (L.sc.present()) {
+      sc = A.f((size_t)N * L.gin);
+      if ((rc = run_linear(m, L.sc, x, sc, N, false, false, st))) return rc;
+    }
+    float *h = saved[t].h;
+    if ((rc = run_linear(m, L.si1, x, h, t == 0 ? NT : N, false, false, st))) return rc;
+    if (t > 0 && NT > N)
+      if ((rc = m->halo_fwd(m->halo_user, h, NT, N, L.dx, stream))) {
+        snet::set_error("snet_model_eval: forward halo callback failed");
+        return rc;
+      }
+    if ((rc = snet_radial_mlp_fwd(L.mlp_plan, emb, E, saved[t].w, st))) return rc;
+    float *mid = A.f((size_t)N * L.dmid);
+    if (E == 0) SNET_REQUIRE(hipMemsetAsync(mid, 0, (size_t)N * L.dmid * 4, st) == hipSuccess, "snet_model_eval: memset");
+    if ((rc = snet_conv_fwd(L.conv, h, sh, saved[t].w, row_ptr, src, N, L.conv_scale, mid, st))) return rc;
+    float *y = saved[t].y;
+    if ((rc = run_linear(m, L.si2, mid, y, N, false, false, st))) return rc;
+    if (sc && (rc = snet_add_inplace(y, sc, N * (int64_t)L.gin, st))) return rc;
+    if ((rc = snet_gate_fwd(y, x2, N, L.gin, L.dout, L.segs.data(), (int)L.segs.size(), st))) return rc;
+    std::swap(x, x2);
+  }
+  A.off = mark;
+  float *h1 = A.f((size_t)N * m->ro1.dim_out), *e_sc = A.f((size_t)N + 64);
+  if ((rc = run_linear(m, m->ro1, x, h1, N, false, false, st))) return rc;
+  if ((rc = run_linear(m, m->ro2, h1, e_sc, N, false, false, st))) return rc;
+  float *ea = e_atom ? e_atom : A.f((size_t)N + 64);
+  if ((rc = snet_rescale_reduce(e_sc, types, m->scale, m->shift, m->n_scale, N, ea, energy, st))) return rc;
+
+  // ---------------- reverse: dE/d(e_scaled) = scale[type]
+  float *g_e = A.f((size_t)N + 64);
+  if (m->n_scale > 1) {
+    if ((rc = snet_embed_rows(m->scale, types, g_e, N, 1, st))) return rc;
+  } else {
+    uint32_t bits;
+    memcpy(&bits, &m->scale0, 4);
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g_e), bits,
+                          (size_t)N, st) != hipSuccess) {
+      snet::set_error("snet_model_eval: fill failed");
+      return 1;
+    }
+  }
+  float *g_h1 = A.f((size_t)N * m->ro1.dim_out);
+  if ((rc = run_linear(m, m->ro2, g_e, g_h1, N, true, false, st))) return rc;
+  float *g_x = x2, *gx_next = x;  // the forward features are dead: x / x2 ping-pong as gradient rows
+  if ((rc = run_linear(m, m->ro1, g_h1, g_x, N, true, false, st))) return rc;
+  SNET_REQUIRE(hipMemsetAsync(g_vec, 0, (size_t)E * 3 * 4, st) == hipSuccess &&
+                   hipMemsetAsync(g_emb, 0, (size_t)E * nb * 4, st) == hipSuccess,
+               "snet_model_eval: memset failed");
+  const size_t mark2 = A.off;
+  for (int t = Lc - 1; t >= 0; --t) {
+    Layer &L = m->layers[t];
+    A.off = mark2;
+    float *g_y = A.f((size_t)N * L.gin);
+    if ((rc = snet_gate_bwd(saved[t].y, g_x, g_y, N, L.gin, L.dout, L.segs.data(), (int)L.segs.size(), st))) return rc;
+    float *g_m = A.f((size_t)N * L.dmid);
+    if ((rc = run_linear(m, L.si2, g_y, g_m, N, true, false, st))) return rc;
+    float *g_w = A.f((size_t)E * L.wn);
+    float *g_xe = t > 0 ? A.f((size_t)E * L.dx) : nullptr;
+    if ((rc = snet_conv_bwd_edge_vec(L.conv, saved[t].h, sh, dsh, saved[t].w, row_ptr, src, N, L.conv_scale, g_m, g_w,
+                                     g_xe, g_vec, st)))
+      return rc;
+    if ((rc = snet_radial_mlp_bwd(L.mlp_plan, emb, g_w, E, g_emb, st))) return rc;
+    if (t == 0) break;  // layer-0 inputs depend on species only
+    float *g_h = A.f((size_t)NT * L.dx);
+    if ((rc = snet_segment_sum_rows(g_xe, col_ptr, eperm, NT, L.dx, g_h, st))) return rc;
+    if (NT > N)
+      if ((rc = m->halo_rev(m->halo_user, g_h, NT, N, L.dx, stream))) {
+        snet::set_error("snet_model_eval: reverse halo callback failed");
+        return rc;
+      }
+    // g_x (for the previous layer's gate output) = SI1^T g_h + sc^T g_y
+    if ((rc = run_linear(m, L.si1, g_h, gx_next, N, true, false, st))) return rc;
+    if (L.sc.present())
+      if ((rc = run_linear(m, L.sc, g_y, gx_next, N, true, true, st))) return rc;
+    std::swap(g_x, gx_next);
+  }
+  if ((rc = snet_edge_embed_bwd(&ep, m->coeffs.data(), edge_vec, E, g_emb, nullptr, g_vec, 1, st))) return rc;
+  A.off = mark2;
+  float *F = forces ? forces : A.f((size_t)NT * 3);
+  if ((rc = snet_edge_force(g_vec, edge_vec, row_ptr, col_ptr, eperm, NT, E, F, virial_atom, virial, st))) return rc;
+  if (NT > N) {
+    if ((rc = m->halo_rev(m->halo_user, F, NT, N, 3, stream))) return rc;
+    if (virial_atom && (rc = m->halo_rev(m->halo_user, virial_atom, NT, N, 6, stream))) return rc;
+  }
+  return 0;
+}

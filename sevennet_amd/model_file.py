@@ -1,0 +1,103 @@
+"""`.snet` model file: the engine-side analogue of the reference's deployed TorchScript model.
+
+The reference deploys a checkpoint to a frozen TorchScript archive that the C++ LAMMPS pair styles
+load (sevenn/scripts/deploy.py:16-76, pair_e3gnn.cpp:308-411).  Here the deployable artefact is a
+flat little-endian binary consumed by `snet_model_load()` of libsnet_hip.so (csrc/snet_model.cpp):
+all tables of `ModelSpec` plus the weights with every normalisation already folded, so a native
+host needs no Python, no torch and no e3nn.
+
+Layout (all ints int32, floats float32 unless noted):
+    magic 'SNETMDL1'
+    header  : n_species n_layers lmax normalize n_basis cutoff_kind poly_p act_radial n_scale d0
+              cutoff(f32) cutoff_on(f32) act_cst(f32)
+    coeffs[n_basis]  embed[n_species*d0]  scale[n_scale]  shift[n_scale]
+    per layer: dx dmid gin dout wn  tag[12 bytes]  conv_scale(f32)
+               mlp dims[4]  W0 W1 W2 (row-major, 1/sqrt(fan_in) folded)
+               linear sc (all-zero header if absent), si1, si2   (see _write_linear)
+               n_gate_segs, segs[kind in_off out_off mul l gate_off act | cst f32]
+    readout linears ro1, ro2
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict
+
+import numpy as np
+
+from .model_spec import ACT_CST, ACT_ID, LinearSpec, build_model_spec, linear_weight_matrices
+
+MAGIC = b'SNETMDL1'
+
+
+def _i(*v):
+    return struct.pack('<%di' % len(v), *[int(x) for x in v])
+
+
+def _f(*v):
+    return struct.pack('<%df' % len(v), *[float(x) for x in v])
+
+
+def _arr(a):
+    return np.ascontiguousarray(a, dtype='<f4').tobytes()
+
+
+def _write_linear(spec: LinearSpec, flat) -> bytes:
+    """dim_in dim_out n_species n_blocks n_zero n_zero_in
+    | blocks[l in_off mul_in out_off mul_out species accumulate]
+    | zero[off len] (output columns no block writes) | zero_in[off len] (input columns no block reads)
+    | weights of every block, [K,N] row-major with alpha folded"""
+    if spec is None:
+        return _i(0, 0, 0, 0, 0, 0)
+    mats = linear_weight_matrices(spec, flat)
+    fed = {b.in_off for b in spec.blocks}
+    zero_in = [(off, m * (2 * l + 1)) for off, (m, l, _) in zip(spec.irreps_in.offsets(), spec.irreps_in)
+               if off not in fed]
+    out = [_i(spec.dim_in, spec.dim_out, spec.n_species, len(spec.blocks), len(spec.zero_out), len(zero_in))]
+    for b in spec.blocks:
+        out.append(_i(b.l, b.in_off, b.mul_in, b.out_off, b.mul_out, b.species, int(b.accumulate)))
+    for off, ln in list(spec.zero_out) + zero_in:
+        out.append(_i(off, ln))
+    for m in mats:
+        out.append(_arr(m))
+    return b''.join(out)
+
+
+def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray]) -> None:
+    sp = build_model_spec(config)
+    sd = {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, 'detach') else v, dtype=np.float64)
+          for k, v in state_dict.items()}
+    for k, shp in sp.param_shapes().items():
+        if k not in sd:
+            raise KeyError(f'state_dict is missing {k}')
+        sd[k] = sd[k].reshape(shp)
+    n_scale = sp.param_shapes()['rescale_atomic_energy.scale'][0]
+    embed = linear_weight_matrices(sp.embed, sd[sp.embed.name])[0]
+    out = [MAGIC,
+           _i(sp.num_species, len(sp.layers), sp.lmax_edge, int(sp.normalize_sph), sp.n_basis, sp.cutoff_kind,
+              sp.cutoff_p, ACT_ID[sp.act_radial], n_scale, sp.embed.dim_out),
+           _f(sp.cutoff, sp.cutoff_on, ACT_CST[sp.act_radial]),
+           _arr(sd['edge_embedding.basis_function.coeffs']), _arr(embed),
+           _arr(sd['rescale_atomic_energy.scale']), _arr(sd['rescale_atomic_energy.shift'])]
+    inv_act = {v: k for k, v in ACT_ID.items()}
+    for ls in sp.layers:
+        d = ls.mlp_dims
+        if len(d) != 4:
+            raise NotImplementedError('.snet files need a radial MLP with two hidden layers')
+        out.append(_i(ls.si1.dim_out, ls.conv.irreps_out.dim, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim,
+                      ls.conv.weight_numel))
+        out.append(ls.conv.tag.encode()[:12].ljust(12, b'\0'))
+        out.append(_f(1.0 / float(sd[f'{ls.t}_convolution.denominator'][0])))
+        out.append(_i(*d))
+        for i in range(3):
+            out.append(_arr(sd[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] / np.sqrt(d[i])))
+        out.append(_write_linear(ls.sc, sd[ls.sc.name] if ls.sc is not None else None))
+        out.append(_write_linear(ls.si1, sd[ls.si1.name]))
+        out.append(_write_linear(ls.si2, sd[ls.si2.name]))
+        out.append(_i(len(ls.gate.segs)))
+        for s in ls.gate.segs:
+            out.append(_i(s.kind, s.in_off, s.out_off, s.mul, s.l, s.gate_off, s.act))
+            out.append(_f(ACT_CST[inv_act[s.act]]))
+    out.append(_write_linear(sp.readout1, sd[sp.readout1.name]))
+    out.append(_write_linear(sp.readout2, sd[sp.readout2.name]))
+    with open(path, 'wb') as f:
+        f.write(b''.join(out))

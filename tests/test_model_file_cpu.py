@@ -1,0 +1,60 @@
+"""CPU: the `.snet` model-file writer and the loader's refusal paths (no GPU work)."""
+import struct
+
+import numpy as np
+import pytest
+
+
+def _write(tmp_path, cfg, seed=3):
+    from sevennet_amd.model_file import write_model_file
+    from sevennet_amd.synthetic import random_state_dict
+    sd = random_state_dict(cfg, seed=seed)
+    p = tmp_path / 'm.snet'
+    write_model_file(str(p), cfg, sd)
+    return p, sd
+
+
+def test_model_file_header_and_size(tmp_path):
+    from sevennet_amd.model_spec import ACT_CST, build_model_spec, sevennet_0_config
+    cfg = sevennet_0_config()
+    p, sd = _write(tmp_path, cfg)
+    blob = p.read_bytes()
+    assert blob[:8] == b'SNETMDL1'
+    sp = build_model_spec(cfg)
+    hdr = struct.unpack('<10i3f', blob[8:8 + 52])
+    assert hdr[0] == sp.num_species and hdr[1] == 5 and hdr[2] == 2 and hdr[4] == 8 and hdr[9] == 128
+    assert hdr[10] == pytest.approx(5.0) and hdr[12] == pytest.approx(ACT_CST['silu'])
+    # every weight of the state dict is in the file exactly once (plus tables): size lower bound
+    n_w = sum(int(np.prod(v.shape)) for k, v in sd.items() if 'weight' in k)
+    assert len(blob) > 4 * n_w
+    # first payload after the header: Bessel coefficients
+    coeffs = np.frombuffer(blob[60:60 + 32], '<f4')
+    assert np.allclose(coeffs, np.asarray(sd['edge_embedding.basis_function.coeffs'], np.float32))
+    # deterministic
+    p2, _ = _write(tmp_path / '..' / tmp_path.name, cfg)
+    assert p2.read_bytes() == blob
+
+
+def test_model_file_missing_weight_is_refused(tmp_path):
+    from sevennet_amd.model_file import write_model_file
+    from sevennet_amd.shapes import unit_test_config
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = unit_test_config()
+    sd = random_state_dict(cfg, seed=0)
+    sd.pop(next(k for k in sd if 'self_interaction_2' in k))
+    with pytest.raises(KeyError):
+        write_model_file(str(tmp_path / 'x.snet'), cfg, sd)
+
+
+def test_loader_rejects_non_model_files_without_gpu(tmp_path):
+    import ctypes as C
+    from sevennet_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    bad = tmp_path / 'bad.snet'
+    bad.write_bytes(b'definitely not a model file')
+    assert lib.snet_model_load(str(bad).encode(), C.byref(h)) != 0
+    assert b'not a .snet' in lib.snet_last_error()
+    assert lib.snet_model_load(str(tmp_path / 'nope').encode(), C.byref(h)) != 0
+    assert b'cannot open' in lib.snet_last_error()
+    assert not h.value
