@@ -248,9 +248,12 @@ int snet_model_info(const snet_model *model, float *cutoff, int32_t *n_species, 
  *   forward(user, x[n_total,dim], ...)  fill rows n_local.. with their owners' rows
  *   reverse(user, gx[n_total,dim], ...) add rows n_local.. into their owners' rows
  * x is a DEVICE pointer, work must be ordered on `stream`; return non-zero to abort the evaluation.
- * Needed iff an evaluation has n_total > n_local. */
+ * Needed iff an evaluation has n_total > n_local.  fold_forces != 0: the engine also calls `reverse`
+ * on forces[n_total,3] (and virial_atom) so ghost rows end up in their owners; 0: ghost rows are
+ * left to the host (LAMMPS folds them itself with reverse_comm when newton_pair is on). */
 typedef int (*snet_halo_fn)(void *user, float *x, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
-int snet_model_set_halo(snet_model *model, snet_halo_fn forward, snet_halo_fn reverse, void *user);
+int snet_model_set_halo(snet_model *model, snet_halo_fn forward, snet_halo_fn reverse, void *user,
+                        int32_t fold_forces);
 /* One energy/force evaluation.  Device inputs: types[n_total] species index, row_ptr[n_local+1] /
  * src[E] edges sorted by center (CSR), col_ptr[n_total+1] / eperm[E] the same edges grouped by source,
  * edge_vec[E,3] = r_src - r_center.  types_host[n_local] (HOST, may be NULL for models without a
@@ -261,6 +264,33 @@ int snet_model_eval(snet_model *model, int64_t n_total, int64_t n_local, int64_t
                     const int32_t *types_host, const int32_t *row_ptr, const int32_t *src, const int32_t *col_ptr,
                     const int32_t *eperm, const float *edge_vec, double *energy, float *e_atom, float *dE_dr,
                     float *forces, double *virial, float *virial_atom, void *stream);
+
+/* ---- MD host: LAMMPS-style neighbor list in, forces accumulated out --------------------------
+ * replaces the body of PairE3GNN::compute (sevenn/pair_e3gnn/pair_e3gnn.cpp:74-289) and the graph
+ * build + force epilogue of PairE3GNNParallel::compute (pair_e3gnn_parallel.cpp:194-306,459-506).
+ * All arrays are HOST pointers exactly as a pair style holds them:
+ *   inum, ilist[inum], numneigh[nall] (indexed by atom), firstneigh[nall] (rows of a FULL list,
+ *   entries may carry special-bond bits), x[nall,3] = &atom->x[0][0], type[nall] (1-based),
+ *   tag[nall] (tag_bytes 4 or 8), type_map[ntypes+1] = the pair style's `map` (type -> species).
+ * ghost_mode 0 (pair e3gnn): a neighbor is aliased to the local atom with the same tag, others are
+ *   dropped (tag_map, :102,147-149) -- one process holding the whole periodic cell.
+ * ghost_mode 1 (pair e3gnn/parallel): every ghost identity is a graph node after the inum locals
+ *   (tag_to_graph_idx, pair_e3gnn_parallel.cpp:262-287); set the model's halo hooks first (with
+ *   fold_forces 0: ghost forces are added to f[ghost] for LAMMPS' reverse_comm).  node_to_atom_out
+ *   (nullable, capacity nall) receives node -> atom index BEFORE the model runs, for those hooks.
+ * The neighbor filter (r^2 < cutoff^2 in fp64, edge_vec = x[j]-x[i] rounded to fp32), the CSR /
+ * source grouping, the model and the force / virial reduction all run on `stream`; results are
+ * ADDED to f[nall,3], *eng, virial[6] (LAMMPS order xx yy zz xy xz yz), eatom[nall], vatom[nall,6]
+ * as ev_tally-free pair styles do.  Blocking: returns after the results are on the host.        */
+typedef struct snet_md_host snet_md_host;
+int snet_md_create(snet_model *model, snet_md_host **host);
+void snet_md_destroy(snet_md_host *host);
+int snet_md_compute(snet_md_host *host, int32_t inum, const int32_t *ilist, const int32_t *numneigh,
+                    const int32_t *const *firstneigh, int32_t nall, const double *x, const int32_t *type,
+                    const void *tag, int32_t tag_bytes, const int32_t *type_map, int32_t ntypes, int32_t ghost_mode,
+                    int32_t eflag_atom, int32_t vflag, int32_t vflag_atom, double *f, double *eng, double *virial,
+                    double *eatom, double *vatom, int32_t *node_to_atom_out, int64_t *n_nodes_out,
+                    int64_t *n_edges_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,350 @@
+// MD-host glue: from the arrays a LAMMPS pair style holds (full neighbor list, x, type, tag) to
+// forces / energy / virial accumulated back into the host's arrays, with everything between --
+// cutoff filter, graph build, model evaluation, force and virial reduction -- on the GPU.
+//
+// Replaces the host loops of PairE3GNN::compute (sevenn/pair_e3gnn/pair_e3gnn.cpp:96-289: tag map,
+// O(E) neighbor filter on one CPU core, torch tensors, H2D, D2H of dE_dr[E,3], CPU scatter) and the
+// graph build of PairE3GNNParallel::compute (pair_e3gnn_parallel.cpp:228-306).  The host only
+// flattens the neighbor pages (one memcpy per atom) and builds the tag -> node table; what comes
+// back is forces[n,3] + a few scalars instead of one gradient per edge.
+#include <hipcub/hipcub.hpp>
+
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "snet_common.h"
+
+namespace {
+
+constexpr int NEIGH_MASK = 0x1FFFFFFF;  // LAMMPS NEIGHMASK (special-bond bits live above it)
+constexpr int GROUP = 16;               // lanes cooperating on one center atom's neighbor row
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t n) {
+    if (n <= cap) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = n + n / 4 + 64;  // headroom: the edge count drifts during MD (pair_e3gnn.cpp:281-288)
+    if (hipMalloc((void **)&p, want * sizeof(T)) != hipSuccess) return false;
+    cap = want;
+    return true;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+template <typename T>
+struct PinBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t n) {
+    if (n <= cap) return true;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = n + n / 4 + 64;
+    if (hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault) != hipSuccess) return false;
+    cap = want;
+    return true;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// one 16-lane group per center atom: count the neighbors that are graph nodes and inside the cutoff
+__global__ void md_count_kernel(const double *__restrict__ x, const int32_t *__restrict__ node_of,
+                                const int32_t *__restrict__ ilist, const int32_t *__restrict__ nb_ptr,
+                                const int32_t *__restrict__ neigh, int inum, double cutsq, int32_t *__restrict__ cnt) {
+  const int ii = (blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+  const int lane = threadIdx.x % GROUP;
+  int c = 0;
+  if (ii < inum) {
+    const int i = ilist[ii];
+    const double xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+    for (int k = nb_ptr[ii] + lane; k < nb_ptr[ii + 1]; k += GROUP) {
+      const int j = neigh[k] & NEIGH_MASK;
+      const double dx = x[3 * j] - xi, dy = x[3 * j + 1] - yi, dz = x[3 * j + 2] - zi;
+      c += (node_of[j] >= 0 && dx * dx + dy * dy + dz * dz < cutsq) ? 1 : 0;
+    }
+  }
+  for (int o = GROUP / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, GROUP);
+  if (ii < inum && lane == 0) cnt[ii] = c;
+}
+
+// same traversal, ordered compaction (the row keeps the neighbor list's order)
+__global__ void md_fill_kernel(const double *__restrict__ x, const int32_t *__restrict__ node_of,
+                               const int32_t *__restrict__ ilist, const int32_t *__restrict__ nb_ptr,
+                               const int32_t *__restrict__ neigh, const int32_t *__restrict__ row_ptr, int inum,
+                               double cutsq, int32_t *__restrict__ src, float *__restrict__ edge_vec) {
+  const int ii = (blockIdx.x * blockDim.x + threadIdx.x) / GROUP;
+  const int lane = threadIdx.x % GROUP;
+  const int shift = (threadIdx.x % 64) / GROUP * GROUP;  // this group's bits inside the wave ballot
+  const bool live = ii < inum;
+  const int i = live ? ilist[ii] : 0;
+  const int beg = live ? nb_ptr[ii] : 0, end = live ? nb_ptr[ii + 1] : 0;
+  const double xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2];
+  int base = live ? row_ptr[ii] : 0;
+  const int trips = (end - beg + GROUP - 1) / GROUP;
+  // every lane of the wave runs the same number of ballots: take the wave maximum
+  int tmax = trips;
+  for (int o = 32; o > 0; o >>= 1) tmax = max(tmax, __shfl_xor(tmax, o, 64));
+  for (int t = 0; t < tmax; ++t) {
+    const int k = beg + t * GROUP + lane;
+    bool keep = false;
+    int node = -1;
+    float dxf = 0.f, dyf = 0.f, dzf = 0.f;
+    if (k < end) {
+      const int j = neigh[k] & NEIGH_MASK;
+      const double dx = x[3 * j] - xi, dy = x[3 * j + 1] - yi, dz = x[3 * j + 2] - zi;
+      node = node_of[j];
+      keep = node >= 0 && dx * dx + dy * dy + dz * dz < cutsq;
+      dxf = (float)dx; dyf = (float)dy; dzf = (float)dz;
+    }
+    const unsigned long long ballot = __ballot(keep);
+    const unsigned mask = (unsigned)(ballot >> shift) & 0xFFFFu;
+    if (keep) {
+      const int pos = base + __popc(mask & ((1u << lane) - 1u));
+      src[pos] = node;
+      edge_vec[3 * pos] = dxf; edge_vec[3 * pos + 1] = dyf; edge_vec[3 * pos + 2] = dzf;
+    }
+    base += __popc(mask);
+  }
+}
+
+__global__ void md_iota_kernel(int32_t *v, int64_t n) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) v[k] = (int32_t)k;
+}
+
+// col_ptr[s] = first position in the sorted source keys that is >= s
+__global__ void md_lower_bound_kernel(const int32_t *__restrict__ keys, int64_t n_keys, int64_t n_nodes,
+                                      int32_t *__restrict__ col_ptr) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > n_nodes) return;
+  int64_t lo = 0, hi = n_keys;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < (int32_t)s) lo = mid + 1; else hi = mid;
+  }
+  col_ptr[s] = (int32_t)lo;
+}
+
+}  // namespace
+
+struct snet_md_host {
+  snet_model *model = nullptr;
+  DevBuf<double> x;
+  DevBuf<int32_t> node_of, ilist, nb_ptr, neigh, types, cnt, row_ptr, src, keys, iota, eperm, col_ptr;
+  DevBuf<float> edge_vec, forces, e_atom, vatom;
+  DevBuf<double> scalars;  // energy, virial[6]
+  DevBuf<char> cub_tmp;
+  PinBuf<int32_t> h_neigh, h_small;  // flattened neighbor rows; nb_ptr | node_of | types | ilist
+  PinBuf<float> h_out;
+  PinBuf<double> h_scalars;
+  std::vector<int32_t> node_to_atom, types_host;
+  std::vector<int32_t> dense_tag;
+  std::unordered_map<int64_t, int32_t> sparse_tag;
+};
+
+extern "C" int snet_md_create(snet_model *model, snet_md_host **out) {
+  SNET_REQUIRE(model != nullptr && out != nullptr, "snet_md_create: null argument");
+  auto *h = new snet_md_host;
+  h->model = model;
+  *out = h;
+  return 0;
+}
+
+extern "C" void snet_md_destroy(snet_md_host *h) {
+  if (!h) return;
+  h->x.release(); h->node_of.release(); h->ilist.release(); h->nb_ptr.release(); h->neigh.release();
+  h->types.release(); h->cnt.release(); h->row_ptr.release(); h->src.release(); h->keys.release();
+  h->iota.release(); h->eperm.release(); h->col_ptr.release(); h->edge_vec.release(); h->forces.release();
+  h->e_atom.release(); h->vatom.release(); h->scalars.release(); h->cub_tmp.release();
+  h->h_neigh.release(); h->h_small.release(); h->h_out.release(); h->h_scalars.release();
+  delete h;
+}
+
+extern "C" int snet_md_compute(snet_md_host *h, int32_t inum, const int32_t *ilist, const int32_t *numneigh,
+                               const int32_t *const *firstneigh, int32_t nall, const double *x, const int32_t *type,
+                               const void *tag, int32_t tag_bytes, const int32_t *type_map, int32_t ntypes,
+                               int32_t ghost_mode, int32_t eflag_atom, int32_t vflag, int32_t vflag_atom, double *f,
+                               double *eng, double *virial, double *eatom, double *vatom, int32_t *node_to_atom_out,
+                               int64_t *n_nodes_out, int64_t *n_edges_out, void *stream) {
+  SNET_REQUIRE(h != nullptr && h->model != nullptr, "snet_md_compute: null host");
+  SNET_REQUIRE(inum > 0 && nall >= inum, "snet_md_compute: need 0 < inum <= nall (an empty sub-domain is not supported)");
+  SNET_REQUIRE(ilist && numneigh && firstneigh && x && type && tag && type_map && f, "snet_md_compute: null array");
+  SNET_REQUIRE(tag_bytes == 4 || tag_bytes == 8, "snet_md_compute: tag_bytes must be 4 or 8");
+  SNET_REQUIRE(ghost_mode == 0 || ghost_mode == 1, "snet_md_compute: ghost_mode must be 0 (alias by tag) or 1 (ghost nodes)");
+  SNET_REQUIRE(!(ghost_mode == 1 && vflag_atom), "snet_md_compute: atomic stress is not supported with ghost nodes");
+  SNET_REQUIRE(!eflag_atom || eatom, "snet_md_compute: eflag_atom needs eatom");
+  SNET_REQUIRE(!vflag || virial, "snet_md_compute: vflag needs virial");
+  SNET_REQUIRE(!vflag_atom || vatom, "snet_md_compute: vflag_atom needs vatom");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  auto tag_of = [&](int a) -> int64_t {
+    return tag_bytes == 4 ? (int64_t) static_cast<const int32_t *>(tag)[a] : static_cast<const int64_t *>(tag)[a];
+  };
+  float cutoff = 0.f;
+  int32_t n_species = 0;
+  snet_model_info(h->model, &cutoff, &n_species, nullptr, nullptr, 0);
+
+  // ---- host: tag -> graph node, node -> LAMMPS atom, species per node, flattened neighbor rows
+  int64_t max_tag = 0;
+  for (int a = 0; a < nall; ++a) max_tag = tag_of(a) > max_tag ? tag_of(a) : max_tag;
+  const bool dense = max_tag <= 8LL * nall + 1024;
+  if (dense) h->dense_tag.assign((size_t)max_tag + 1, -1);
+  else h->sparse_tag.clear();
+  auto lookup = [&](int64_t t) -> int32_t {
+    if (dense) return h->dense_tag[(size_t)t];
+    auto it = h->sparse_tag.find(t);
+    return it == h->sparse_tag.end() ? -1 : it->second;
+  };
+  auto assign = [&](int64_t t, int32_t v) {
+    if (dense) h->dense_tag[(size_t)t] = v;
+    else h->sparse_tag[t] = v;
+  };
+  h->node_to_atom.clear();
+  h->types_host.clear();
+  int64_t n_slots = 0;
+  for (int ii = 0; ii < inum; ++ii) {
+    const int i = ilist[ii];
+    SNET_REQUIRE(i >= 0 && i < nall, "snet_md_compute: ilist entry out of range");
+    SNET_REQUIRE(type[i] >= 1 && type[i] <= ntypes, "snet_md_compute: atom type out of range");
+    const int sp = type_map[type[i]];
+    SNET_REQUIRE(sp >= 0 && sp < n_species, "snet_md_compute: type_map entry is not a species of the model");
+    assign(tag_of(i), ii);
+    h->node_to_atom.push_back(i);
+    h->types_host.push_back(sp);
+    n_slots += numneigh[i];
+  }
+  SNET_REQUIRE(n_slots < (1LL << 31), "snet_md_compute: neighbor list too large");
+  if (ghost_mode == 1)  // every ghost identity (tag) not owned here is a graph node of its own
+    for (int j = 0; j < nall; ++j)
+      if (lookup(tag_of(j)) < 0) {
+        SNET_REQUIRE(type[j] >= 1 && type[j] <= ntypes, "snet_md_compute: atom type out of range");
+        const int sp = type_map[type[j]];
+        SNET_REQUIRE(sp >= 0 && sp < n_species, "snet_md_compute: type_map entry is not a species of the model");
+        assign(tag_of(j), (int32_t)h->node_to_atom.size());
+        h->node_to_atom.push_back(j);
+        h->types_host.push_back(sp);
+      }
+  const int64_t NT = (int64_t)h->node_to_atom.size(), N = inum;
+  if (node_to_atom_out) memcpy(node_to_atom_out, h->node_to_atom.data(), (size_t)NT * 4);  // the halo hooks need it
+  if (n_nodes_out) *n_nodes_out = NT;
+  const size_t small = (size_t)(inum + 1) + nall + NT + inum;
+  SNET_REQUIRE(h->h_small.ensure(small) && h->h_neigh.ensure((size_t)n_slots + 1), "snet_md_compute: pinned allocation failed");
+  int32_t *hp_nb = h->h_small.p, *hp_node = hp_nb + inum + 1, *hp_types = hp_node + nall, *hp_ilist = hp_types + NT;
+  hp_nb[0] = 0;
+  for (int ii = 0; ii < inum; ++ii) {
+    const int i = ilist[ii];
+    memcpy(h->h_neigh.p + hp_nb[ii], firstneigh[i], (size_t)numneigh[i] * 4);
+    hp_nb[ii + 1] = hp_nb[ii] + numneigh[i];
+    hp_ilist[ii] = i;
+  }
+  for (int j = 0; j < nall; ++j) hp_node[j] = lookup(tag_of(j));
+  memcpy(hp_types, h->types_host.data(), (size_t)NT * 4);
+
+  // ---- device: upload, filter, CSR by center, grouping by source
+  SNET_REQUIRE(h->x.ensure((size_t)nall * 3) && h->node_of.ensure(nall) && h->ilist.ensure(inum) &&
+                   h->nb_ptr.ensure(inum + 1) && h->neigh.ensure((size_t)n_slots + 1) && h->types.ensure(NT) &&
+                   h->cnt.ensure(NT + 1) && h->row_ptr.ensure(NT + 1) && h->col_ptr.ensure(NT + 1) &&
+                   h->forces.ensure((size_t)NT * 3) && h->e_atom.ensure(N) && h->scalars.ensure(8) &&
+                   h->h_scalars.ensure(8) && (!vflag_atom || h->vatom.ensure((size_t)NT * 6)),
+               "snet_md_compute: device allocation failed");
+  bool ok = true;
+  ok &= hipMemcpyAsync(h->x.p, x, (size_t)nall * 24, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(h->nb_ptr.p, hp_nb, (size_t)(inum + 1) * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(h->node_of.p, hp_node, (size_t)nall * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(h->types.p, hp_types, (size_t)NT * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemcpyAsync(h->ilist.p, hp_ilist, (size_t)inum * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+  if (n_slots)
+    ok &= hipMemcpyAsync(h->neigh.p, h->h_neigh.p, (size_t)n_slots * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok &= hipMemsetAsync(h->cnt.p, 0, (size_t)(NT + 1) * 4, st) == hipSuccess;
+  SNET_REQUIRE(ok, "snet_md_compute: upload failed");
+  const double cutsq = (double)cutoff * (double)cutoff;
+  const int tb = 256, per_block = tb / GROUP;
+  const int nblk = (inum + per_block - 1) / per_block;
+  md_count_kernel<<<nblk, tb, 0, st>>>(h->x.p, h->node_of.p, h->ilist.p, h->nb_ptr.p, h->neigh.p, inum, cutsq, h->cnt.p);
+  SNET_CHECK_LAUNCH("md_count_kernel");
+  size_t scan_bytes = 0;
+  SNET_REQUIRE(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, h->cnt.p, h->row_ptr.p, (int)(NT + 1), st) == hipSuccess,
+               "snet_md_compute: scan sizing failed");
+  SNET_REQUIRE(h->cub_tmp.ensure(scan_bytes), "snet_md_compute: device allocation failed");
+  size_t tmp_bytes = h->cub_tmp.cap;
+  SNET_REQUIRE(hipcub::DeviceScan::ExclusiveSum(h->cub_tmp.p, tmp_bytes, h->cnt.p, h->row_ptr.p, (int)(NT + 1), st) == hipSuccess,
+               "snet_md_compute: scan failed");
+  int32_t E32 = 0;
+  SNET_REQUIRE(hipMemcpyAsync(&E32, h->row_ptr.p + NT, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                   hipStreamSynchronize(st) == hipSuccess,
+               "snet_md_compute: edge count readback failed");
+  const int64_t E = E32;
+  SNET_REQUIRE(h->src.ensure(E + 1) && h->edge_vec.ensure((size_t)E * 3 + 3) && h->keys.ensure(E + 1) &&
+                   h->iota.ensure(E + 1) && h->eperm.ensure(E + 1),
+               "snet_md_compute: device allocation failed");
+  if (E > 0) {
+    md_fill_kernel<<<nblk, tb, 0, st>>>(h->x.p, h->node_of.p, h->ilist.p, h->nb_ptr.p, h->neigh.p, h->row_ptr.p, inum,
+                                        cutsq, h->src.p, h->edge_vec.p);
+    SNET_CHECK_LAUNCH("md_fill_kernel");
+    md_iota_kernel<<<(unsigned)((E + 255) / 256), 256, 0, st>>>(h->iota.p, E);
+    SNET_CHECK_LAUNCH("md_iota_kernel");
+    int end_bit = 1;
+    while ((1LL << end_bit) < NT) ++end_bit;
+    size_t sort_bytes = 0;
+    SNET_REQUIRE(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, h->src.p, h->keys.p, h->iota.p, h->eperm.p, (int)E,
+                                                    0, end_bit, st) == hipSuccess,
+                 "snet_md_compute: sort sizing failed");
+    SNET_REQUIRE(h->cub_tmp.ensure(sort_bytes), "snet_md_compute: device allocation failed");
+    tmp_bytes = h->cub_tmp.cap;
+    SNET_REQUIRE(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp.p, tmp_bytes, h->src.p, h->keys.p, h->iota.p, h->eperm.p,
+                                                    (int)E, 0, end_bit, st) == hipSuccess,
+                 "snet_md_compute: sort failed");
+  }
+  md_lower_bound_kernel<<<(unsigned)((NT + 1 + 255) / 256), 256, 0, st>>>(h->keys.p, E, NT, h->col_ptr.p);
+  SNET_CHECK_LAUNCH("md_lower_bound_kernel");
+
+  // ---- the model
+  double *d_energy = h->scalars.p, *d_virial = h->scalars.p + 1;
+  int rc = snet_model_eval(h->model, NT, N, E, h->types.p, h->types_host.data(), h->row_ptr.p, h->src.p, h->col_ptr.p,
+                           h->eperm.p, h->edge_vec.p, d_energy, eflag_atom ? h->e_atom.p : nullptr, nullptr, h->forces.p,
+                           d_virial, vflag_atom ? h->vatom.p : nullptr, stream);
+  if (rc) return rc;
+
+  // ---- back to the host's arrays (pair_e3gnn.cpp:210-275)
+  const size_t n_out = (size_t)NT * 3 + (eflag_atom ? N : 0) + (vflag_atom ? (size_t)NT * 6 : 0);
+  SNET_REQUIRE(h->h_out.ensure(n_out), "snet_md_compute: pinned allocation failed");
+  float *hf = h->h_out.p, *he = hf + (size_t)NT * 3, *hv = he + (eflag_atom ? N : 0);
+  ok = hipMemcpyAsync(hf, h->forces.p, (size_t)NT * 12, hipMemcpyDeviceToHost, st) == hipSuccess;
+  if (eflag_atom) ok &= hipMemcpyAsync(he, h->e_atom.p, (size_t)N * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+  if (vflag_atom) ok &= hipMemcpyAsync(hv, h->vatom.p, (size_t)NT * 24, hipMemcpyDeviceToHost, st) == hipSuccess;
+  ok &= hipMemcpyAsync(h->h_scalars.p, h->scalars.p, 7 * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
+  SNET_REQUIRE(ok && hipStreamSynchronize(st) == hipSuccess, "snet_md_compute: result readback failed");
+  for (int64_t g = 0; g < NT; ++g) {
+    const int a = h->node_to_atom[g];
+    f[3 * a] += hf[3 * g]; f[3 * a + 1] += hf[3 * g + 1]; f[3 * a + 2] += hf[3 * g + 2];
+  }
+  if (eng) *eng += h->h_scalars.p[0];
+  if (vflag) {  // model order xx yy zz xy yz zx -> LAMMPS xx yy zz xy xz yz (pair_e3gnn.cpp:249-255)
+    const double *v = h->h_scalars.p + 1;
+    virial[0] += v[0]; virial[1] += v[1]; virial[2] += v[2]; virial[3] += v[3]; virial[4] += v[5]; virial[5] += v[4];
+  }
+  if (eflag_atom)
+    for (int64_t g = 0; g < N; ++g) eatom[h->node_to_atom[g]] += he[g];
+  if (vflag_atom)
+    for (int64_t g = 0; g < N; ++g) {
+      double *va = vatom + 6 * (size_t)h->node_to_atom[g];
+      const float *vg = hv + 6 * g;
+      va[0] += vg[0]; va[1] += vg[1]; va[2] += vg[2]; va[3] += vg[3]; va[4] += vg[5]; va[5] += vg[4];
+    }
+  if (n_edges_out) *n_edges_out = E;
+  return 0;
+}

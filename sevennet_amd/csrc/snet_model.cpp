@@ -169,6 +169,7 @@ struct snet_model {
   Arena arena;
   snet_halo_fn halo_fwd = nullptr, halo_rev = nullptr;
   void *halo_user = nullptr;
+  bool fold_forces = true;
   std::vector<std::vector<int32_t>> species_rows_host;  // scratch
   int32_t *species_rows = nullptr;                       // device, concatenated
   size_t species_rows_cap = 0;
@@ -317,11 +318,14 @@ extern "C" int snet_model_info(const snet_model *m, float *cutoff, int32_t *n_sp
   return 0;
 }
 
-extern "C" int snet_model_set_halo(snet_model *m, snet_halo_fn forward, snet_halo_fn reverse, void *user) {
+extern "C" int snet_model_set_halo(snet_model *m, snet_halo_fn forward, snet_halo_fn reverse, void *user,
+                                   int32_t fold_forces) {
   SNET_REQUIRE(m != nullptr, "snet_model_set_halo: null model");
+  SNET_REQUIRE((forward == nullptr) == (reverse == nullptr), "snet_model_set_halo: set both hooks or neither");
   m->halo_fwd = forward;
   m->halo_rev = reverse;
   m->halo_user = user;
+  m->fold_forces = fold_forces != 0;
   return 0;
 }
 
@@ -493,7 +497,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   A.off = mark2;
   float *F = forces ? forces : A.f((size_t)NT * 3);
   if ((rc = snet_edge_force(g_vec, edge_vec, row_ptr, col_ptr, eperm, NT, E, F, virial_atom, virial, st))) return rc;
-  if (NT > N) {
+  if (NT > N && m->fold_forces) {
     if ((rc = m->halo_rev(m->halo_user, F, NT, N, 3, stream))) return rc;
     if (virial_atom && (rc = m->halo_rev(m->halo_user, virial_atom, NT, N, 6, stream))) return rc;
   }

@@ -61,12 +61,12 @@ class NativeModel:
         except Exception:
             pass
 
-    def set_halo(self, halo) -> None:
+    def set_halo(self, halo, fold_forces: bool = True) -> None:
         """halo: object with forward(x, n_local) / reverse(gx, n_local) on device tensors
         (sevennet_amd.parallel.HaloExchange), or None."""
         if halo is None:
             self._cb = None
-            _lib.check(self.lib.snet_model_set_halo(self.handle, None, None, None), 'snet_model_set_halo')
+            _lib.check(self.lib.snet_model_set_halo(self.handle, None, None, None, 1), 'snet_model_set_halo')
             return
 
         def wrap(fn):
@@ -82,7 +82,8 @@ class NativeModel:
 
         self._cb = (wrap(halo.forward), wrap(halo.reverse))
         _lib.check(self.lib.snet_model_set_halo(self.handle, C.cast(self._cb[0], C.c_void_p),
-                                                C.cast(self._cb[1], C.c_void_p), None), 'snet_model_set_halo')
+                                                C.cast(self._cb[1], C.c_void_p), None, int(fold_forces)),
+                   'snet_model_set_halo')
 
     def compute(self, g: Graph, want_atomic_virial: bool = False):
         """Same results dict as HipForceEngine.compute."""
@@ -93,7 +94,10 @@ class NativeModel:
             virial = torch.empty(6, dtype=torch.float64, device=self.dev)
             e_atom, g_vec, forces = torch.empty(N, **f32), torch.empty(E, 3, **f32), torch.empty(NT, 3, **f32)
             vir_atom = torch.empty(NT, 6, **f32) if want_atomic_virial else None
-            types_host = np.ascontiguousarray(g.types[:N].cpu().numpy(), dtype=np.int32)
+            types_host = getattr(g, '_types_host', None)  # host copy made once per graph (a D2H copy syncs)
+            if types_host is None:
+                types_host = np.ascontiguousarray(g.types[:N].cpu().numpy(), dtype=np.int32)
+                g._types_host = types_host
             p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
             self._cb_error = None
             rc = self.lib.snet_model_eval(self.handle, NT, N, E, p(g.types), C.c_void_p(types_host.ctypes.data),
