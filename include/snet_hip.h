@@ -244,6 +244,10 @@ void snet_model_destroy(snet_model *model);
  * archive's extra files ("cutoff", "comm_size", ...).  Any output pointer may be NULL. */
 int snet_model_info(const snet_model *model, float *cutoff, int32_t *n_species, int32_t *n_layers,
                     int32_t *comm_dims, int32_t max_layers);
+/* value of one metadata key of the model file into value[capacity] (NUL-terminated); keys as in the
+ * reference's deployed model (pair_e3gnn.cpp:321-330): chemical_symbols_to_index, cutoff, num_species,
+ * model_type, version, dtype.  rc 3: no such key. */
+int snet_model_meta(const snet_model *model, const char *key, char *value, int32_t capacity);
 /* Ghost exchange hooks (pair_e3gnn_parallel.cpp:369,435; comm_brick.cpp:1057-1123):
  *   forward(user, x[n_total,dim], ...)  fill rows n_local.. with their owners' rows
  *   reverse(user, gx[n_total,dim], ...) add rows n_local.. into their owners' rows

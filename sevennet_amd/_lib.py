@@ -94,6 +94,7 @@ SIGNATURES = {
     'snet_model_destroy': (None, [C.c_void_p]),
     'snet_model_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32), C.c_int32]),
+    'snet_model_meta': (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32]),
     'snet_model_set_halo': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     'snet_model_eval': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p,
                                   c_i32p, c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, c_stream]),

@@ -166,6 +166,7 @@ struct snet_model {
   float scale0 = 1.f;
   std::vector<Layer> layers;
   Linear ro1, ro2;
+  std::string meta;  // key=value lines
   Arena arena;
   snet_halo_fn halo_fwd = nullptr, halo_rev = nullptr;
   void *halo_user = nullptr;
@@ -259,7 +260,12 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
     }
     m->layers.push_back(L);
   }
-  good = good && read_linear(r, m->ro1) && read_linear(r, m->ro2) && r.p == r.end;
+  good = good && read_linear(r, m->ro1) && read_linear(r, m->ro2);
+  if (good) {
+    const int nm = r.i32();
+    good = r.ok && nm >= 0 && nm <= (1 << 20) && (int64_t)(r.end - r.p) == nm;
+    if (good) m->meta.assign(reinterpret_cast<const char *>(r.p), (size_t)nm);
+  }
   if (!good) {
     const std::string prev = snet_last_error();
     snet::set_error("snet_model_load: malformed model file or device upload failed" +
@@ -316,6 +322,25 @@ extern "C" int snet_model_info(const snet_model *m, float *cutoff, int32_t *n_sp
   if (comm_dims)
     for (int t = 0; t < m->n_layers && t < max_layers; ++t) comm_dims[t] = m->layers[t].dx;
   return 0;
+}
+
+extern "C" int snet_model_meta(const snet_model *m, const char *key, char *value, int32_t capacity) {
+  SNET_REQUIRE(m != nullptr && key != nullptr && value != nullptr && capacity > 0, "snet_model_meta: bad argument");
+  const std::string k = std::string(key) + "=";
+  size_t pos = 0;
+  while (pos < m->meta.size()) {
+    size_t eol = m->meta.find('\n', pos);
+    if (eol == std::string::npos) eol = m->meta.size();
+    if (m->meta.compare(pos, k.size(), k) == 0) {
+      const std::string v = m->meta.substr(pos + k.size(), eol - pos - k.size());
+      SNET_REQUIRE((int64_t)v.size() < capacity, "snet_model_meta: value does not fit the buffer");
+      memcpy(value, v.c_str(), v.size() + 1);
+      return 0;
+    }
+    pos = eol + 1;
+  }
+  snet::set_error(std::string("snet_model_meta: no such key: ") + key);
+  return 3;
 }
 
 extern "C" int snet_model_set_halo(snet_model *m, snet_halo_fn forward, snet_halo_fn reverse, void *user,

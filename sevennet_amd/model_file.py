@@ -16,6 +16,9 @@ Layout (all ints int32, floats float32 unless noted):
                linear sc (all-zero header if absent), si1, si2   (see _write_linear)
                n_gate_segs, segs[kind in_off out_off mul l gate_off act | cst f32]
     readout linears ro1, ro2
+    metadata : n_bytes, then `key=value` lines (utf-8) -- the `_extra_files` of the reference's deployed
+               model (deploy.py:56-72): chemical_symbols_to_index, cutoff, num_species, model_type,
+               version, dtype
 """
 from __future__ import annotations
 
@@ -27,6 +30,22 @@ import numpy as np
 from .model_spec import ACT_CST, ACT_ID, LinearSpec, build_model_spec, linear_weight_matrices
 
 MAGIC = b'SNETMDL1'
+
+_SYMBOLS = ('X H He Li Be B C N O F Ne Na Mg Al Si P S Cl Ar K Ca Sc Ti V Cr Mn Fe Co Ni Cu Zn Ga Ge As Se Br Kr Rb Sr '
+            'Y Zr Nb Mo Tc Ru Rh Pd Ag Cd In Sn Sb Te I Xe Cs Ba La Ce Pr Nd Pm Sm Eu Gd Tb Dy Ho Er Tm Yb Lu Hf Ta W '
+            'Re Os Ir Pt Au Hg Tl Pb Bi Po At Rn Fr Ra Ac Th Pa U Np Pu Am Cm Bk Cf Es Fm Md No Lr Rf Db Sg Bh Hs Mt '
+            'Ds Rg Cn Nh Fl Mc Lv Ts Og').split()
+
+
+def species_symbols(config: dict, n_species: int):
+    """element symbol of every species index (deploy.py:57-61: symbols in `_type_map` key order)"""
+    tm = config.get('_type_map')
+    if tm:
+        by_index = sorted(((int(v), int(z)) for z, v in tm.items()))
+        return [_SYMBOLS[z] for _, z in by_index]
+    if config.get('chemical_species'):
+        return list(config['chemical_species'])[:n_species]
+    return [f'X{i}' for i in range(n_species)]
 
 
 def _i(*v):
@@ -99,5 +118,12 @@ def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray])
             out.append(_f(ACT_CST[inv_act[s.act]]))
     out.append(_write_linear(sp.readout1, sd[sp.readout1.name]))
     out.append(_write_linear(sp.readout2, sd[sp.readout2.name]))
+    meta = {'chemical_symbols_to_index': ' '.join(species_symbols(config, sp.num_species)),
+            'cutoff': repr(float(sp.cutoff)), 'num_species': str(sp.num_species),
+            'model_type': str(config.get('model_type', 'E3_equivariant_model')),
+            'version': str(config.get('version', '')), 'dtype': 'single'}
+    text = ''.join(f'{k}={v}\n' for k, v in meta.items()).encode()
+    out.append(_i(len(text)))
+    out.append(text)
     with open(path, 'wb') as f:
         f.write(b''.join(out))

@@ -53,6 +53,11 @@ class NativeModel:
         self.comm_dims = [int(comm[i]) for i in range(self.n_layers)]
         self._cb = None
 
+    def meta(self, key: str) -> str:
+        buf = C.create_string_buffer(4096)
+        _lib.check(self.lib.snet_model_meta(self.handle, key.encode(), buf, 4096), 'snet_model_meta')
+        return buf.value.decode()
+
     def __del__(self):
         try:
             if getattr(self, 'handle', None):

@@ -58,3 +58,22 @@ def test_loader_rejects_non_model_files_without_gpu(tmp_path):
     assert lib.snet_model_load(str(tmp_path / 'nope').encode(), C.byref(h)) != 0
     assert b'cannot open' in lib.snet_last_error()
     assert not h.value
+
+
+def test_deploy_cli_from_checkpoint(tmp_path):
+    """reference-format checkpoint (config + model_state_dict) -> .snet with the deploy metadata"""
+    import torch
+    import json
+    from helpers import GOLDEN
+    from sevennet_amd.deploy import main
+    d = np.load(f'{GOLDEN}/cp0_state.npz')
+    cfg = json.loads(str(d['__config__']))
+    sd = {k: d[k] for k in d.files if not k.startswith('__')}
+    ck = tmp_path / 'cp.pth'
+    torch.save({'config': cfg, 'model_state_dict': {k: torch.as_tensor(v) for k, v in sd.items()}}, ck)
+    out = tmp_path / 'm.snet'
+    assert main([str(ck), '-o', str(out)]) == 0
+    blob = out.read_bytes()
+    assert blob[:8] == b'SNETMDL1'
+    tail = blob[-400:].decode('latin1')
+    assert 'chemical_symbols_to_index=Hf O\n' in tail and 'model_type=E3_equivariant_model' in tail

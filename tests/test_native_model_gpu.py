@@ -43,6 +43,10 @@ def test_native_model_vs_reference_torchscript_outputs(name):
     assert np.abs(b['dE_dr'].cpu().numpy() - d['par_dE_dr']).max() < F_TOL
     assert nat.cutoff == pytest.approx(float(cfg['cutoff'])) and nat.n_layers == len(eng.layers)
     assert nat.comm_dims == [L.spec.si1.dim_out for L in eng.layers]
+    assert nat.meta('chemical_symbols_to_index') == 'Hf O' and float(nat.meta('cutoff')) == 4.0
+    assert nat.meta('model_type') == 'E3_equivariant_model'
+    with pytest.raises(RuntimeError, match='no such key'):
+        nat.meta('nope')
 
 
 CASES = {
