@@ -80,13 +80,20 @@ int snet_gemm(const float *A, const float *B, float *C, int64_t n_nodes, int32_t
  * list; blocks writing the same output block must not be grouped unless the later ones accumulate
  * into distinct rows -- the host keeps accumulating blocks in separate launches).             */
 typedef struct snet_gemm_desc {
-  const float *B;     /* device [K,N] row-major */
+  const float *B;      /* device [K,N] row-major (exact fp32 MFMA), or NULL when B_split is given */
+  const void *B_split; /* device copy of a snet_gemm_split_pack buffer: bf16 x 6 split-precision MFMA
+                          (fp32-rounding-class error, ~2.5x the fp32 matrix-pipe rate); or NULL */
   int64_t a_off, c_off;
   int32_t d, K, N, accumulate;
 } snet_gemm_desc;
 #define SNET_MAX_GEMM_GROUP 8
 int snet_gemm_grouped(const snet_gemm_desc *descs_host, int32_t n_desc, const float *A, float *C, int64_t n_nodes,
                       int64_t a_node_stride, int64_t c_node_stride, const int32_t *row_idx, void *stream);
+/* weights [K,N] (HOST, fp32, normalisation folded) -> matrix-core B fragments, each value written as
+ * a sum of three bf16 terms (HOST buffer of snet_gemm_split_size bytes; upload it and pass the device
+ * copy as snet_gemm_desc.B_split).  All problems of one grouped launch must use the same kind. */
+int64_t snet_gemm_split_size(int32_t K, int32_t N);
+int snet_gemm_split_pack(const float *B_host, int32_t K, int32_t N, void *packed_host);
 
 /* Fused radial MLP, e3nn FullyConnectedNet([nb,h1,h2,wn], act) (convolution.py:93-95,121):
  *   fwd  w[E,wn] = (act(act(emb W0) cst W1) cst) W2          W0[nb,h1] W1[h1,h2] W2[h2,wn]

@@ -25,7 +25,7 @@ class EdgeParams(C.Structure):
 
 
 class GemmDesc(C.Structure):
-    _fields_ = [('B', C.c_void_p), ('a_off', C.c_int64), ('c_off', C.c_int64), ('d', C.c_int32), ('K', C.c_int32),
+    _fields_ = [('B', C.c_void_p), ('B_split', C.c_void_p), ('a_off', C.c_int64), ('c_off', C.c_int64), ('d', C.c_int32), ('K', C.c_int32),
                 ('N', C.c_int32), ('accumulate', C.c_int32)]
 
 
@@ -56,6 +56,8 @@ SIGNATURES = {
                             C.c_int64, C.c_int64, C.c_int64, c_i32p, C.c_int32, c_stream]),
     'snet_gemm_grouped': (C.c_int, [C.POINTER(GemmDesc), C.c_int32, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int64,
                                     c_i32p, c_stream]),
+    'snet_gemm_split_size': (C.c_int64, [C.c_int32, C.c_int32]),
+    'snet_gemm_split_pack': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'snet_act_fwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_stream]),
     'snet_act_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_stream]),
     'snet_conv_plan_create': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),

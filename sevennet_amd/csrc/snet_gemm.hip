@@ -8,11 +8,15 @@
 // chosen by N), K staged through LDS in slabs of BK=32.  A is stored k-major in LDS
 // (As[k][row], row stride 129 -> conflict-free ds_write_b32 and ds_read_b32), so the
 // MFMA A fragment (lane l: row l&31, k = 2*kk + (l>>5)) is one ds_read_b32 per step.
+// Weights packed by snet_gemm_split_pack take the split-precision kernel further down instead.
+#include <cstring>
+
 #include "snet_common.h"
+#include "snet_split.h"
 
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+using snet::f32x16;
 
 constexpr int BM = 128;
 constexpr int BK = 32;
@@ -123,6 +127,136 @@ __device__ __forceinline__ void gemm_body(float *As, float *Bs, int bx, int by,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-precision variant (bf16 x 6 on v_mfma_f32_32x32x16_bf16, snet_split.h): same contraction,
+// weights pre-packed on the host by snet_gemm_split_pack into B fragments
+//     packed[((tile*nq + q)*3 + term)*64 + lane] = 8 bf16 : B[k = 16q + 8(lane>>5) + i][32 tile + (lane&31)]
+// A wave owns MT*32 rows and all NT column tiles of its block: the A fragment (8 consecutive k of
+// one row = 32 B per lane) comes straight from global memory into registers and is split there --
+// A is not shared between waves, so it never visits LDS.  B fragments are shared by the 4 waves:
+// one NT*3-KB slab per 16-wide k step, double buffered in LDS (each ds_read_b128 feeds MT MFMAs).
+template <int NT, int MT>
+__device__ __forceinline__ void gemm_split_body(snet::u32x4 *Bs, int bx, int by, const float *__restrict__ A,
+    const snet::u32x4 *__restrict__ Bp, float *__restrict__ C, int64_t n_rows, int d, int K, int N,
+    int64_t a_node_stride, int64_t a_off, int64_t c_node_stride, int64_t c_off, const int32_t *__restrict__ row_idx,
+    int accumulate) {
+  using namespace snet;
+  constexpr int SLAB = NT * 192;  // u32x4 per k step
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, li = lane & 31;
+  const int64_t row0 = ((int64_t)bx * 4 + wave) * (32 * MT);
+  const int nq = (K + 15) >> 4, n_tiles = (N + 31) >> 5, tile0 = by * NT;
+
+  const float *a_ptr[MT];
+  bool a_ok[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int64_t r = row0 + 32 * mt + li;
+    a_ok[mt] = r < n_rows;
+    const int64_t rr = a_ok[mt] ? r : 0;
+    const int64_t n = rr / d;
+    const int m = (int)(rr - n * d);
+    const int64_t node = row_idx ? (int64_t)row_idx[n] : n;
+    a_ptr[mt] = A + node * a_node_stride + a_off + (int64_t)m * K + 8 * half;
+  }
+  const bool a_vec = ((K & 3) == 0) && ((a_off & 3) == 0) && ((a_node_stride & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  auto load_a = [&](int q, float (&v)[MT][8]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int k = 16 * q + 8 * half;
+      if (a_ok[mt] && a_vec && k + 7 < K) {
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(a_ptr[mt] + 16 * q);
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(a_ptr[mt] + 16 * q + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[mt][i] = lo[i]; v[mt][4 + i] = hi[i]; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[mt][i] = (a_ok[mt] && k + i < K) ? a_ptr[mt][16 * q + i] : 0.f;
+      }
+    }
+  };
+  constexpr int NST = (SLAB + 255) / 256;
+  auto load_b = [&](int q, u32x4 (&st)[NST]) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = tid + 256 * i;
+      const int t = idx / 192, rem = idx - 192 * t;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      if (idx < SLAB && tile0 + t < n_tiles) z = Bp[((int64_t)(tile0 + t) * nq + q) * 192 + rem];
+      st[i] = z;
+    }
+  };
+  auto store_b = [&](int buf, const u32x4 (&st)[NST]) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < SLAB) Bs[buf * SLAB + idx] = st[i];
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[mt][t] = zero16();
+
+  float av[MT][8], an[MT][8];
+  u32x4 st[NST];
+  load_a(0, av);
+  load_b(0, st);
+  store_b(0, st);
+  __syncthreads();
+  int buf = 0;
+  for (int q = 0; q < nq; ++q) {
+    const bool more = q + 1 < nq;
+    if (more) {
+      load_a(q + 1, an);
+      load_b(q + 1, st);
+    }
+    Split3 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = split8(av[mt]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int term = 0; term < 3; ++term) b[term] = as_bf16x8(Bs[buf * SLAB + (t * 3 + term) * 64 + lane]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][t] = mfma6(a[mt], b, acc[mt][t]);
+    }
+    if (more) {
+      store_b(buf ^ 1, st);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) av[mt][i] = an[mt][i];
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int64_t r = row0 + 32 * mt + (j & 3) + 8 * (j >> 2) + 4 * half;
+      if (r >= n_rows) continue;
+      const int64_t n = r / d;
+      const int m = (int)(r - n * d);
+      const int64_t node = row_idx ? (int64_t)row_idx[n] : n;
+      float *crow = C + node * c_node_stride + c_off + (int64_t)m * N;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 32 * (tile0 + t) + li;
+        if (col < N) {
+          const float v = acc[mt][t][j];
+          crow[col] = accumulate ? crow[col] + v : v;
+        }
+      }
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void gemm_kernel(
     const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int64_t n_rows, int d, int K,
@@ -167,7 +301,71 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupArgs G, const fl
                  row_idx, P.accumulate);
 }
 
+template <int MT>
+__global__ __launch_bounds__(256, 2) void gemm_split_grouped_kernel(GroupArgs G, const float *__restrict__ A,
+                                                                    float *__restrict__ C, int64_t n_nodes,
+                                                                    int64_t a_node_stride, int64_t c_node_stride,
+                                                                    const int32_t *__restrict__ row_idx) {
+  __shared__ snet::u32x4 Bs[2 * 4 * 192];
+  int q = 0;
+  while (q + 1 < G.n && (int)blockIdx.x >= G.first_block[q + 1]) ++q;
+  const snet_gemm_desc P = G.p[q];
+  const int b = blockIdx.x - G.first_block[q];
+  const int bx = b % G.nbx[q], by = b / G.nbx[q];
+  const int64_t n_rows = n_nodes * P.d;
+  const snet::u32x4 *Bp = static_cast<const snet::u32x4 *>(P.B_split);
+  if (P.N > 64)
+    gemm_split_body<4, MT>(Bs, bx, by, A, Bp, C, n_rows, P.d, P.K, P.N, a_node_stride, P.a_off, c_node_stride, P.c_off,
+                           row_idx, P.accumulate);
+  else if (P.N > 32)
+    gemm_split_body<2, MT>(Bs, bx, by, A, Bp, C, n_rows, P.d, P.K, P.N, a_node_stride, P.a_off, c_node_stride, P.c_off,
+                           row_idx, P.accumulate);
+  else
+    gemm_split_body<1, MT>(Bs, bx, by, A, Bp, C, n_rows, P.d, P.K, P.N, a_node_stride, P.a_off, c_node_stride, P.c_off,
+                           row_idx, P.accumulate);
+}
+
+inline uint16_t bf16_rne(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float bf16_f(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
 }  // namespace
+
+extern "C" int64_t snet_gemm_split_size(int32_t K, int32_t N) {
+  if (K < 1 || N < 1) return 0;
+  return (int64_t)((N + 31) / 32) * ((K + 15) / 16) * 3 * 64 * 16;
+}
+
+extern "C" int snet_gemm_split_pack(const float *B_host, int32_t K, int32_t N, void *packed_host) {
+  SNET_REQUIRE(B_host != nullptr && packed_host != nullptr && K >= 1 && N >= 1, "snet_gemm_split_pack: bad argument");
+  uint16_t *out = static_cast<uint16_t *>(packed_host);
+  const int nq = (K + 15) / 16, n_tiles = (N + 31) / 32;
+  for (int t = 0; t < n_tiles; ++t)
+    for (int q = 0; q < nq; ++q)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int i = 0; i < 8; ++i) {
+          const int k = 16 * q + 8 * (lane >> 5) + i, n = 32 * t + (lane & 31);
+          const float x = (k < K && n < N) ? B_host[(size_t)k * N + n] : 0.f;
+          const uint16_t h = bf16_rne(x);
+          const float r1 = x - bf16_f(h);
+          const uint16_t m = bf16_rne(r1);
+          const uint16_t l = bf16_rne(r1 - bf16_f(m));
+          const size_t base = ((size_t)(t * nq + q) * 3) * 64;
+          out[((base + 0 * 64 + lane) * 8) + i] = h;
+          out[((base + 1 * 64 + lane) * 8) + i] = m;
+          out[((base + 2 * 64 + lane) * 8) + i] = l;
+        }
+  return 0;
+}
 
 extern "C" int snet_gemm_grouped(const snet_gemm_desc *descs_host, int32_t n_desc, const float *A, float *C,
                                  int64_t n_nodes, int64_t a_node_stride, int64_t c_node_stride,
@@ -177,12 +375,24 @@ extern "C" int snet_gemm_grouped(const snet_gemm_desc *descs_host, int32_t n_des
   if (n_nodes <= 0) return 0;
   GroupArgs G;
   G.n = n_desc;
+  int n_split = 0;
+  int64_t rows_max = 0;
+  for (int i = 0; i < n_desc; ++i) {
+    n_split += descs_host[i].B_split != nullptr;
+    rows_max = rows_max > n_nodes * descs_host[i].d ? rows_max : n_nodes * descs_host[i].d;
+  }
+  SNET_REQUIRE(n_split == 0 || n_split == n_desc, "snet_gemm_grouped: mix of split-packed and fp32 weights in one group");
+  const bool split = n_split > 0;
+  // split kernel: 64 rows per wave once that still leaves >= 2 workgroups per CU, else 32
+  const int mt = (split && rows_max >= 256 * 512) ? 2 : 1;
+  const int bm = split ? 128 * mt : BM;
   int64_t total = 0;
   for (int i = 0; i < n_desc; ++i) {
     const snet_gemm_desc &p = descs_host[i];
-    SNET_REQUIRE(p.d >= 1 && p.K >= 1 && p.N >= 1 && p.B != nullptr, "snet_gemm_grouped: bad problem");
+    SNET_REQUIRE(p.d >= 1 && p.K >= 1 && p.N >= 1 && (p.B != nullptr || p.B_split != nullptr),
+                 "snet_gemm_grouped: bad problem");
     const int bn = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
-    const int64_t nbx = (n_nodes * p.d + BM - 1) / BM;
+    const int64_t nbx = (n_nodes * p.d + bm - 1) / bm;
     const int64_t nby = (p.N + bn - 1) / bn;
     SNET_REQUIRE(nbx < (1ll << 30), "snet_gemm_grouped: too many rows");
     G.p[i] = p;
@@ -192,8 +402,13 @@ extern "C" int snet_gemm_grouped(const snet_gemm_desc *descs_host, int32_t n_des
   }
   G.first_block[n_desc] = (int)total;
   SNET_REQUIRE(total < (1ll << 31), "snet_gemm_grouped: grid too large");
-  gemm_grouped_kernel<<<(unsigned)total, 256, 0, static_cast<hipStream_t>(stream)>>>(G, A, C, n_nodes, a_node_stride,
-                                                                                     c_node_stride, row_idx);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!split)
+    gemm_grouped_kernel<<<(unsigned)total, 256, 0, st>>>(G, A, C, n_nodes, a_node_stride, c_node_stride, row_idx);
+  else if (mt == 2)
+    gemm_split_grouped_kernel<2><<<(unsigned)total, 256, 0, st>>>(G, A, C, n_nodes, a_node_stride, c_node_stride, row_idx);
+  else
+    gemm_split_grouped_kernel<1><<<(unsigned)total, 256, 0, st>>>(G, A, C, n_nodes, a_node_stride, c_node_stride, row_idx);
   SNET_CHECK_LAUNCH("snet_gemm_grouped");
   return 0;
 }

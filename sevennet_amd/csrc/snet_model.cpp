@@ -42,7 +42,7 @@ struct Reader {
 
 struct Block {
   int l, in_off, mul_in, out_off, mul_out, species, accumulate;
-  float *W = nullptr, *WT = nullptr;  // device [K,N] and [N,K]
+  void *W = nullptr, *WT = nullptr;  // device split-packed fragments of [K,N] and [N,K] (snet_gemm_split_pack)
 };
 struct Linear {
   int dim_in = 0, dim_out = 0, n_species = 0;
@@ -68,7 +68,8 @@ void plan_groups(Linear &L, bool transpose) {
     bool acc = false;
     for (auto &w : written) acc |= (w.first == tgt && w.second == b.species);
     snet_gemm_desc d;
-    d.B = transpose ? b.WT : b.W;
+    d.B = nullptr;
+    d.B_split = transpose ? b.WT : b.W;
     d.a_off = transpose ? b.out_off : b.in_off;
     d.c_off = tgt;
     d.d = 2 * b.l + 1;
@@ -112,6 +113,13 @@ bool dev_upload(const std::vector<float> &h, float **d) {
   return hipMemcpy(*d, h.data(), h.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
 }
 
+bool upload_split(const std::vector<float> &w, int K, int N, void **d) {
+  std::vector<unsigned char> packed((size_t)snet_gemm_split_size(K, N));
+  if (snet_gemm_split_pack(w.data(), K, N, packed.data())) return false;
+  if (hipMalloc(d, packed.size()) != hipSuccess) return false;
+  return hipMemcpy(*d, packed.data(), packed.size(), hipMemcpyHostToDevice) == hipSuccess;
+}
+
 bool read_linear(Reader &r, Linear &L) {
   L.dim_in = r.i32();
   L.dim_out = r.i32();
@@ -137,7 +145,7 @@ bool read_linear(Reader &r, Linear &L) {
     std::vector<float> wt(w.size());
     for (int k = 0; k < b.mul_in; ++k)
       for (int n = 0; n < b.mul_out; ++n) wt[(size_t)n * b.mul_in + k] = w[(size_t)k * b.mul_out + n];
-    if (!dev_upload(w, &b.W) || !dev_upload(wt, &b.WT)) return false;
+    if (!upload_split(w, b.mul_in, b.mul_out, &b.W) || !upload_split(wt, b.mul_out, b.mul_in, &b.WT)) return false;
   }
   plan_groups(L, false);
   plan_groups(L, true);

@@ -1,0 +1,81 @@
+// Split-precision matrix-core arithmetic shared by the gfx950 GEMM-shaped kernels:
+// an fp32 operand is written as x = x1 + x2 + x3 with bf16 terms (round-to-nearest-even), and a
+// product A*B is accumulated in fp32 from the six term products of order <= 2
+//     a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2)
+// on v_mfma_f32_32x32x16_bf16: fp32-rounding-class error at 6/16 of the fp32 matrix-pipe time.
+#pragma once
+#include "snet_common.h"
+
+namespace snet {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+// native clang vectors: HIP's float4/uint4 are structs wrapping unions, and arrays of them are not
+// scalarised by SROA (they end up in scratch memory)
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+struct Split3 {
+  bf16x8 t[3];
+};
+
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+
+__device__ __forceinline__ bf16x8 cat4(bf16x2 a, bf16x2 b, bf16x2 c, bf16x2 d) {
+  const bf16x4 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3);
+  const bf16x4 cd = __builtin_shufflevector(c, d, 0, 1, 2, 3);
+  return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// x = x1 + x2 + x3 (bf16 each, round-to-nearest-even via v_cvt_pk_bf16_f32); pure register code
+__device__ __forceinline__ Split3 split8(const float (&v)[8]) {
+  bf16x2 h[4], m[4], l[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const f32x2 x = {v[2 * p], v[2 * p + 1]};
+    h[p] = __builtin_convertvector(x, bf16x2);
+    const f32x2 r1 = x - __builtin_convertvector(h[p], f32x2);
+    m[p] = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(m[p], f32x2);
+    l[p] = __builtin_convertvector(r2, bf16x2);
+  }
+  Split3 s;
+  s.t[0] = cat4(h[0], h[1], h[2], h[3]);
+  s.t[1] = cat4(m[0], m[1], m[2], m[3]);
+  s.t[2] = cat4(l[0], l[1], l[2], l[3]);
+  return s;
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 u) { return __builtin_bit_cast(bf16x8, u); }
+
+// acc += A * B with both operands given as 3-term splits (A from packed fragments a[0..2])
+__device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const Split3 &b, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.t[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b.t[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b.t[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.t[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b.t[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b.t[0], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f32x16 mfma6(const Split3 &a, const bf16x8 (&b)[3], f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b[0], acc, 0, 0, 0);
+  return acc;
+}
+
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+}  // namespace snet

@@ -93,15 +93,31 @@ def build_graph(types, edge_index, edge_vec, n_local: Optional[int] = None, devi
 
 
 # --------------------------------------------------------------------------- #
+def _pack_split(m: np.ndarray, dev) -> torch.Tensor:
+    """[K,N] fp32 weights -> device buffer of split-precision B fragments (snet_gemm_split_pack)."""
+    lib = _lib.load()
+    m = np.ascontiguousarray(m, dtype=np.float32)
+    K, N = m.shape
+    buf = np.empty(int(lib.snet_gemm_split_size(K, N)), np.uint8)
+    _lib.check(lib.snet_gemm_split_pack(C.c_void_p(m.ctypes.data), K, N, C.c_void_p(buf.ctypes.data)),
+               'snet_gemm_split_pack')
+    return torch.from_numpy(buf).to(dev)
+
+
 class _Linear:
     """Device weights of one LinearSpec (per-GEMM [K,N] and [N,K] copies) and its launch plan:
     per-irrep GEMMs that write distinct output blocks are grouped into one launch."""
 
-    def __init__(self, spec: LinearSpec, flat: np.ndarray, dev):
+    def __init__(self, spec: LinearSpec, flat: np.ndarray, dev, split: bool = True):
         self.spec = spec
+        self.split = split
         mats = linear_weight_matrices(spec, flat)
-        self.w = [torch.from_numpy(m).to(dev) for m in mats]
-        self.wt = [torch.from_numpy(np.ascontiguousarray(m.T)).to(dev) for m in mats]
+        if split:  # bf16 x 6 split-precision MFMA: weights live on the device as packed B fragments
+            self.w = [_pack_split(m, dev) for m in mats]
+            self.wt = [_pack_split(np.ascontiguousarray(m.T), dev) for m in mats]
+        else:
+            self.w = [torch.from_numpy(m).to(dev) for m in mats]
+            self.wt = [torch.from_numpy(np.ascontiguousarray(m.T)).to(dev) for m in mats]
         self.groups_fwd = self._plan(transpose=False)
         self.groups_T = self._plan(transpose=True)
 
@@ -118,7 +134,8 @@ class _Linear:
                 tgt, a_off, c_off, K, N, B = b.out_off, b.in_off, b.out_off, b.mul_in, b.mul_out, w
             key = (tgt, b.species)
             acc = key in written
-            desc = _lib.GemmDesc(B.data_ptr(), a_off, c_off, 2 * b.l + 1, K, N, int(acc))
+            desc = _lib.GemmDesc(None if self.split else B.data_ptr(), B.data_ptr() if self.split else None, a_off, c_off,
+                                 2 * b.l + 1, K, N, int(acc))
             placed = False
             if groups and groups[-1][0] == b.species and len(groups[-1][1]) < 8 and tgt not in groups[-1][2]:
                 groups[-1][1].append(desc)
@@ -153,12 +170,14 @@ class _Span:
 
 
 class HipForceEngine:
-    def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6'):
-        """mlp_mode: 'bf16x6' (split-precision MFMA, fp32-class accuracy, default) or 'fp32'
-        (exact fp32 MFMA) for the fused radial MLP."""
-        if mlp_mode not in ('bf16x6', 'fp32'):
-            raise ValueError("mlp_mode must be 'bf16x6' or 'fp32'")
+    def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6',
+                 linear_mode: str = 'bf16x6'):
+        """mlp_mode / linear_mode: 'bf16x6' (split-precision MFMA, fp32-class accuracy, default) or
+        'fp32' (exact fp32 MFMA) for the fused radial MLP / the node-level equivariant linears."""
+        if mlp_mode not in ('bf16x6', 'fp32') or linear_mode not in ('bf16x6', 'fp32'):
+            raise ValueError("mlp_mode / linear_mode must be 'bf16x6' or 'fp32'")
         self.mlp_mode = mlp_mode
+        self.linear_mode = linear_mode
         self.events = None  # set to [] to collect (name, start, end) HIP events per kernel class
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -184,12 +203,13 @@ class HipForceEngine:
             assert len(emb) == 1
             self.embed_table = torch.from_numpy(emb[0]).to(self.dev)  # [n_species, dim0]
             self.layers = []
+            split = linear_mode == 'bf16x6'
             for ls in sp.layers:
                 L = type('L', (), {})()
                 L.spec = ls
-                L.sc = _Linear(ls.sc, sd[ls.sc.name], self.dev) if ls.sc is not None else None
-                L.si1 = _Linear(ls.si1, sd[ls.si1.name], self.dev)
-                L.si2 = _Linear(ls.si2, sd[ls.si2.name], self.dev)
+                L.sc = _Linear(ls.sc, sd[ls.sc.name], self.dev, split) if ls.sc is not None else None
+                L.si1 = _Linear(ls.si1, sd[ls.si1.name], self.dev, split)
+                L.si2 = _Linear(ls.si2, sd[ls.si2.name], self.dev, split)
                 L.mlp_w, L.mlp_wt = [], []
                 for i in range(len(ls.mlp_dims) - 1):
                     w = sd[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] / np.sqrt(ls.mlp_dims[i])
@@ -220,8 +240,8 @@ class HipForceEngine:
                                            ACT_CST[inv_act[s.act]])
                 L.gate_segs = segs
                 self.layers.append(L)
-            self.ro1 = _Linear(sp.readout1, sd[sp.readout1.name], self.dev)
-            self.ro2 = _Linear(sp.readout2, sd[sp.readout2.name], self.dev)
+            self.ro1 = _Linear(sp.readout1, sd[sp.readout1.name], self.dev, split)
+            self.ro2 = _Linear(sp.readout2, sd[sp.readout2.name], self.dev, split)
             n_sc = shapes['rescale_atomic_energy.scale'][0]
             self.n_scale = n_sc
             self.scale = torch.tensor(sd['rescale_atomic_energy.scale'], dtype=torch.float32, device=self.dev)
@@ -264,7 +284,7 @@ class HipForceEngine:
                 if m == 0:
                     continue
             if force_acc:
-                arr2 = (_lib.GemmDesc * cnt)(*[_lib.GemmDesc(d.B, d.a_off, d.c_off, d.d, d.K, d.N, 1) for d in arr[:cnt]])
+                arr2 = (_lib.GemmDesc * cnt)(*[_lib.GemmDesc(d.B, d.B_split, d.a_off, d.c_off, d.d, d.K, d.N, 1) for d in arr[:cnt]])
                 arr = arr2
             _lib.check(self.lib.snet_gemm_grouped(arr, cnt, _ptr(A), _ptr(Cm), m, a_stride, c_stride, _ptr(rows),
                                                   _stream()), 'snet_gemm_grouped')

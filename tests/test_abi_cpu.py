@@ -89,3 +89,29 @@ def test_neighbor_list_edge_count_pins():
     h2o = np.array([[0, 0, 0.119262], [0, 0.763239, -0.477047], [0, -0.763239, -0.477047]])
     assert neighbor_list(h2o, np.zeros((3, 3)), [0, 0, 0], 4.0)[0].shape[1] == 6
     assert neighbor_list(np.zeros((1, 3)), np.zeros((3, 3)), [0, 0, 0], 4.0)[0].shape[1] == 0
+
+
+def test_gemm_split_pack_is_an_exact_three_term_bf16_sum():
+    """host packing of weights for the split-precision GEMM: every value = hi + mid + lo (bf16 each)
+    to within 2^-24 relative, laid out as MFMA B fragments with zero padding"""
+    import ctypes as C
+    import numpy as np
+    from sevennet_amd import _lib
+    lib = _lib.load()
+    K, N = 21, 37
+    B = np.random.default_rng(0).standard_normal((K, N)).astype(np.float32)
+    size = lib.snet_gemm_split_size(K, N)
+    assert size == 2 * 2 * 3 * 64 * 16
+    buf = np.zeros(size, np.uint8)
+    assert lib.snet_gemm_split_pack(C.c_void_p(B.ctypes.data), K, N, C.c_void_p(buf.ctypes.data)) == 0
+    h = buf.view(np.uint16).reshape(2, 2, 3, 64, 8)   # [tile][q][term][lane][i]
+    f = (h.astype(np.uint32) << 16).view(np.float32)
+    total = f.sum(axis=2, dtype=np.float64)            # [tile][q][lane][i]
+    for t in range(2):
+        for q in range(2):
+            for lane in range(64):
+                for i in range(8):
+                    k, n = 16 * q + 8 * (lane >> 5) + i, 32 * t + (lane & 31)
+                    want = float(B[k, n]) if (k < K and n < N) else 0.0
+                    assert abs(total[t, q, lane, i] - want) <= 2.0 ** -22 * abs(want)
+    assert lib.snet_gemm_split_pack(None, K, N, C.c_void_p(buf.ctypes.data)) != 0

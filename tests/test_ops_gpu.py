@@ -64,12 +64,67 @@ def test_gemm_grouped_matches_separate_launches():
     C2 = torch.zeros(n, dout, device=dev)
     for (d, K, N, ao, co), B in zip(probs, Bs):
         L.check(lib.snet_gemm(_p(A), _p(B), _p(C1), n, d, K, N, din, ao, dout, co, None, 0, None))
-    descs = (L.GemmDesc * 3)(*[L.GemmDesc(B.data_ptr(), ao, co, d, K, N, 0) for (d, K, N, ao, co), B in zip(probs, Bs)])
+    descs = (L.GemmDesc * 3)(*[L.GemmDesc(B.data_ptr(), None, ao, co, d, K, N, 0) for (d, K, N, ao, co), B in zip(probs, Bs)])
     L.check(lib.snet_gemm_grouped(descs, 3, _p(A), _p(C2), n, din, dout, None, None))
     torch.cuda.synchronize()
     assert torch.equal(C1, C2)
     ref = (A[:, :128].double() @ Bs[0].double())
     assert (C2[:, :224].double() - ref).abs().max() < 1e-3
+
+
+def _pack_split(L, lib, B):
+    import ctypes as C
+    Bh = np.ascontiguousarray(B.cpu().numpy(), np.float32)
+    K, N = Bh.shape
+    buf = np.empty(int(lib.snet_gemm_split_size(K, N)), np.uint8)
+    L.check(lib.snet_gemm_split_pack(C.c_void_p(Bh.ctypes.data), K, N, C.c_void_p(buf.ctypes.data)))
+    return torch.from_numpy(buf).to(B.device)
+
+
+@pytest.mark.parametrize('n', [1234, 70000])   # 32 and 64 rows per wave
+@pytest.mark.parametrize('shape', ['sevennet0_sc', 'si2_like', 'ragged'])
+def test_gemm_split_precision_vs_fp64(shape, n):
+    """bf16 x 6 split-precision GEMM on packed weights: fp32-class accuracy (same bar as the fp32 MFMA
+    kernel), including K, N that are not multiples of the 16 x 32 fragment, species row lists and
+    accumulation"""
+    L, lib = _lib()
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(11)
+    if shape == 'sevennet0_sc':
+        din, dout, probs = 480, 576, [(1, 128, 224, 0, 0), (3, 64, 64, 128, 224), (5, 32, 32, 320, 416)]
+    elif shape == 'si2_like':
+        din, dout, probs = 3136, 576, [(1, 224, 224, 0, 0), (3, 384, 64, 224, 224), (5, 352, 32, 1376, 416)]
+    else:
+        din, dout, probs = 61, 83, [(1, 4, 7, 0, 0), (3, 9, 20, 4, 7), (5, 6, 3, 31, 67)]
+    if n > 10000 and shape == 'si2_like':
+        n = 20000
+    A = torch.randn(n, din, generator=g).to(dev)
+    Bs = [torch.randn(K, N, generator=g).to(dev) for (_, K, N, _, _) in probs]
+    packed = [_pack_split(L, lib, B) for B in Bs]
+    C1 = torch.full((n, dout), 7.0, device=dev)
+    descs = (L.GemmDesc * 3)(*[L.GemmDesc(None, P.data_ptr(), ao, co, d, K, N, 0) for (d, K, N, ao, co), P in zip(probs, packed)])
+    L.check(lib.snet_gemm_grouped(descs, 3, _p(A), _p(C1), n, din, dout, None, None))
+    torch.cuda.synchronize()
+    for (d, K, N, ao, co), B in zip(probs, Bs):
+        ref = torch.einsum('nmk,kj->nmj', A[:, ao:ao + d * K].reshape(n, d, K).double(), B.double()).reshape(n, d * N)
+        got = C1[:, co:co + d * N].double()
+        assert (got - ref).abs().max() <= 3e-6 * ref.abs().max(), (shape, d, K, N)
+    # accumulate + row list: only the listed rows change, by exactly one more product
+    rows = torch.arange(0, n, 3, dtype=torch.int32, device=dev)
+    C2 = C1.clone()
+    descs_acc = (L.GemmDesc * 3)(*[L.GemmDesc(None, P.data_ptr(), ao, co, d, K, N, 1) for (d, K, N, ao, co), P in zip(probs, packed)])
+    L.check(lib.snet_gemm_grouped(descs_acc, 3, _p(A), _p(C2), rows.numel(), din, dout, _p(rows), None))
+    torch.cuda.synchronize()
+    d, K, N, ao, co = probs[0]
+    sel = rows.long()
+    assert torch.allclose(C2[sel, co:co + N], 2 * C1[sel, co:co + N], rtol=1e-5, atol=1e-4)
+    mask = torch.ones(n, dtype=torch.bool, device=dev)
+    mask[sel] = False
+    assert torch.equal(C2[mask], C1[mask])
+    # mixing packed and fp32 weights in one group is refused
+    mixed = (L.GemmDesc * 2)(L.GemmDesc(Bs[0].data_ptr(), None, 0, 0, 1, probs[0][1], probs[0][2], 0),
+                             L.GemmDesc(None, packed[1].data_ptr(), probs[1][3], probs[1][4], probs[1][0], probs[1][1], probs[1][2], 0))
+    assert lib.snet_gemm_grouped(mixed, 2, _p(A), _p(C2), n, din, dout, None, None) != 0
 
 
 @pytest.mark.parametrize('mode', [0, 1])
