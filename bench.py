@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--host', default='python', choices=['python', 'native'],
                     help="who sequences the kernels: the Python host (per-kernel HIP-event timers) or the native "
                          "snet_model_eval sequencer (same kernels; kernel timers then come from an extra untimed pass)")
+    ap.add_argument('--fuse-conv', action='store_true',
+                    help='experimental: radial-MLP last layer inside the forward tensor-product kernels')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-reps', type=int, default=5, help='CPU-baseline sample: cells per axis (5 -> 1000 atoms)')
     return ap.parse_args()
@@ -68,6 +70,7 @@ def kernel_model(ls, n_nodes, n_edges):
     mlp_flops = 2.0 * n_edges * sum(h[i] * h[i + 1] for i in range(len(h) - 1))
     return {
         f'conv_fwd[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 4 * nsh + 8) + n_nodes * 4 * dmid),
+        f'conv_fwd_fused[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 4 * nsh + 8) + n_nodes * 4 * dmid),
         f'conv_bwd_edge[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 2 * 4 * nsh + 8) + n_nodes * 4 * dmid),
         f'conv_bwd_node[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dmid + 4 * nsh + 12) + n_nodes * 4 * dx),
         f'radial_mlp_fwd[wn={wn}]': dict(bound='mfma', flops=mlp_flops),
@@ -130,7 +133,7 @@ def main():
 
     cfg = model_config(a.model)
     sd = random_state_dict(cfg, seed=0)
-    eng = HipForceEngine(cfg, sd, device=dev, mlp_mode=a.mlp_mode)
+    eng = HipForceEngine(cfg, sd, device=dev, mlp_mode=a.mlp_mode, fuse_conv=a.fuse_conv)
 
     pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
     n_atoms = len(pos)
@@ -215,7 +218,7 @@ def main():
         pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))[-1]
         with open(pmc) as f:
             tr = json.load(f)
-        key = dominant.replace('conv_bwd_edge[', 'conv_bwd_edge_vec_').replace('conv_fwd[', 'conv_fwd_') \
+        key = dominant.replace('conv_bwd_edge[', 'conv_bwd_edge_vec_').replace('conv_fwd_fused[', 'conv_ffwd_').replace('conv_fwd[', 'conv_fwd_') \
             .replace('conv_bwd_node[', 'conv_bwd_node_').rstrip(']')
         # a kernel class may be several kernels (one per x irrep block: <name>_k0, _k1, ...)
         parts = [v for k, v in tr.items() if k == key or k.startswith(key + '_k')]

@@ -135,6 +135,19 @@ int snet_conv_plan_dims(const snet_conv_plan *plan, int32_t *dx, int32_t *dout, 
 int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
                   const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, float *out,
                   void *stream);
+/* Radial MLP's last layer fused into the forward: w = h2 @ W2 is formed on the matrix cores inside the
+ * tensor-product kernel (one wavefront per node x 32-channel tile x path group; w lands with
+ * lane = channel, accumulator register = edge, exactly the tensor product's operand layout) instead
+ * of being written by snet_radial_mlp_fwd and read back -- E*wn*4 bytes less HBM traffic per layer.
+ *   h2[E,64]  hidden activations of the MLP (snet_radial_mlp_hidden_fwd, split-precision plan)
+ *   w_out     nullable: the weights are also streamed out once for the reverse kernels
+ * snet_conv_plan_fused() != 0 iff the shape has such a kernel (every channel multiplicity and path
+ * weight offset a multiple of 32); results equal snet_radial_mlp_fwd + snet_conv_fwd to fp32 rounding. */
+int snet_radial_mlp_hidden_fwd(const snet_mlp_plan *plan, const float *emb, int64_t n_edges, float *h2, void *stream);
+int snet_conv_plan_fused(const snet_conv_plan *plan);
+int snet_conv_fwd_fused(const snet_conv_plan *plan, const snet_mlp_plan *mlp, const float *x, const float *sh,
+                        const float *h2, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
+                        float *out, float *w_out, void *stream);
 /* per-edge gradients given g_out[n_dst,dout]: g_w[E,wn] (overwritten), g_sh[E,nsh] (ACCUMULATED,
  * so one buffer collects all layers) and, if g_xe != NULL, this edge's contribution to the gradient
  * of its source row, g_xe[E,dx] (overwritten; sum it per source node with snet_segment_sum_rows --

@@ -66,6 +66,10 @@ SIGNATURES = {
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'snet_conv_fwd': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_float,
                                 c_f32p, c_stream]),
+    'snet_radial_mlp_hidden_fwd': (C.c_int, [C.c_void_p, c_f32p, C.c_int64, c_f32p, c_stream]),
+    'snet_conv_plan_fused': (C.c_int, [C.c_void_p]),
+    'snet_conv_fwd_fused': (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_float,
+                                      c_f32p, c_f32p, c_stream]),
     'snet_conv_bwd_edge': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_float,
                                      c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     'snet_segment_sum_rows': (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, c_f32p, c_stream]),

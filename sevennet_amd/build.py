@@ -49,7 +49,7 @@ def _flags() -> List[str]:
 
 def _stamp(src: str) -> str:
     h = hashlib.sha1()
-    for p in [src, os.path.join(CSRC, 'snet_common.h'), os.path.join(INCLUDE, 'snet_hip.h'),
+    for p in [src, os.path.join(CSRC, 'snet_common.h'), os.path.join(CSRC, 'snet_split.h'), os.path.join(INCLUDE, 'snet_hip.h'),
               os.path.join(CSRC, 'generated', 'sh_generated.h')]:
         with open(p, 'rb') as f:
             h.update(f.read())

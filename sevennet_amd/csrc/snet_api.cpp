@@ -84,6 +84,22 @@ int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, c
   SNET_CHECK_LAUNCH("snet_conv_fwd");
   return 0;
 }
+int snet_conv_plan_fused(const snet_conv_plan *plan) { return plan != nullptr && plan->k->fwd_fused != nullptr; }
+int snet_conv_fwd_fused(const snet_conv_plan *plan, const snet_mlp_plan *mlp, const float *x, const float *sh,
+                        const float *h2, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
+                        float *out, float *w_out, void *stream) {
+  SNET_REQUIRE(plan != nullptr && mlp != nullptr, "snet_conv_fwd_fused: null plan");
+  SNET_REQUIRE(plan->k->fwd_fused != nullptr, "snet_conv_fwd_fused: this tensor-product shape has no fused kernel "
+                                              "(channel multiplicities must be multiples of 32)");
+  SNET_REQUIRE(snet::mlp_plan_w2_split(mlp) != nullptr && snet::mlp_plan_wn(mlp) == plan->k->wn,
+               "snet_conv_fwd_fused: radial-MLP plan must be split-precision with the shape's weight_numel");
+  SNET_REQUIRE(n_dst < (1ll << 31), "snet_conv_fwd_fused: too many nodes");
+  if (n_dst <= 0) return 0;
+  plan->k->fwd_fused(x, sh, h2, snet::mlp_plan_w2_split(mlp), row_ptr, src, n_dst, scale, out, w_out,
+                     static_cast<hipStream_t>(stream));
+  SNET_CHECK_LAUNCH("snet_conv_fwd_fused");
+  return 0;
+}
 int snet_conv_bwd_edge(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
                        const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, const float *g_out,
                        float *g_w, float *g_xe, float *g_sh, void *stream) {

@@ -43,8 +43,16 @@ struct ConvKernels {
   void (*bwd_node)(const float *sh, const float *w, const int32_t *col_ptr, const int32_t *eperm,
                    const int32_t *dst, int64_t n_src, float scale, const float *g_out, float *g_x,
                    hipStream_t st);
+  // radial-MLP last layer fused into the forward (nullptr when the shape has no such kernel):
+  // h2[E,64] hidden activations, W2p = snet_gemm_split_pack(W2[64,wn]); w_out nullable
+  void (*fwd_fused)(const float *x, const float *sh, const float *h2, const void *W2p, const int32_t *row_ptr,
+                    const int32_t *src, int64_t n_dst, float scale, float *out, float *w_out, hipStream_t st);
 };
 void register_conv(const ConvKernels *k);
+
+// radial-MLP plan internals needed by the fused tensor-product launch (snet_mlp.hip)
+const void *mlp_plan_w2_split(const snet_mlp_plan *plan);  // nullptr unless the plan is split-precision
+int mlp_plan_wn(const snet_mlp_plan *plan);
 
 struct ConvRegistrar {
   explicit ConvRegistrar(const ConvKernels *k) { register_conv(k); }

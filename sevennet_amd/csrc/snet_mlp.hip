@@ -411,6 +411,32 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_kernel(const floa
   }
 }
 
+// hidden activations only: h2[E,64] = act(act(emb W0) cst W1) cst -- the operand of the radial MLP's last
+// layer when that layer is fused into the tensor-product kernels (generated conv_ffwd_*)
+__global__ __launch_bounds__(256, 2) void radial_mlp_hidden_split_kernel(const float *__restrict__ emb, int64_t E, int nb,
+                                                                      const float *__restrict__ W0,
+                                                                      const u32x4 *__restrict__ W1A, int act, float cst,
+                                                                      float *__restrict__ h2) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, li = lane & 31;
+  const int64_t e_lane = ((int64_t)blockIdx.x * 4 + wave) * 32 + li;
+  const bool e_ok = e_lane < E;
+  f32x16 z1[2], z2[2];
+  hidden_forward_split(emb, e_ok ? e_lane : 0, e_ok, nb, W0, W1A, act, cst, lane, z1, z2);
+  if (!e_ok) return;
+  // lane (li, half) holds hidden units 32t + (r&3) + 8(r>>2) + 4 half of edge li: 16-byte groups
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = snet::act_fwd(z2[t][4 * g + i], act) * cst;
+      *reinterpret_cast<f32x4 *>(h2 + e_lane * H + 32 * t + 8 * g + 4 * half) = v;
+    }
+}
+
 constexpr int GS_STRIDE = 36;               // g_w tile row stride (floats): conflict-free 16-B column reads
 constexpr int GS_TILE = 32 * GS_STRIDE;
 constexpr int SLAB_U4 = 2 * 2 * 3 * 64;     // uint4 per 32-channel slab of W2A: [step(2)][tile(2)][term(3)][lane]
@@ -557,6 +583,7 @@ struct snet_mlp_plan {
   float cst;
   float *W0 = nullptr, *W1 = nullptr, *W2 = nullptr, *W2T = nullptr;               // fp32 mode
   u32x4 *W1A = nullptr, *W2B = nullptr, *W2A = nullptr, *W1A2 = nullptr, *W0A = nullptr;  // split mode
+  void *W2S = nullptr;  // split mode: W2 as snet_gemm_split_pack fragments (natural k order) for the fused conv
 };
 
 namespace {
@@ -650,6 +677,9 @@ extern "C" int snet_radial_mlp_plan_create(int32_t nb, int32_t h1, int32_t h2, i
                     const int k0 = lane & 31;
                     return k0 < nb ? w0[(size_t)k0 * H + kmap(f, lane >> 5, i)] : 0.f;
                   }), (void **)&p->W0A);
+    std::vector<unsigned char> packed((size_t)snet_gemm_split_size(H, wn));
+    bad |= snet_gemm_split_pack(w2.data(), H, wn, packed.data());
+    bad |= upload(packed, &p->W2S);
   }
   if (bad) {
     snet::set_error("snet_radial_mlp_plan_create: device allocation / upload failed");
@@ -663,7 +693,7 @@ extern "C" int snet_radial_mlp_plan_create(int32_t nb, int32_t h1, int32_t h2, i
 extern "C" void snet_radial_mlp_plan_destroy(snet_mlp_plan *p) {
   if (!p) return;
   for (void *d : {(void *)p->W0, (void *)p->W1, (void *)p->W2, (void *)p->W2T, (void *)p->W1A, (void *)p->W2B,
-                  (void *)p->W2A, (void *)p->W1A2, (void *)p->W0A})
+                  (void *)p->W2A, (void *)p->W1A2, (void *)p->W0A, p->W2S})
     if (d) (void)hipFree(d);
   delete p;
 }
@@ -683,6 +713,23 @@ extern "C" int snet_radial_mlp_fwd(const snet_mlp_plan *p, const float *emb, int
   SNET_CHECK_LAUNCH("snet_radial_mlp_fwd");
   return 0;
 }
+
+extern "C" int snet_radial_mlp_hidden_fwd(const snet_mlp_plan *p, const float *emb, int64_t E, float *h2, void *stream) {
+  SNET_REQUIRE(p != nullptr, "snet_radial_mlp_hidden_fwd: null plan");
+  SNET_REQUIRE(p->mode == 1, "snet_radial_mlp_hidden_fwd: split-precision plans only (mode 1)");
+  if (E <= 0) return 0;
+  const int64_t grid = (E + 127) / 128;
+  SNET_REQUIRE(grid < (1ll << 31), "snet_radial_mlp_hidden_fwd: too many edges");
+  radial_mlp_hidden_split_kernel<<<(unsigned)grid, 256, 0, static_cast<hipStream_t>(stream)>>>(emb, E, p->nb, p->W0, p->W1A,
+                                                                                              p->act, p->cst, h2);
+  SNET_CHECK_LAUNCH("snet_radial_mlp_hidden_fwd");
+  return 0;
+}
+
+namespace snet {
+const void *mlp_plan_w2_split(const snet_mlp_plan *plan) { return plan ? plan->W2S : nullptr; }
+int mlp_plan_wn(const snet_mlp_plan *plan) { return plan ? plan->wn : 0; }
+}  // namespace snet
 
 extern "C" int snet_radial_mlp_bwd(const snet_mlp_plan *p, const float *emb, const float *g_w, int64_t E,
                                    float *g_emb, void *stream) {

@@ -171,9 +171,13 @@ class _Span:
 
 class HipForceEngine:
     def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6',
-                 linear_mode: str = 'bf16x6'):
+                 linear_mode: str = 'bf16x6', fuse_conv: bool = False):
         """mlp_mode / linear_mode: 'bf16x6' (split-precision MFMA, fp32-class accuracy, default) or
-        'fp32' (exact fp32 MFMA) for the fused radial MLP / the node-level equivariant linears."""
+        'fp32' (exact fp32 MFMA) for the fused radial MLP / the node-level equivariant linears.
+        fuse_conv: run the radial MLP's last layer inside the forward tensor-product kernels where the
+        shape has such a kernel (needs mlp_mode 'bf16x6').  Off by default: parity-tested, but at
+        8.3 ms per SevenNet-0 middle layer it is still slower than the separate kernels (2.4 + 2.6 ms);
+        DESIGN.md section 7 has the analysis."""
         if mlp_mode not in ('bf16x6', 'fp32') or linear_mode not in ('bf16x6', 'fp32'):
             raise ValueError("mlp_mode / linear_mode must be 'bf16x6' or 'fp32'")
         self.mlp_mode = mlp_mode
@@ -233,6 +237,8 @@ class HipForceEngine:
                 plan = C.c_void_p()
                 _lib.check(self.lib.snet_conv_plan_create(ls.conv.tag.encode(), C.byref(plan)), 'snet_conv_plan_create')
                 L.plan = plan
+                L.fused_conv = bool(fuse_conv and L.fused_mlp and mlp_mode == 'bf16x6'
+                                    and self.lib.snet_conv_plan_fused(plan))
                 segs = (_lib.GateSeg * len(ls.gate.segs))()
                 inv_act = {v: k for k, v in ACT_ID.items()}
                 for i, s in enumerate(ls.gate.segs):
@@ -387,15 +393,28 @@ class HipForceEngine:
                 if t > 0 and halo is not None:
                     with _Span(self, 'halo_fwd'):
                         halo.forward(h, N)
-                with _Span(self, f'radial_mlp_fwd[wn={ls.conv.weight_numel}]'):
-                    w, zs = self._mlp_fwd(L, emb, E)
                 dmid = ls.conv.irreps_out.dim
                 m = self._new(N, dmid)
                 if E == 0:
                     m.zero_()
-                with _Span(self, f'conv_fwd[{ls.conv.tag}]'):
-                    _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N,
-                                                 L.scale, _ptr(m), st), 'snet_conv_fwd')
+                if L.fused_conv:
+                    # last MLP layer inside the tensor-product kernel: w is written once, never read back here
+                    h2 = self._new(E, 64)
+                    w, zs = self._new(E, ls.conv.weight_numel), None
+                    with _Span(self, 'radial_mlp_hidden_fwd'):
+                        _lib.check(lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb), E, _ptr(h2), st),
+                                   'snet_radial_mlp_hidden_fwd')
+                    with _Span(self, f'conv_fwd_fused[{ls.conv.tag}]'):
+                        _lib.check(lib.snet_conv_fwd_fused(L.plan, L.mlp_plan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.row_ptr),
+                                                           _ptr(g.src), N, L.scale, _ptr(m), _ptr(w), st),
+                                   'snet_conv_fwd_fused')
+                    del h2
+                else:
+                    with _Span(self, f'radial_mlp_fwd[wn={ls.conv.weight_numel}]'):
+                        w, zs = self._mlp_fwd(L, emb, E)
+                    with _Span(self, f'conv_fwd[{ls.conv.tag}]'):
+                        _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N,
+                                                     L.scale, _ptr(m), st), 'snet_conv_fwd')
                 with _Span(self, 'node_linear_fwd'):
                     y = self._linear(L.si2, m, N, g)
                 if sc is not None:

@@ -247,6 +247,63 @@ def test_conv_plugin_vs_oracle_autograd(cfg_name):
         assert err < 3e-5 * max(1.0, b.abs().max().item()), (name, err)
 
 
+@pytest.mark.parametrize('layer', [0, 1, 4])
+def test_conv_fwd_fused_matches_separate_kernels(layer):
+    """radial-MLP last layer inside the tensor-product kernel == snet_radial_mlp_fwd + snet_conv_fwd
+    (same split-precision products, so w agrees to the last bits and out to fp32 summation order);
+    nodes with 0, 1, 31, 32, 33 and 70 edges exercise the 32-row passes"""
+    from sevennet_amd.model_spec import build_model_spec, sevennet_0_config
+    L, lib = _lib()
+    dev = 'cuda:0'
+    ls = build_model_spec(sevennet_0_config()).layers[layer]
+    spec = ls.conv
+    nb, wn, dx, dout, nsh = 8, spec.weight_numel, spec.irreps_x.dim, spec.irreps_out.dim, spec.irreps_sh.dim
+    g = torch.Generator().manual_seed(40 + layer)
+    deg = torch.tensor([0, 1, 31, 32, 33, 70, 0, 28, 28, 5] + [28] * 30)
+    N = len(deg)
+    row_ptr = torch.zeros(N + 1, dtype=torch.int32)
+    row_ptr[1:] = torch.cumsum(deg, 0)
+    E = int(row_ptr[-1])
+    NT = N + 7  # ghost rows: sources only
+    src = torch.randint(0, NT, (E,), generator=g).to(torch.int32)
+    x = torch.randn(NT, dx, generator=g).to(dev)
+    sh = torch.randn(E, nsh, generator=g).to(dev)
+    emb = torch.randn(E, nb, generator=g).to(dev)
+    W0 = (torch.randn(nb, 64, generator=g) / nb ** 0.5).contiguous()
+    W1 = (torch.randn(64, 64, generator=g) / 8).contiguous()
+    W2 = (torch.randn(64, wn, generator=g) / 8).contiguous()
+    fp = lambda t: t.numpy().ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    mlp, plan = C.c_void_p(), C.c_void_p()
+    L.check(lib.snet_radial_mlp_plan_create(nb, 64, 64, wn, fp(W0), fp(W1), fp(W2), 0, 1.6791767923989418, 1, C.byref(mlp)))
+    L.check(lib.snet_conv_plan_create(spec.tag.encode(), C.byref(plan)))
+    assert lib.snet_conv_plan_fused(plan) == 1
+    rp, sr = row_ptr.to(dev), src.to(dev)
+    w_ref = torch.empty(E, wn, device=dev)
+    out_ref = torch.empty(N, dout, device=dev)
+    L.check(lib.snet_radial_mlp_fwd(mlp, _p(emb), E, _p(w_ref), None))
+    L.check(lib.snet_conv_fwd(plan, _p(x), _p(sh), _p(w_ref), _p(rp), _p(sr), N, 0.25, _p(out_ref), None))
+    h2 = torch.empty(E, 64, device=dev)
+    w = torch.full((E, wn), float('nan'), device=dev)
+    out = torch.full((N, dout), float('nan'), device=dev)
+    L.check(lib.snet_radial_mlp_hidden_fwd(mlp, _p(emb), E, _p(h2), None))
+    L.check(lib.snet_conv_fwd_fused(plan, mlp, _p(x), _p(sh), _p(h2), _p(rp), _p(sr), N, 0.25, _p(out), _p(w), None))
+    torch.cuda.synchronize()
+    a1 = torch.nn.functional.silu(emb.double().cpu() @ W0.double()) * 1.6791767923989418
+    a2 = torch.nn.functional.silu(a1 @ W1.double()) * 1.6791767923989418
+    assert (h2.cpu().double() - a2).abs().max() < 5e-6 * a2.abs().max()
+    assert not torch.isnan(w).any() and not torch.isnan(out).any()
+    assert (w - w_ref).abs().max() <= 2e-6 * w_ref.abs().max()
+    assert (out - out_ref).abs().max() <= 2e-5 * out_ref.abs().max()
+    assert out[0].abs().max() == 0 and out[6].abs().max() == 0   # nodes without edges
+    # w_out is optional
+    out2 = torch.empty_like(out)
+    L.check(lib.snet_conv_fwd_fused(plan, mlp, _p(x), _p(sh), _p(h2), _p(rp), _p(sr), N, 0.25, _p(out2), None, None))
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    lib.snet_conv_plan_destroy(plan)
+    lib.snet_radial_mlp_plan_destroy(mlp)
+
+
 def test_segment_sum_rows():
     L, lib = _lib()
     dev = 'cuda:0'

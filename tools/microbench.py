@@ -54,7 +54,11 @@ def main():
     g_xe = eng._new(E, dx)
     km = kernel_model(ls, N, E)
     st = _stream()
+    h2 = rnd(E, 64)
     ops = {
+        'radial_mlp_hidden_fwd': lambda: lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb), E, _ptr(h2), st),
+        f'conv_fwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_fwd_fused(L.plan, L.mlp_plan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), _ptr(w), st),
+        f'conv_fwd_fused_nowout[{ls.conv.tag}]': lambda: lib.snet_conv_fwd_fused(L.plan, L.mlp_plan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), None, st),
         f'radial_mlp_fwd[wn={wn}]': lambda: eng._mlp_fwd(L, emb, E),
         f'conv_fwd[{ls.conv.tag}]': lambda: lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
         f'conv_bwd_edge[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_edge_vec(L.plan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_xe), _ptr(g_vec), st),
