@@ -43,20 +43,62 @@ except ImportError:  # pragma: no cover - depends on the environment
             self.atoms = atoms
 
 
+_OLD_MODULE_NAMES = {
+    'EdgeEmbedding': 'edge_embedding',
+    'reducing nn input to hidden': 'reduce_input_to_hidden',
+    'reducing nn hidden to energy': 'reduce_hidden_to_energy',
+    'rescale atomic energy': 'rescale_atomic_energy',
+}
+for _i in range(10):
+    for _old, _new in (('self connection intro', 'self_connection_intro'), ('convolution', 'convolution'),
+                       ('self interaction 2', 'self_interaction_2'), ('equivariant gate', 'equivariant_gate')):
+        _OLD_MODULE_NAMES[f'{_i} {_old}'] = f'{_i}_{_new}'
+
+
+def map_old_state_dict(state_dict):
+    """Module names of checkpoints written before the 2024-04 renaming -> current names, and the
+    'denumerator' spelling -> 'denominator' (map_old_model, scripts/backward_compatibility.py:44-76)."""
+    out = {}
+    for k, v in state_dict.items():
+        head, _, follower = k.partition('.')
+        follower = follower.replace('denumerator', 'denominator')
+        head = _OLD_MODULE_NAMES.get(head, head)
+        out[head + ('.' + follower if follower else '')] = v
+    return out
+
+
+def patch_old_config(cfg: dict) -> dict:
+    """Defaults that configs of version <= 0.9 lack (patch_old_config, backward_compatibility.py:18-41)."""
+    version = cfg.get('version')
+    if not version:
+        raise ValueError('No version found in config')
+    major, minor = (int(t) for t in str(version).split('.')[:2])
+    if major == 0 and minor <= 9:
+        cf = cfg.get('cutoff_function')
+        if isinstance(cf, dict) and cf.get('cutoff_function_name') == 'XPLOR':
+            cf.pop('poly_cut_p_value', None)
+        if 'train_denominator' not in cfg:
+            cfg['train_denominator'] = cfg.pop('train_avg_num_neigh', False)
+        if cfg.pop('optimize_by_reduce', None) is False:
+            raise ValueError('This checkpoint(optimize_by_reduce: False) is no longer supported')
+        cfg.setdefault('conv_denominator', 0.0)
+        cfg.setdefault('_normalize_sph', False)
+    return cfg
+
+
 def load_reference_checkpoint(path: str):
     """(config, state_dict) from a reference checkpoint file (sevenn/checkpoint.py:286-308:
-    a torch pickle holding 'config' and 'model_state_dict').  Old-version weight re-ordering
-    (scripts/backward_compatibility.py) is not implemented: configs older than 0.10 are accepted
-    as long as their tensors match the engine's expected shapes."""
+    a torch pickle holding 'config' and 'model_state_dict'), with the reference's own
+    backward-compatibility steps: old config defaults and old module names.  The third step of the
+    reference, `sort_old_convolution` (weight-column permutation for < 0.11 instruction order), is not
+    needed here: the engine derives the radial-weight column offsets from the instruction order the
+    checkpoint's version implies (model_spec.build_model_spec) instead of re-sorting the weights."""
     cp = torch.load(path, map_location='cpu', weights_only=False)
     if not isinstance(cp, dict) or 'config' not in cp or 'model_state_dict' not in cp:
         raise ValueError(f'{path} is not a SevenNet checkpoint (config + model_state_dict expected)')
-    cfg = dict(cp['config'])
-    major, minor = (int(t) for t in str(cfg.get('version', '0.12.0')).split('.')[:2])
-    if major == 0 and minor <= 9:  # patch_old_config, backward_compatibility.py:18-41
-        cfg.setdefault('_normalize_sph', False)
-        cfg.setdefault('conv_denominator', 0.0)
-    sd = {k: v.detach().cpu().numpy() for k, v in cp['model_state_dict'].items() if hasattr(v, 'detach')}
+    cfg = patch_old_config(dict(cp['config']))
+    sd = {k: v.detach().cpu().numpy() for k, v in map_old_state_dict(cp['model_state_dict']).items()
+          if hasattr(v, 'detach')}
     return cfg, sd
 
 

@@ -77,3 +77,35 @@ def test_deploy_cli_from_checkpoint(tmp_path):
     assert blob[:8] == b'SNETMDL1'
     tail = blob[-400:].decode('latin1')
     assert 'chemical_symbols_to_index=Hf O\n' in tail and 'model_type=E3_equivariant_model' in tail
+
+
+def test_old_checkpoint_names_and_config_defaults(tmp_path):
+    """checkpoints written before the 2024-04 module renaming / version <= 0.9 configs
+    (reference: scripts/backward_compatibility.py:18-76)"""
+    import torch
+    from sevennet_amd.calculator import load_reference_checkpoint
+    old = {'EdgeEmbedding.basis_function.coeffs': torch.arange(8.0),
+           '0 convolution.denumerator': torch.tensor([28.0]),
+           '0 self interaction 2.linear.weight': torch.ones(4),
+           '0 equivariant gate.x': torch.zeros(1),
+           '1 self connection intro.linear.weight': torch.ones(2),
+           'reducing nn input to hidden.linear.weight': torch.ones(3),
+           'rescale atomic energy.shift': torch.zeros(1),
+           'onehot_to_feature_x.linear.weight': torch.ones(5)}
+    cfg = {'version': '0.9.0', 'train_avg_num_neigh': True, 'cutoff': 5.0,
+           'cutoff_function': {'cutoff_function_name': 'XPLOR', 'cutoff_on': 4.5, 'poly_cut_p_value': 6}}
+    p = tmp_path / 'old.pth'
+    torch.save({'config': cfg, 'model_state_dict': old}, p)
+    c, sd = load_reference_checkpoint(str(p))
+    assert set(sd) == {'edge_embedding.basis_function.coeffs', '0_convolution.denominator',
+                       '0_self_interaction_2.linear.weight', '0_equivariant_gate.x',
+                       '1_self_connection_intro.linear.weight', 'reduce_input_to_hidden.linear.weight',
+                       'rescale_atomic_energy.shift', 'onehot_to_feature_x.linear.weight'}
+    assert c['train_denominator'] is True and c['conv_denominator'] == 0.0 and c['_normalize_sph'] is False
+    assert 'poly_cut_p_value' not in c['cutoff_function']
+    torch.save({'config': {'cutoff': 5.0}, 'model_state_dict': old}, p)
+    with pytest.raises(ValueError, match='version'):
+        load_reference_checkpoint(str(p))
+    torch.save({'config': dict(cfg, optimize_by_reduce=False), 'model_state_dict': old}, p)
+    with pytest.raises(ValueError, match='optimize_by_reduce'):
+        load_reference_checkpoint(str(p))
