@@ -437,11 +437,14 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_hidden_split_kernel(const f
     }
 }
 
+#ifndef SNET_MLP_BWD_OCC
+#define SNET_MLP_BWD_OCC 3
+#endif
 constexpr int GS_STRIDE = 36;               // g_w tile row stride (floats): conflict-free 16-B column reads
 constexpr int GS_TILE = 32 * GS_STRIDE;
 constexpr int SLAB_U4 = 2 * 2 * 3 * 64;     // uint4 per 32-channel slab of W2A: [step(2)][tile(2)][term(3)][lane]
 
-__global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(
+__global__ __launch_bounds__(256, SNET_MLP_BWD_OCC) void radial_mlp_bwd_split_kernel(
     const float *__restrict__ emb, const float *__restrict__ g_w, int64_t E, int nb, int wn,
     const float *__restrict__ W0, const u32x4 *__restrict__ W1A, const u32x4 *__restrict__ W2A,
     const u32x4 *__restrict__ W1A2, const u32x4 *__restrict__ W0A, int act, float cst, float *__restrict__ g_emb) {
@@ -497,10 +500,8 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(
   store_chunk(0, 0);
   __syncthreads();
 
-  f32x16 z1[2], z2[2];
-  hidden_forward_split(emb, e_ok ? e_lane : 0, e_ok, nb, W0, W1A, act, cst, lane, z1, z2);
-
-  // G_a2^T[k, e] = sum_ch W2'[k][ch] g_w[e][ch]
+  // G_a2^T[k, e] = sum_ch W2'[k][ch] g_w[e][ch]   (the hidden activations are recomputed AFTER this
+  // loop: 64 fewer live VGPRs while g_w streams through, i.e. one more resident workgroup per CU)
   f32x16 ga2[2];
   ga2[0] = zero16();
   ga2[1] = zero16();
@@ -531,6 +532,8 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_bwd_split_kernel(
     if (ck + 1 < n_chunks) SNET_CHUNK_BODY(ck + 1, 1)
   }
 #undef SNET_CHUNK_BODY
+  f32x16 z1[2], z2[2];
+  hidden_forward_split(emb, e_ok ? e_lane : 0, e_ok, nb, W0, W1A, act, cst, lane, z1, z2);
   // g_z2, then G_a1^T[h, e] = sum_h' W1'[h][h'] g_z2[e][h']
   f32x16 ga1[2];
   ga1[0] = zero16();
