@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round evidence on one MI355X (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh r01
+# writes gpurun_out/<tag>_bench_n1.json, <tag>_rocprofv3_kernel_stats.csv, <tag>_pmc_hbm_traffic.json;
+# copy them into profiles/ afterwards.  The PMC passes run alone (--kernel-trace only), one counter each.
+set -u
+TAG=${1:-rXX}
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o r -- $BENCH > $OUT/${TAG}_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -o r -- $BENCH > $OUT/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -o r -- $BENCH > $OUT/${TAG}_write.log 2>&1
+cd $ROOT
+cp $(find $OUT/${TAG}_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats.csv
+python tools/pmc_reduce.py $(find $OUT/${TAG}_fetch -name "*counter_collection.csv" | head -1) \
+                           $(find $OUT/${TAG}_write -name "*counter_collection.csv" | head -1) > $OUT/${TAG}_pmc_hbm_traffic.json
+# the bench line itself, with the fresh traffic file visible to bench.py
+cp $OUT/${TAG}_pmc_hbm_traffic.json profiles/${TAG}_pmc_hbm_traffic.json
+python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err
+rm -rf $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_stats   # raw traces are large; summaries stay
+tail -c 600 $OUT/${TAG}_bench_n1.json
