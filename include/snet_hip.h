@@ -132,7 +132,11 @@ int snet_conv_plan_create(const char *tag, snet_conv_plan **plan);
 void snet_conv_plan_destroy(snet_conv_plan *plan);
 int snet_conv_plan_dims(const snet_conv_plan *plan, int32_t *dx, int32_t *dout, int32_t *nsh, int32_t *wn);
 
-int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
+/* w_row (nullable, int32[E]): row of w that edge e reads.  NULL = edge e reads row e (the reference's
+ * layout, convolution.py:121).  The radial weights depend on |r| only, so the two directed edges of
+ * one undirected pair carry the same w row; snet_edge_pairs builds the map that lets the radial MLP
+ * run once per pair and w hold one row per pair.                                                   */
+int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, const float *w, const int32_t *w_row,
                   const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, float *out,
                   void *stream);
 /* Radial MLP's last layer fused into the forward: w = h2 @ W2 is formed on the matrix cores inside the
@@ -153,18 +157,20 @@ int snet_conv_fwd_fused(const snet_conv_plan *plan, const snet_mlp_plan *mlp, co
  * of its source row, g_xe[E,dx] (overwritten; sum it per source node with snet_segment_sum_rows --
  * 1.9 KB/edge written once instead of the 12.5 KB/edge g_out gathers of snet_conv_bwd_node).    */
 int snet_conv_bwd_edge(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
-                       const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
+                       const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
                        const float *g_out, float *g_w, float *g_xe, float *g_sh, void *stream);
 /* same, but the spherical-harmonic gradient is contracted with dsh[E,nsh,3] (snet_edge_embed_fwd)
  * inside the kernel and ACCUMULATED into g_vec[E,3]: 3 instead of nsh values per edge cross the
  * wavefront reduction.  This is the variant the whole-model engine uses. */
 int snet_conv_bwd_edge_vec(const snet_conv_plan *plan, const float *x, const float *sh, const float *dsh,
-                           const float *w, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
-                           const float *g_out, float *g_w, float *g_xe, float *g_vec, void *stream);
+                           const float *w, const int32_t *w_row, const int32_t *row_ptr, const int32_t *src,
+                           int64_t n_dst, float scale, const float *g_out, float *g_w, float *g_xe, float *g_vec,
+                           void *stream);
 /* source-node gradient g_x[n_src,dx] (overwritten) via the source-sorted edge
  * permutation: col_ptr[n_src+1], eperm[E] (edge ids grouped by source), dst[E].
  * Deterministic replacement of the scatter-add autograd performs for x[src]. */
-int snet_conv_bwd_node(const snet_conv_plan *plan, const float *sh, const float *w, const int32_t *col_ptr,
+int snet_conv_bwd_node(const snet_conv_plan *plan, const float *sh, const float *w, const int32_t *w_row,
+                       const int32_t *col_ptr,
                        const int32_t *eperm, const int32_t *dst, int64_t n_src, float scale,
                        const float *g_out, float *g_x, void *stream);
 
@@ -281,13 +287,27 @@ int snet_model_set_halo(snet_model *model, snet_halo_fn forward, snet_halo_fn re
 /* One energy/force evaluation.  Device inputs: types[n_total] species index, row_ptr[n_local+1] /
  * src[E] edges sorted by center (CSR), col_ptr[n_total+1] / eperm[E] the same edges grouped by source,
  * edge_vec[E,3] = r_src - r_center.  types_host[n_local] (HOST, may be NULL for models without a
- * per-species self-connection).  Device outputs, each nullable: energy (double), e_atom[n_local],
+ * per-species self-connection).  w_row[E] / pair_edge[n_pairs] (snet_edge_pairs; both NULL and
+ * n_pairs 0 = one radial-weight row per directed edge).  Device outputs, each nullable: energy (double), e_atom[n_local],
  * dE_dr[E,3], forces[n_total,3] (ghost rows folded into owners when halo hooks are set),
  * virial[6] (double, xx yy zz xy yz zx = -sum r (x) dE/dr), virial_atom[n_total,6].             */
 int snet_model_eval(snet_model *model, int64_t n_total, int64_t n_local, int64_t n_edges, const int32_t *types,
                     const int32_t *types_host, const int32_t *row_ptr, const int32_t *src, const int32_t *col_ptr,
-                    const int32_t *eperm, const float *edge_vec, double *energy, float *e_atom, float *dE_dr,
-                    float *forces, double *virial, float *virial_atom, void *stream);
+                    const int32_t *eperm, const float *edge_vec, const int32_t *w_row, const int32_t *pair_edge,
+                    int64_t n_pairs, double *energy, float *e_atom, float *dE_dr, float *forces, double *virial,
+                    float *virial_atom, void *stream);
+
+/* ---- undirected pairs: one radial-weight row per pair --------------------------------------------
+ * The radial MLP's input (Bessel x cutoff of |r|, edge_embedding.py:101-160) is the same for the two
+ * directed edges i->j and j->i, so w[e] == w[rev(e)].  Given the center-sorted edge list of
+ * n_local owned atoms, this finds each edge's reverse (same atom pair, opposite vector within
+ * 2e-5) and numbers the undirected pairs: w_row[e] in [0, n_pairs) is the row edge e reads,
+ * pair_edge[p] is one edge of pair p (whose embedding row feeds the MLP).  Edges whose source is a
+ * ghost (row on another rank) form singleton pairs.  Evaluate the radial MLP on the n_pairs gathered
+ * embedding rows and pass w_row to the snet_conv_* calls: half the MLP work and half the w bytes for
+ * a bulk cell, identical results.  Device in/out; *n_pairs on the HOST (the call synchronises). */
+int snet_edge_pairs(const int32_t *row_ptr, const int32_t *src, const float *edge_vec, int64_t n_local,
+                    int64_t n_edges, int32_t *w_row, int32_t *pair_edge, int64_t *n_pairs, void *stream);
 
 /* ---- MD host: LAMMPS-style neighbor list in, forces accumulated out --------------------------
  * replaces the body of PairE3GNN::compute (sevenn/pair_e3gnn/pair_e3gnn.cpp:74-289) and the graph

@@ -50,7 +50,7 @@ SIGNATURES = {
     'snet_radial_mlp_plan_destroy': (None, [C.c_void_p]),
     'snet_radial_mlp_fwd': (C.c_int, [C.c_void_p, c_f32p, C.c_int64, c_f32p, c_stream]),
     'snet_radial_mlp_bwd': (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int64, c_f32p, c_stream]),
-    'snet_conv_bwd_edge_vec': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int64,
+    'snet_conv_bwd_edge_vec': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64,
                                          C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     'snet_gemm': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                             C.c_int64, C.c_int64, C.c_int64, c_i32p, C.c_int32, c_stream]),
@@ -64,16 +64,16 @@ SIGNATURES = {
     'snet_conv_plan_destroy': (None, [C.c_void_p]),
     'snet_conv_plan_dims': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    'snet_conv_fwd': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_float,
+    'snet_conv_fwd': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_float,
                                 c_f32p, c_stream]),
     'snet_radial_mlp_hidden_fwd': (C.c_int, [C.c_void_p, c_f32p, C.c_int64, c_f32p, c_stream]),
     'snet_conv_plan_fused': (C.c_int, [C.c_void_p]),
     'snet_conv_fwd_fused': (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_float,
                                       c_f32p, c_f32p, c_stream]),
-    'snet_conv_bwd_edge': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_float,
+    'snet_conv_bwd_edge': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_float,
                                      c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     'snet_segment_sum_rows': (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, c_f32p, c_stream]),
-    'snet_conv_bwd_node': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_float,
+    'snet_conv_bwd_node': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_float,
                                      c_f32p, c_f32p, c_stream]),
     'snet_gate_fwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(GateSeg), C.c_int32,
                                 c_stream]),
@@ -103,7 +103,9 @@ SIGNATURES = {
     'snet_model_meta': (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32]),
     'snet_model_set_halo': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     'snet_model_eval': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p,
-                                  c_i32p, c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, c_stream]),
+                                  c_i32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, c_stream]),
+    'snet_edge_pairs': (C.c_int, [c_i32p, c_i32p, c_f32p, C.c_int64, C.c_int64, c_i32p, c_i32p, C.POINTER(C.c_int64),
+                                  c_stream]),
     'snet_md_create': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     'snet_md_destroy': (None, [C.c_void_p]),
     'snet_md_compute': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,

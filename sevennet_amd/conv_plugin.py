@@ -92,7 +92,7 @@ class _UvuConvFn(torch.autograd.Function):
         xc = x.detach().float().contiguous()
         _lib.check(lib.snet_permute_cols(_p(xc), _p(mod.idx_in), _p(x_im), N, mod.dx, _st()), 'snet_permute_cols')
         out_im = torch.empty(N, mod.dout, dtype=torch.float32, device=x.device)
-        _lib.check(lib.snet_conv_fwd(mod.plan, _p(x_im), _p(sh_s), _p(w_s), _p(row_ptr), _p(src_s), N, 1.0,
+        _lib.check(lib.snet_conv_fwd(mod.plan, _p(x_im), _p(sh_s), _p(w_s), None, _p(row_ptr), _p(src_s), N, 1.0,
                                      _p(out_im), _st()), 'snet_conv_fwd')
         out = torch.empty_like(out_im)
         _lib.check(lib.snet_permute_cols(_p(out_im), _p(mod.idx_out_inv), _p(out), N, mod.dout, _st()), 'snet_permute_cols')
@@ -111,13 +111,13 @@ class _UvuConvFn(torch.autograd.Function):
         _lib.check(lib.snet_permute_cols(_p(g_c), _p(mod.idx_out), _p(g_im), N, mod.dout, _st()), 'snet_permute_cols')
         g_w_s = torch.empty(E, mod.wn, dtype=torch.float32, device=dev)
         g_sh_s = torch.zeros(E, mod.nsh, dtype=torch.float32, device=dev)
-        _lib.check(lib.snet_conv_bwd_edge(mod.plan, _p(x_im), _p(sh_s), _p(w_s), _p(row_ptr), _p(src_s), N, 1.0,
+        _lib.check(lib.snet_conv_bwd_edge(mod.plan, _p(x_im), _p(sh_s), _p(w_s), None, _p(row_ptr), _p(src_s), N, 1.0,
                                           _p(g_im), _p(g_w_s), None, _p(g_sh_s), _st()), 'snet_conv_bwd_edge')
         col_ptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
         col_ptr[1:] = torch.cumsum(torch.bincount(src_s.long(), minlength=N), 0)
         eperm = torch.sort(src_s.long(), stable=True).indices.to(torch.int32)
         g_x_im = torch.empty(N, mod.dx, dtype=torch.float32, device=dev)
-        _lib.check(lib.snet_conv_bwd_node(mod.plan, _p(sh_s), _p(w_s), _p(col_ptr.to(torch.int32)), _p(eperm), _p(dst_s),
+        _lib.check(lib.snet_conv_bwd_node(mod.plan, _p(sh_s), _p(w_s), None, _p(col_ptr.to(torch.int32)), _p(eperm), _p(dst_s),
                                           N, 1.0, _p(g_im), _p(g_x_im), _st()), 'snet_conv_bwd_node')
         g_x = torch.empty_like(g_x_im)
         _lib.check(lib.snet_permute_cols(_p(g_x_im), _p(mod.idx_in_inv), _p(g_x), N, mod.dx, _st()), 'snet_permute_cols')

@@ -75,12 +75,12 @@ int snet_conv_plan_dims(const snet_conv_plan *plan, int32_t *dx, int32_t *dout, 
   return 0;
 }
 
-int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
+int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, const float *w, const int32_t *w_row,
                   const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, float *out, void *stream) {
   SNET_REQUIRE(plan != nullptr, "snet_conv_fwd: null plan");
   SNET_REQUIRE(n_dst < (1ll << 31), "snet_conv_fwd: too many nodes");
   if (n_dst <= 0) return 0;
-  plan->k->fwd(x, sh, w, row_ptr, src, n_dst, scale, out, static_cast<hipStream_t>(stream));
+  plan->k->fwd(x, sh, w, w_row, row_ptr, src, n_dst, scale, out, static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_conv_fwd");
   return 0;
 }
@@ -101,33 +101,34 @@ int snet_conv_fwd_fused(const snet_conv_plan *plan, const snet_mlp_plan *mlp, co
   return 0;
 }
 int snet_conv_bwd_edge(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
-                       const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, const float *g_out,
+                       const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, const float *g_out,
                        float *g_w, float *g_xe, float *g_sh, void *stream) {
   SNET_REQUIRE(plan != nullptr, "snet_conv_bwd_edge: null plan");
   SNET_REQUIRE(n_dst < (1ll << 31), "snet_conv_bwd_edge: too many nodes");
   if (n_dst <= 0) return 0;
-  plan->k->bwd_edge(x, sh, w, row_ptr, src, n_dst, scale, g_out, g_w, g_xe, g_sh, static_cast<hipStream_t>(stream));
+  plan->k->bwd_edge(x, sh, w, w_row, row_ptr, src, n_dst, scale, g_out, g_w, g_xe, g_sh, static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_conv_bwd_edge");
   return 0;
 }
 int snet_conv_bwd_edge_vec(const snet_conv_plan *plan, const float *x, const float *sh, const float *dsh,
-                           const float *w, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
+                           const float *w, const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
                            const float *g_out, float *g_w, float *g_xe, float *g_vec, void *stream) {
   SNET_REQUIRE(plan != nullptr, "snet_conv_bwd_edge_vec: null plan");
   SNET_REQUIRE(n_dst < (1ll << 31), "snet_conv_bwd_edge_vec: too many nodes");
   if (n_dst <= 0) return 0;
-  plan->k->bwd_edge_vec(x, sh, dsh, w, row_ptr, src, n_dst, scale, g_out, g_w, g_xe, g_vec,
+  plan->k->bwd_edge_vec(x, sh, dsh, w, w_row, row_ptr, src, n_dst, scale, g_out, g_w, g_xe, g_vec,
                         static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_conv_bwd_edge_vec");
   return 0;
 }
-int snet_conv_bwd_node(const snet_conv_plan *plan, const float *sh, const float *w, const int32_t *col_ptr,
+int snet_conv_bwd_node(const snet_conv_plan *plan, const float *sh, const float *w, const int32_t *w_row,
+                       const int32_t *col_ptr,
                        const int32_t *eperm, const int32_t *dst, int64_t n_src, float scale, const float *g_out,
                        float *g_x, void *stream) {
   SNET_REQUIRE(plan != nullptr, "snet_conv_bwd_node: null plan");
   SNET_REQUIRE(n_src < (1ll << 31), "snet_conv_bwd_node: too many nodes");
   if (n_src <= 0) return 0;
-  plan->k->bwd_node(sh, w, col_ptr, eperm, dst, n_src, scale, g_out, g_x, static_cast<hipStream_t>(stream));
+  plan->k->bwd_node(sh, w, w_row, col_ptr, eperm, dst, n_src, scale, g_out, g_x, static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_conv_bwd_node");
   return 0;
 }

@@ -32,15 +32,16 @@ void set_error(const std::string &msg);
 struct ConvKernels {
   const char *tag;
   int dx, dout, nsh, wn, threads;
-  void (*fwd)(const float *x, const float *sh, const float *w, const int32_t *row_ptr, const int32_t *src,
-              int64_t n_dst, float scale, float *out, hipStream_t st);
-  void (*bwd_edge)(const float *x, const float *sh, const float *w, const int32_t *row_ptr, const int32_t *src,
-                   int64_t n_dst, float scale, const float *g_out, float *g_w, float *g_xe, float *g_sh,
-                   hipStream_t st);
-  void (*bwd_edge_vec)(const float *x, const float *sh, const float *dsh, const float *w, const int32_t *row_ptr,
-                       const int32_t *src, int64_t n_dst, float scale, const float *g_out, float *g_w, float *g_xe,
-                       float *g_vec, hipStream_t st);
-  void (*bwd_node)(const float *sh, const float *w, const int32_t *col_ptr, const int32_t *eperm,
+  // w_row (nullable): row of w read by edge e (edges of one undirected pair may share a row)
+  void (*fwd)(const float *x, const float *sh, const float *w, const int32_t *w_row, const int32_t *row_ptr,
+              const int32_t *src, int64_t n_dst, float scale, float *out, hipStream_t st);
+  void (*bwd_edge)(const float *x, const float *sh, const float *w, const int32_t *w_row, const int32_t *row_ptr,
+                   const int32_t *src, int64_t n_dst, float scale, const float *g_out, float *g_w, float *g_xe,
+                   float *g_sh, hipStream_t st);
+  void (*bwd_edge_vec)(const float *x, const float *sh, const float *dsh, const float *w, const int32_t *w_row,
+                       const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, const float *g_out,
+                       float *g_w, float *g_xe, float *g_vec, hipStream_t st);
+  void (*bwd_node)(const float *sh, const float *w, const int32_t *w_row, const int32_t *col_ptr, const int32_t *eperm,
                    const int32_t *dst, int64_t n_src, float scale, const float *g_out, float *g_x,
                    hipStream_t st);
   // radial-MLP last layer fused into the forward (nullptr when the shape has no such kernel):

@@ -140,12 +140,95 @@ __global__ void md_lower_bound_kernel(const int32_t *__restrict__ keys, int64_t 
   col_ptr[s] = (int32_t)lo;
 }
 
+// ---- undirected pairs of a directed CSR edge list -------------------------------------------
+// canon[e] = min(e, reverse edge) when the reverse edge (center <-> source swapped, opposite vector)
+// is in this list, else e itself (source is a ghost: its row lives on another rank)
+__global__ void pair_find_kernel(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ src,
+                                 const float *__restrict__ ev, int64_t n_local, int64_t E, float tol,
+                                 int32_t *__restrict__ canon, int32_t *__restrict__ flag) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e > E) return;
+  if (e == E) {
+    flag[E] = 0;
+    return;
+  }
+  int64_t lo = 0, hi = n_local;  // center i: row_ptr[i] <= e < row_ptr[i+1]
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (row_ptr[mid] <= e) lo = mid; else hi = mid;
+  }
+  const int i = (int)lo, j = src[e];
+  int32_t c = (int32_t)e;
+  if (j < n_local) {
+    const float vx = ev[3 * e], vy = ev[3 * e + 1], vz = ev[3 * e + 2];
+    for (int k = row_ptr[j]; k < row_ptr[j + 1]; ++k)
+      if (src[k] == i && fabsf(ev[3 * k] + vx) <= tol && fabsf(ev[3 * k + 1] + vy) <= tol &&
+          fabsf(ev[3 * k + 2] + vz) <= tol) {
+        c = k < c ? k : c;
+        break;
+      }
+  }
+  canon[e] = c;
+  flag[e] = c == (int32_t)e;
+}
+
+__global__ void pair_assign_kernel(const int32_t *__restrict__ canon, const int32_t *__restrict__ pid, int64_t E,
+                                   int32_t *__restrict__ w_row, int32_t *__restrict__ pair_edge) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int32_t c = canon[e];
+  w_row[e] = pid[c];
+  if (c == (int32_t)e) pair_edge[pid[e]] = (int32_t)e;
+}
+
+struct PairScratch {
+  DevBuf<int32_t> canon, flag, pid;
+  DevBuf<char> tmp;
+};
+
+int edge_pairs_impl(PairScratch &S, const int32_t *row_ptr, const int32_t *src, const float *edge_vec, int64_t n_local,
+                    int64_t E, int32_t *w_row, int32_t *pair_edge, int64_t *n_pairs, hipStream_t st) {
+  SNET_REQUIRE(E < (1LL << 31) - 1, "snet_edge_pairs: too many edges");
+  *n_pairs = 0;
+  if (E <= 0) return 0;
+  SNET_REQUIRE(n_local > 0, "snet_edge_pairs: edges without local atoms");
+  SNET_REQUIRE(S.canon.ensure(E + 1) && S.flag.ensure(E + 1) && S.pid.ensure(E + 1), "snet_edge_pairs: allocation failed");
+  const unsigned nb = (unsigned)((E + 1 + 255) / 256);
+  pair_find_kernel<<<nb, 256, 0, st>>>(row_ptr, src, edge_vec, n_local, E, 2e-5f, S.canon.p, S.flag.p);
+  SNET_CHECK_LAUNCH("pair_find_kernel");
+  size_t bytes = 0;
+  SNET_REQUIRE(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, S.flag.p, S.pid.p, (int)(E + 1), st) == hipSuccess,
+               "snet_edge_pairs: scan sizing failed");
+  SNET_REQUIRE(S.tmp.ensure(bytes), "snet_edge_pairs: allocation failed");
+  bytes = S.tmp.cap;
+  SNET_REQUIRE(hipcub::DeviceScan::ExclusiveSum(S.tmp.p, bytes, S.flag.p, S.pid.p, (int)(E + 1), st) == hipSuccess,
+               "snet_edge_pairs: scan failed");
+  pair_assign_kernel<<<nb, 256, 0, st>>>(S.canon.p, S.pid.p, E, w_row, pair_edge);
+  SNET_CHECK_LAUNCH("pair_assign_kernel");
+  int32_t np = 0;
+  SNET_REQUIRE(hipMemcpyAsync(&np, S.pid.p + E, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                   hipStreamSynchronize(st) == hipSuccess,
+               "snet_edge_pairs: readback failed");
+  *n_pairs = np;
+  return 0;
+}
+
 }  // namespace
+
+extern "C" int snet_edge_pairs(const int32_t *row_ptr, const int32_t *src, const float *edge_vec, int64_t n_local,
+                               int64_t n_edges, int32_t *w_row, int32_t *pair_edge, int64_t *n_pairs, void *stream) {
+  SNET_REQUIRE(row_ptr && w_row && pair_edge && n_pairs && (n_edges <= 0 || (src && edge_vec)),
+               "snet_edge_pairs: null argument");
+  static thread_local PairScratch scratch;  // grow-only, one per host thread
+  return edge_pairs_impl(scratch, row_ptr, src, edge_vec, n_local, n_edges, w_row, pair_edge, n_pairs,
+                         static_cast<hipStream_t>(stream));
+}
 
 struct snet_md_host {
   snet_model *model = nullptr;
   DevBuf<double> x;
-  DevBuf<int32_t> node_of, ilist, nb_ptr, neigh, types, cnt, row_ptr, src, keys, iota, eperm, col_ptr;
+  DevBuf<int32_t> node_of, ilist, nb_ptr, neigh, types, cnt, row_ptr, src, keys, iota, eperm, col_ptr, w_row, pair_edge;
+  PairScratch pairs;
   DevBuf<float> edge_vec, forces, e_atom, vatom;
   DevBuf<double> scalars;  // energy, virial[6]
   DevBuf<char> cub_tmp;
@@ -171,6 +254,8 @@ extern "C" void snet_md_destroy(snet_md_host *h) {
   h->types.release(); h->cnt.release(); h->row_ptr.release(); h->src.release(); h->keys.release();
   h->iota.release(); h->eperm.release(); h->col_ptr.release(); h->edge_vec.release(); h->forces.release();
   h->e_atom.release(); h->vatom.release(); h->scalars.release(); h->cub_tmp.release();
+  h->w_row.release(); h->pair_edge.release(); h->pairs.canon.release(); h->pairs.flag.release(); h->pairs.pid.release();
+  h->pairs.tmp.release();
   h->h_neigh.release(); h->h_small.release(); h->h_out.release(); h->h_scalars.release();
   delete h;
 }
@@ -312,10 +397,20 @@ extern "C" int snet_md_compute(snet_md_host *h, int32_t inum, const int32_t *ili
   md_lower_bound_kernel<<<(unsigned)((NT + 1 + 255) / 256), 256, 0, st>>>(h->keys.p, E, NT, h->col_ptr.p);
   SNET_CHECK_LAUNCH("md_lower_bound_kernel");
 
+  // ---- undirected pairs: the radial MLP runs once per pair
+  int64_t n_pairs = 0;
+  SNET_REQUIRE(h->w_row.ensure(E + 1) && h->pair_edge.ensure(E + 1), "snet_md_compute: device allocation failed");
+  {
+    const int prc = edge_pairs_impl(h->pairs, h->row_ptr.p, h->src.p, h->edge_vec.p, N, E, h->w_row.p, h->pair_edge.p,
+                                    &n_pairs, st);
+    if (prc) return prc;
+  }
+
   // ---- the model
   double *d_energy = h->scalars.p, *d_virial = h->scalars.p + 1;
   int rc = snet_model_eval(h->model, NT, N, E, h->types.p, h->types_host.data(), h->row_ptr.p, h->src.p, h->col_ptr.p,
-                           h->eperm.p, h->edge_vec.p, d_energy, eflag_atom ? h->e_atom.p : nullptr, nullptr, h->forces.p,
+                           h->eperm.p, h->edge_vec.p, E > 0 ? h->w_row.p : nullptr, E > 0 ? h->pair_edge.p : nullptr, n_pairs,
+                           d_energy, eflag_atom ? h->e_atom.p : nullptr, nullptr, h->forces.p,
                            d_virial, vflag_atom ? h->vatom.p : nullptr, stream);
   if (rc) return rc;
 

@@ -364,12 +364,17 @@ extern "C" int snet_model_set_halo(snet_model *m, snet_halo_fn forward, snet_hal
 
 extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, const int32_t *types,
                                const int32_t *types_host, const int32_t *row_ptr, const int32_t *src,
-                               const int32_t *col_ptr, const int32_t *eperm, const float *edge_vec, double *energy,
+                               const int32_t *col_ptr, const int32_t *eperm, const float *edge_vec,
+                               const int32_t *w_row, const int32_t *pair_edge, int64_t n_pairs, double *energy,
                                float *e_atom, float *dE_dr, float *forces, double *virial, float *virial_atom,
                                void *stream) {
   SNET_REQUIRE(m != nullptr, "snet_model_eval: null model");
   SNET_REQUIRE(NT >= N && N > 0 && E >= 0, "snet_model_eval: need n_total >= n_local > 0 and n_edges >= 0");
   SNET_REQUIRE(NT == N || (m->halo_fwd && m->halo_rev), "snet_model_eval: ghost atoms need halo callbacks");
+  const bool pairs = w_row != nullptr && E > 0;
+  SNET_REQUIRE(!pairs || (pair_edge != nullptr && n_pairs > 0 && n_pairs <= E),
+               "snet_model_eval: w_row needs pair_edge and 0 < n_pairs <= n_edges");
+  const int64_t WR = pairs ? n_pairs : E;  // rows of each layer's radial-weight matrix
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nb = m->n_basis, nsh = (m->lmax + 1) * (m->lmax + 1);
   const int Lc = m->n_layers;
@@ -409,9 +414,10 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   auto add = [&](size_t n) { need += ((n * 4 + 255) / 256) * 256; };
   size_t dmax = (size_t)m->d0, trans = 0;
   add((size_t)E * nb); add((size_t)E * nsh); add((size_t)E * nsh * 3); add((size_t)E * 3); add((size_t)E * nb);
+  add((size_t)WR * nb);
   for (auto &L : m->layers) {
     dmax = dmax > (size_t)L.dout ? dmax : (size_t)L.dout;
-    add((size_t)NT * L.dx); add((size_t)E * L.wn); add((size_t)N * L.gin);  // saved h, w, y
+    add((size_t)NT * L.dx); add((size_t)WR * L.wn); add((size_t)N * L.gin);  // saved h, w, y
     const size_t t = ((size_t)N * L.gin + 64) * 2 + (size_t)N * L.dmid * 2 + (size_t)E * L.wn + (size_t)E * L.dx +
                      (size_t)NT * L.dx * 2 + (size_t)N * L.dout + 4096;
     trans = trans > t ? trans : t;
@@ -433,6 +439,12 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   float *g_vec = dE_dr ? dE_dr : A.f((size_t)E * 3), *g_emb = A.f((size_t)E * nb);
   int rc;
   if ((rc = snet_edge_embed_fwd(&ep, m->coeffs.data(), edge_vec, E, emb, sh, dsh, st))) return rc;
+  const float *emb_w = emb;  // rows the radial MLP runs on: one per undirected pair when a pair map is given
+  if (pairs) {
+    float *ep = A.f((size_t)WR * nb);
+    if ((rc = snet_gather_rows(emb, pair_edge, ep, WR, nb, st))) return rc;
+    emb_w = ep;
+  }
   float *x = A.f((size_t)NT * dmax), *x2 = A.f((size_t)NT * dmax);
   if ((rc = snet_embed_rows(m->embed, types, x, NT, m->d0, st))) return rc;
 
@@ -440,7 +452,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   std::vector<Saved> saved(Lc);
   for (int t = 0; t < Lc; ++t) {
     saved[t].h = A.f((size_t)NT * m->layers[t].dx);
-    saved[t].w = A.f((size_t)E * m->layers[t].wn);
+    saved[t].w = A.f((size_t)WR * m->layers[t].wn);
     saved[t].y = A.f((size_t)N * m->layers[t].gin);
   }
   const size_t mark = A.off;  // transient region starts here
@@ -461,10 +473,11 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
         snet::set_error("snet_model_eval: forward halo callback failed");
         return rc;
       }
-    if ((rc = snet_radial_mlp_fwd(L.mlp_plan, emb, E, saved[t].w, st))) return rc;
+    if ((rc = snet_radial_mlp_fwd(L.mlp_plan, emb_w, WR, saved[t].w, st))) return rc;
     float *mid = A.f((size_t)N * L.dmid);
     if (E == 0) SNET_REQUIRE(hipMemsetAsync(mid, 0, (size_t)N * L.dmid * 4, st) == hipSuccess, "snet_model_eval: memset");
-    if ((rc = snet_conv_fwd(L.conv, h, sh, saved[t].w, row_ptr, src, N, L.conv_scale, mid, st))) return rc;
+    if ((rc = snet_conv_fwd(L.conv, h, sh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, N, L.conv_scale, mid, st)))
+      return rc;
     float *y = saved[t].y;
     if ((rc = run_linear(m, L.si2, mid, y, N, false, false, st))) return rc;
     if (sc && (rc = snet_add_inplace(y, sc, N * (int64_t)L.gin, st))) return rc;
@@ -508,7 +521,8 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     if ((rc = run_linear(m, L.si2, g_y, g_m, N, true, false, st))) return rc;
     float *g_w = A.f((size_t)E * L.wn);
     float *g_xe = t > 0 ? A.f((size_t)E * L.dx) : nullptr;
-    if ((rc = snet_conv_bwd_edge_vec(L.conv, saved[t].h, sh, dsh, saved[t].w, row_ptr, src, N, L.conv_scale, g_m, g_w,
+    if ((rc = snet_conv_bwd_edge_vec(L.conv, saved[t].h, sh, dsh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, N,
+                                     L.conv_scale, g_m, g_w,
                                      g_xe, g_vec, st)))
       return rc;
     if ((rc = snet_radial_mlp_bwd(L.mlp_plan, emb, g_w, E, g_emb, st))) return rc;

@@ -55,10 +55,30 @@ class Graph:
     edge_vec: torch.Tensor   # float32 [E,3]
     order: Optional[torch.Tensor] = None  # permutation applied to the caller's edge order (None = already sorted)
     species_rows: Optional[List[torch.Tensor]] = None  # per species: int32 local row ids (FCTP self-connection)
+    # undirected pairs (snet_edge_pairs): w_row[e] = radial-weight row of edge e, pair_edge[p] = one edge of pair p
+    w_row: Optional[torch.Tensor] = None
+    pair_edge: Optional[torch.Tensor] = None
+    n_pairs: int = 0
+
+    def share_pairs(self):
+        """Number the undirected pairs so the radial MLP runs once per pair (in place; returns self)."""
+        lib = _lib.load()
+        E = self.n_edges
+        if E == 0:
+            return self
+        dev = self.edge_vec.device
+        with torch.cuda.device(dev):
+            w_row = torch.empty(E, dtype=torch.int32, device=dev)
+            pair_edge = torch.empty(E, dtype=torch.int32, device=dev)
+            n = C.c_int64()
+            _lib.check(lib.snet_edge_pairs(_ptr(self.row_ptr), _ptr(self.src), _ptr(self.edge_vec), self.n_local, E,
+                                           _ptr(w_row), _ptr(pair_edge), C.byref(n), _stream()), 'snet_edge_pairs')
+        self.w_row, self.pair_edge, self.n_pairs = w_row, pair_edge[:n.value].contiguous(), int(n.value)
+        return self
 
 
 def build_graph(types, edge_index, edge_vec, n_local: Optional[int] = None, device='cuda',
-                num_species: int = 0) -> Graph:
+                num_species: int = 0, share_pairs: bool = True) -> Graph:
     """types[n_total] (species index), edge_index[2,E] (row 0 = center / destination,
     row 1 = neighbor / source; pair_e3gnn.cpp:192-197 convention), edge_vec[E,3]."""
     dev = torch.device(device)
@@ -87,9 +107,10 @@ def build_graph(types, edge_index, edge_vec, n_local: Optional[int] = None, devi
     rows = None
     if num_species:
         rows = [torch.nonzero(types[:n_local] == s).reshape(-1).to(torch.int32) for s in range(num_species)]
-    return Graph(n_total, n_local, E, types, center.to(torch.int32).contiguous(), src.to(torch.int32).contiguous(),
-                 row_ptr.to(torch.int32), col_ptr.to(torch.int32), eperm.to(torch.int32).contiguous(),
-                 ev.contiguous(), order, rows)
+    g = Graph(n_total, n_local, E, types, center.to(torch.int32).contiguous(), src.to(torch.int32).contiguous(),
+              row_ptr.to(torch.int32), col_ptr.to(torch.int32), eperm.to(torch.int32).contiguous(),
+              ev.contiguous(), order, rows)
+    return g.share_pairs() if share_pairs and dev.type == 'cuda' else g
 
 
 # --------------------------------------------------------------------------- #
@@ -376,6 +397,14 @@ class HipForceEngine:
             with _Span(self, 'edge_embed_fwd'):
                 _lib.check(lib.snet_edge_embed_fwd(C.byref(self.edge_params), self.coeffs, _ptr(g.edge_vec), E,
                                                    _ptr(emb), _ptr(sh), _ptr(dsh), st), 'snet_edge_embed_fwd')
+            # radial weights once per undirected pair (fused-MLP layers only: the unfused fallback keeps
+            # its per-edge hidden activations for the reverse pass)
+            pairs = g.w_row is not None and all(L.fused_mlp for L in self.layers)
+            w_row = g.w_row if pairs else None
+            if pairs:
+                emb_p = self._new(g.n_pairs, nb)
+                _lib.check(lib.snet_gather_rows(_ptr(emb), _ptr(g.pair_edge), _ptr(emb_p), g.n_pairs, nb, st),
+                           'snet_gather_rows')
             d0 = sp.embed.dim_out
             x = self._new(NT, d0)  # ghost layer-0 features depend only on species (model_build.py:383-421)
             _lib.check(lib.snet_embed_rows(_ptr(self.embed_table), _ptr(g.types), _ptr(x), NT, d0, st),
@@ -411,10 +440,11 @@ class HipForceEngine:
                     del h2
                 else:
                     with _Span(self, f'radial_mlp_fwd[wn={ls.conv.weight_numel}]'):
-                        w, zs = self._mlp_fwd(L, emb, E)
+                        # one weight row per undirected pair when the graph carries the pair map
+                        w, zs = self._mlp_fwd(L, emb_p, g.n_pairs) if pairs else self._mlp_fwd(L, emb, E)
                     with _Span(self, f'conv_fwd[{ls.conv.tag}]'):
-                        _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(g.row_ptr), _ptr(g.src), N,
-                                                     L.scale, _ptr(m), st), 'snet_conv_fwd')
+                        _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(w_row), _ptr(g.row_ptr),
+                                                     _ptr(g.src), N, L.scale, _ptr(m), st), 'snet_conv_fwd')
                 with _Span(self, 'node_linear_fwd'):
                     y = self._linear(L.si2, m, N, g)
                 if sc is not None:
@@ -456,7 +486,8 @@ class HipForceEngine:
                 # layer 0: inputs depend on species only -> no source-row gradient needed
                 g_xe = self._new(E, ls.si1.dim_out) if t > 0 else None
                 with _Span(self, f'conv_bwd_edge[{ls.conv.tag}]'):
-                    _lib.check(lib.snet_conv_bwd_edge_vec(L.plan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(w), _ptr(g.row_ptr),
+                    _lib.check(lib.snet_conv_bwd_edge_vec(L.plan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(w),
+                                                          _ptr(None if L.fused_conv else w_row), _ptr(g.row_ptr),
                                                           _ptr(g.src), N, L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_xe),
                                                           _ptr(g_vec), st), 'snet_conv_bwd_edge_vec')
                 with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]'):

@@ -106,7 +106,8 @@ class NativeModel:
             p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
             self._cb_error = None
             rc = self.lib.snet_model_eval(self.handle, NT, N, E, p(g.types), C.c_void_p(types_host.ctypes.data),
-                                          p(g.row_ptr), p(g.src), p(g.col_ptr), p(g.eperm), p(g.edge_vec), p(energy),
+                                          p(g.row_ptr), p(g.src), p(g.col_ptr), p(g.eperm), p(g.edge_vec), p(g.w_row), p(g.pair_edge),
+                                          g.n_pairs if g.w_row is not None else 0, p(energy),
                                           p(e_atom), p(g_vec), p(forces), p(virial), p(vir_atom),
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
             if rc and self._cb_error is not None:

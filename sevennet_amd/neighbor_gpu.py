@@ -26,7 +26,7 @@ def gpu_neighbor_supported(cell, pbc, cutoff: float) -> bool:
 
 
 def build_graph_gpu(types, pos, cell, cutoff: float, device='cuda:0', num_species: int = 0,
-                    with_shifts: bool = False) -> Graph:
+                    with_shifts: bool = False, share_pairs: bool = True) -> Graph:
     """All edges with |r_j - r_i + S.cell| < cutoff of a fully periodic cell, as a device Graph."""
     lib = _lib.load()
     dev = torch.device(device)
@@ -77,4 +77,4 @@ def build_graph_gpu(types, pos, cell, cutoff: float, device='cuda:0', num_specie
             rows = [torch.nonzero(ty == s).reshape(-1).to(torch.int32) for s in range(num_species)]
         g = Graph(n, n, E, ty, center, src, row_ptr, col_ptr.to(torch.int32), eperm, ev, None, rows)
         g.shifts = shifts
-        return g
+        return g.share_pairs() if share_pairs else g

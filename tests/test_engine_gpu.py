@@ -294,3 +294,47 @@ def test_sevennet_l3i5_shape_vs_oracle_small_cell():
     eng, out = _run(cfg, sd, types, ei, ev, keep=True)
     ref = oracle_model(cfg, sd).forward(types, ei, ev, keep=True)
     _compare(eng, out, ref, len(types), rel=1e-4)
+
+
+@pytest.mark.parametrize('case', ['bulk', 'tiny_cell', 'brick'])
+def test_undirected_pair_map_and_shared_radial_weights(case):
+    """snet_edge_pairs: every directed edge finds its reverse (same atoms, opposite vector), pairs are
+    numbered densely, ghost-source edges stay singletons; running the radial MLP once per pair leaves
+    energies and forces unchanged (the two directions have the same |r|)."""
+    from sevennet_amd.engine import build_graph
+    from sevennet_amd.parallel import build_brick_graph
+    from sevennet_amd.shapes import mini_sevennet_0_config
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = mini_sevennet_0_config()
+    sd = random_state_dict(cfg, seed=3)
+    reps = (1, 1, 1) if case == 'tiny_cell' else (3, 3, 3)
+    types, pos, cell, ei, ev = synthetic_system(reps, sigma=0.06, seed=8, cutoff=5.0, n_species=2)
+    n_local = None
+    if case == 'brick':
+        b = build_brick_graph(pos, cell, types, 5.0, 2, 0, neighbors=(ei, ev))
+        types, ei, ev, n_local = b.types, b.edge_index, b.edge_vec, b.n_local
+    g = build_graph(types, ei, ev, n_local=n_local, device='cuda:0')
+    g0 = build_graph(types, ei, ev, n_local=n_local, device='cuda:0', share_pairs=False)
+    assert g0.w_row is None and g.w_row is not None
+    E = g.n_edges
+    w_row, pe = g.w_row.cpu().numpy(), g.pair_edge.cpu().numpy()
+    c, s, v = g.center.cpu().numpy(), g.src.cpu().numpy(), g.edge_vec.cpu().numpy()
+    assert len(pe) == g.n_pairs and w_row.min() == 0 and w_row.max() == g.n_pairs - 1
+    assert np.array_equal(w_row[pe], np.arange(g.n_pairs))          # pair_edge[p] is a member of pair p
+    counts = np.bincount(w_row, minlength=g.n_pairs)
+    assert counts.max() <= 2
+    for p in np.nonzero(counts == 2)[0][:2000]:
+        a, bb = np.nonzero(w_row == p)[0]
+        assert c[a] == s[bb] and s[a] == c[bb] and np.abs(v[a] + v[bb]).max() <= 2e-5
+    singles = np.nonzero(counts == 1)[0]
+    if case == 'brick':
+        assert len(singles) > 0 and (s[pe[singles]] >= g.n_local).all()   # reverse edge lives on the peer
+    else:
+        assert len(singles) == 0 and g.n_pairs * 2 == E
+    if case != 'brick':
+        eng = _engine(cfg, sd)
+        a, bb = eng.compute(g), eng.compute(g0)
+        torch.cuda.synchronize()
+        assert abs(float(a['energy'].cpu()) - float(bb['energy'].cpu())) <= 1e-6 * abs(float(bb['energy'].cpu()))
+        _close(a['forces'], bb['forces'], 2e-6, 1e-8, 'forces (pair-shared radial weights)')
+        _close(a['dE_dr'], bb['dE_dr'], 2e-6, 1e-8, 'dE_dr (pair-shared radial weights)')

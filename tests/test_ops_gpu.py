@@ -281,7 +281,7 @@ def test_conv_fwd_fused_matches_separate_kernels(layer):
     w_ref = torch.empty(E, wn, device=dev)
     out_ref = torch.empty(N, dout, device=dev)
     L.check(lib.snet_radial_mlp_fwd(mlp, _p(emb), E, _p(w_ref), None))
-    L.check(lib.snet_conv_fwd(plan, _p(x), _p(sh), _p(w_ref), _p(rp), _p(sr), N, 0.25, _p(out_ref), None))
+    L.check(lib.snet_conv_fwd(plan, _p(x), _p(sh), _p(w_ref), None, _p(rp), _p(sr), N, 0.25, _p(out_ref), None))
     h2 = torch.empty(E, 64, device=dev)
     w = torch.full((E, wn), float('nan'), device=dev)
     out = torch.full((N, dout), float('nan'), device=dev)
