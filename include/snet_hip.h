@@ -205,6 +205,9 @@ int snet_embed_rows(const float *table, const int32_t *types, float *out, int64_
 
 /* ---- a4.1 and friends: y += x ; column permutation (layout conversion) --- */
 int snet_add_inplace(float *y, const float *x, int64_t n, void *stream);
+/* y[r, :] += bias[:] for r < n_rows: the constant a multi-modal linear's one-hot inputs contribute for a
+ * fixed fidelity channel (IrrepsLinear._patch_modal_to_data, sevenn/nn/linear.py:72-92) */
+int snet_add_row_bias(float *y, const float *bias, int64_t n_rows, int32_t dim, void *stream);
 int snet_permute_cols(const float *x, const int32_t *col_idx, float *out, int64_t n_rows, int32_t dim,
                       void *stream); /* out[r,c] = x[r,col_idx[c]] */
 

@@ -246,11 +246,28 @@ class OracleModel:
     """config + state_dict -> energy/forces.  Follows
     sevenn/model_build.py:448-636 and sevenn/nn/interaction_blocks.py:41-76."""
 
-    def __init__(self, config: dict, state_dict: Optional[dict] = None, dtype=torch.float32):
+    def __init__(self, config: dict, state_dict: Optional[dict] = None, dtype=torch.float32, modal=None):
+        """modal: name (key of config['_modal_map']) or index of the fidelity channel of a multi-modal
+        model (sevenn/model_build.py:185-231); required iff config['use_modality']."""
         cfg = dict(DEFAULTS)
         cfg.update(config)
         self.cfg = cfg
         self.dtype = dtype
+        # multi-modal models: a one-hot of the fidelity channel is appended as extra 0e inputs of the
+        # flagged linears (sevenn/nn/linear.py:66-92) and shift/scale may carry a modal axis
+        self.n_modal = int(cfg.get('_number_of_modalities', 0)) if cfg.get('use_modality') else 0
+        self.modal_idx = None
+        if self.n_modal:
+            if self.n_modal < 2:
+                raise ValueError('use_modality needs _number_of_modalities >= 2')
+            if modal is None:
+                raise ValueError('multi-modal model: a modal must be given')
+            self.modal_idx = int(cfg['_modal_map'][modal]) if isinstance(modal, str) else int(modal)
+            if not 0 <= self.modal_idx < self.n_modal:
+                raise ValueError(f'modal index {self.modal_idx} out of range')
+        self.modal_in = {k: bool(self.n_modal and cfg.get(f, False)) for k, f in (
+            ('embed', 'use_modal_node_embedding'), ('si1', 'use_modal_self_inter_intro'),
+            ('si2', 'use_modal_self_inter_outro'), ('out', 'use_modal_output_block'))}
         self.cutoff = float(cfg['cutoff'])
         self.num_species = int(cfg.get('_number_of_species', cfg.get('num_species', 0))
                                or len(cfg['chemical_species']))
@@ -325,11 +342,25 @@ class OracleModel:
             v = torch.as_tensor(np.asarray(state_dict[k]), dtype=dtype).reshape(shp)
             self.p[k] = v
 
+    # ---------------------------------------------------------------- modal plumbing
+    def _mi(self, irreps: Irreps, which: str) -> Irreps:
+        """input irreps of a (possibly modal-patched) linear: + Mx0e (linear.py:66-71)"""
+        return irreps + Irreps(f'{self.n_modal}x0e') if self.modal_in[which] else irreps
+
+    def _mx(self, x, which: str):
+        """append the modal one-hot columns to every row (linear.py:85-92, unbatched branch)"""
+        if not self.modal_in[which]:
+            return x
+        oh = torch.zeros(self.n_modal, dtype=x.dtype)
+        oh[self.modal_idx] = 1.0
+        return torch.cat([x, oh.expand(x.shape[0], -1)], dim=1)
+
     # ---------------------------------------------------------------- shapes
     def param_shapes(self) -> Dict[str, tuple]:
         s = OrderedDict()
         s['edge_embedding.basis_function.coeffs'] = (self.n_basis,)
-        s['onehot_to_feature_x.linear.weight'] = (linear_weight_numel(Irreps(f'{self.num_species}x0e'), self.irreps_embed),)
+        s['onehot_to_feature_x.linear.weight'] = (
+            linear_weight_numel(self._mi(Irreps(f'{self.num_species}x0e'), 'embed'), self.irreps_embed),)
         for ls in self.layers:
             t = ls.t
             if ls.sc_type == 'nequip':
@@ -338,13 +369,20 @@ class OracleModel:
             elif ls.sc_type == 'linear':
                 s[f'{t}_self_connection_intro.linear.weight'] = (
                     linear_weight_numel(ls.irreps_x, ls.irreps_gate_in),)
-            s[f'{t}_self_interaction_1.linear.weight'] = (linear_weight_numel(ls.irreps_x, ls.irreps_x),)
+            s[f'{t}_self_interaction_1.linear.weight'] = (linear_weight_numel(self._mi(ls.irreps_x, 'si1'), ls.irreps_x),)
             s[f'{t}_convolution.denominator'] = (1,)
             for i in range(len(ls.mlp_dims) - 1):
                 s[f'{t}_convolution.weight_nn.layer{i}.weight'] = (ls.mlp_dims[i], ls.mlp_dims[i + 1])
-            s[f'{t}_self_interaction_2.linear.weight'] = (linear_weight_numel(ls.irreps_out_tp, ls.irreps_gate_in),)
-        s['reduce_input_to_hidden.linear.weight'] = (linear_weight_numel(self.irreps_final, self.irreps_hidden),)
+            s[f'{t}_self_interaction_2.linear.weight'] = (
+                linear_weight_numel(self._mi(ls.irreps_out_tp, 'si2'), ls.irreps_gate_in),)
+        s['reduce_input_to_hidden.linear.weight'] = (
+            linear_weight_numel(self._mi(self.irreps_final, 'out'), self.irreps_hidden),)
         s['reduce_hidden_to_energy.linear.weight'] = (linear_weight_numel(self.irreps_hidden, Irreps('1x0e')),)
+        if self.n_modal:  # ModalWiseRescale (scale.py:196-363): always per species, optionally per modal
+            ns = self.num_species
+            s['rescale_atomic_energy.shift'] = (self.n_modal, ns) if self.cfg.get('use_modal_wise_shift') else (ns,)
+            s['rescale_atomic_energy.scale'] = (self.n_modal, ns) if self.cfg.get('use_modal_wise_scale') else (ns,)
+            return s
         nsc = np.asarray(self.cfg['shift']).size
         nsl = np.asarray(self.cfg['scale']).size
         n = max(nsc, nsl)
@@ -379,7 +417,7 @@ class OracleModel:
 
     def node_embed(self, types):
         onehot = torch.nn.functional.one_hot(types, self.num_species).to(self.dtype)
-        x = linear_apply(onehot, Irreps(f'{self.num_species}x0e'), self.irreps_embed,
+        x = linear_apply(self._mx(onehot, 'embed'), self._mi(Irreps(f'{self.num_species}x0e'), 'embed'), self.irreps_embed,
                          self.p['onehot_to_feature_x.linear.weight'])
         return onehot, x
 
@@ -394,7 +432,8 @@ class OracleModel:
         return None
 
     def si1(self, ls, x):
-        return linear_apply(x, ls.irreps_x, ls.irreps_x, self.p[f'{ls.t}_self_interaction_1.linear.weight'])
+        return linear_apply(self._mx(x, 'si1'), self._mi(ls.irreps_x, 'si1'), ls.irreps_x,
+                            self.p[f'{ls.t}_self_interaction_1.linear.weight'])
 
     def radial_weights(self, ls, emb):
         ws = [self.p[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] for i in range(len(ls.mlp_dims) - 1)]
@@ -411,12 +450,18 @@ class OracleModel:
         return out[:n_out]
 
     def si2(self, ls, x):
-        return linear_apply(x, ls.irreps_out_tp, ls.irreps_gate_in, self.p[f'{ls.t}_self_interaction_2.linear.weight'])
+        return linear_apply(self._mx(x, 'si2'), self._mi(ls.irreps_out_tp, 'si2'), ls.irreps_gate_in,
+                            self.p[f'{ls.t}_self_interaction_2.linear.weight'])
 
     def readout(self, x, types):
-        h = linear_apply(x, self.irreps_final, self.irreps_hidden, self.p['reduce_input_to_hidden.linear.weight'])
+        h = linear_apply(self._mx(x, 'out'), self._mi(self.irreps_final, 'out'), self.irreps_hidden,
+                         self.p['reduce_input_to_hidden.linear.weight'])
         e = linear_apply(h, self.irreps_hidden, Irreps('1x0e'), self.p['reduce_hidden_to_energy.linear.weight'])
         sc, sh = self.p['rescale_atomic_energy.scale'], self.p['rescale_atomic_energy.shift']
+        if self.n_modal:  # ModalWiseRescale.forward, scale.py:341-363
+            sc = sc[self.modal_idx] if sc.dim() == 2 else sc
+            sh = sh[self.modal_idx] if sh.dim() == 2 else sh
+            return e * sc[types].view(-1, 1) + sh[types].view(-1, 1)
         if sc.numel() == 1:
             return e * sc + sh  # Rescale, sevenn/nn/scale.py:53-56
         return e * sc[types].view(-1, 1) + sh[types].view(-1, 1)  # SpeciesWiseRescale :155-162

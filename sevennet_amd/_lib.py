@@ -80,6 +80,7 @@ SIGNATURES = {
     'snet_gate_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(GateSeg),
                                 C.c_int32, c_stream]),
     'snet_embed_rows': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
+    'snet_add_row_bias': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
     'snet_add_inplace': (C.c_int, [c_f32p, c_f32p, C.c_int64, c_stream]),
     'snet_permute_cols': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
     'snet_rescale_reduce': (C.c_int, [c_f32p, c_i32p, c_f32p, c_f32p, C.c_int32, C.c_int64, c_f32p, c_f64p,

@@ -152,12 +152,18 @@ class SevenNetCalculator(Calculator):
             raise ValueError('Model must have the type_map to be used with calculator')
         self.type_map = {int(k): int(v) for k, v in tm.items()}
         self.cutoff = float(cfg['cutoff'])
-        if cfg.get('use_modality'):
-            raise ValueError('multi-modal models are not supported by the HIP engine yet')
-        if modal:
-            warnings.warn(f'modal={modal} is ignored as model has no modal_map')
         self.modal = None
-        self.model = HipForceEngine(cfg, sd, device=str(self.device))
+        modal_map = cfg.get('_modal_map') if cfg.get('use_modality') else None
+        if modal_map:  # sevenn/calculator.py:159-170
+            modal_ava = list(modal_map.keys())
+            if not modal:
+                raise ValueError(f'modal argument missing (avail: {modal_ava})')
+            if modal not in modal_ava:
+                raise ValueError(f'unknown modal {modal} (not in {modal_ava})')
+            self.modal = modal
+        elif modal:
+            warnings.warn(f'modal={modal} is ignored as model has no modal_map')
+        self.model = HipForceEngine(cfg, sd, device=str(self.device), modal=self.modal)
         self._z2type = np.full(120, -1, np.int64)  # sequential.py:80-83
         for z, t in self.type_map.items():
             self._z2type[z] = t

@@ -53,6 +53,7 @@ struct Linear {
     std::vector<snet_gemm_desc> descs;
   };
   std::vector<Group> fwd, rev;  // launch plans: per-irrep GEMMs with distinct targets share a launch
+  float *bias = nullptr;        // device [dim_out]: constant row bias of a multi-modal linear, or null
   bool present() const { return dim_out > 0; }
 };
 
@@ -147,6 +148,12 @@ bool read_linear(Reader &r, Linear &L) {
       for (int n = 0; n < b.mul_out; ++n) wt[(size_t)n * b.mul_in + k] = w[(size_t)k * b.mul_out + n];
     if (!upload_split(w, b.mul_in, b.mul_out, &b.W) || !upload_split(wt, b.mul_out, b.mul_in, &b.WT)) return false;
   }
+  const int has_bias = r.i32();
+  if (!r.ok || (has_bias != 0 && has_bias != 1)) return false;
+  if (has_bias) {
+    std::vector<float> b = r.farr((size_t)L.dim_out);
+    if (!r.ok || !dev_upload(b, &L.bias)) return false;
+  }
   plan_groups(L, false);
   plan_groups(L, true);
   return r.ok;
@@ -218,6 +225,7 @@ int run_linear(snet_model *m, const Linear &L, const float *x, float *y, int64_t
     }
     if (rc) return rc;
   }
+  if (!transpose && L.bias) return snet_add_row_bias(y, L.bias, n, L.dim_out, st);  // multi-modal linear
   return 0;
 }
 
@@ -228,7 +236,7 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
   Reader r{static_cast<const unsigned char *>(blob), static_cast<const unsigned char *>(blob) + n_bytes};
   char magic[8];
   r.get(magic, 8);
-  SNET_REQUIRE(r.ok && memcmp(magic, "SNETMDL1", 8) == 0, "snet_model_load: not a .snet model file");
+  SNET_REQUIRE(r.ok && memcmp(magic, "SNETMDL2", 8) == 0, "snet_model_load: not a .snet model file");
   auto *m = new snet_model;
   m->n_species = r.i32(); m->n_layers = r.i32(); m->lmax = r.i32(); m->normalize = r.i32(); m->n_basis = r.i32();
   m->cutoff_kind = r.i32(); m->poly_p = r.i32(); m->act_radial = r.i32(); m->n_scale = r.i32(); m->d0 = r.i32();
@@ -309,6 +317,7 @@ extern "C" void snet_model_destroy(snet_model *m) {
       if (b.W) (void)hipFree(b.W);
       if (b.WT) (void)hipFree(b.WT);
     }
+    if (L.bias) (void)hipFree(L.bias);
   };
   for (auto &L : m->layers) {
     snet_conv_plan_destroy(L.conv);

@@ -236,6 +236,19 @@ extern "C" int snet_act_bwd(const float *z, const float *g_a, float *g_z, int64_
   SNET_CHECK_LAUNCH("snet_act_bwd");
   return 0;
 }
+namespace {
+__global__ void add_row_bias_kernel(float *__restrict__ y, const float *__restrict__ bias, int64_t n, int dim) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n * dim) y[k] += bias[k % dim];
+}
+}  // namespace
+extern "C" int snet_add_row_bias(float *y, const float *bias, int64_t n_rows, int32_t dim, void *stream) {
+  SNET_REQUIRE(dim >= 1, "snet_add_row_bias: bad dim");
+  if (n_rows <= 0) return 0;
+  add_row_bias_kernel<<<grid_for(n_rows * dim), 256, 0, static_cast<hipStream_t>(stream)>>>(y, bias, n_rows, dim);
+  SNET_CHECK_LAUNCH("snet_add_row_bias");
+  return 0;
+}
 extern "C" int snet_add_inplace(float *y, const float *x, int64_t n, void *stream) {
   if (n <= 0) return 0;
   add_kernel<<<grid_for(n), 256, 0, static_cast<hipStream_t>(stream)>>>(y, x, n);

@@ -17,16 +17,17 @@ def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog='python -m sevennet_amd.deploy', description=__doc__.split('\n\n')[1])
     ap.add_argument('checkpoint', help='reference checkpoint (.pth with config + model_state_dict)')
     ap.add_argument('-o', '--output', default='deployed_model.snet')
+    ap.add_argument('-m', '--modal', default=None, help='fidelity channel of a multi-modal checkpoint (sevenn get_model -m)')
     a = ap.parse_args(argv)
     from .calculator import load_reference_checkpoint
     from .model_file import write_model_file
     from .model_spec import build_model_spec
     cfg, sd = load_reference_checkpoint(a.checkpoint)
-    if cfg.get('use_modality'):
-        print('multi-modal checkpoints are not supported yet', file=sys.stderr)
+    if cfg.get('use_modality') and a.modal is None:
+        print(f"Modal is not given. It has: {list((cfg.get('_modal_map') or {}).keys())}", file=sys.stderr)
         return 2
     out = a.output if a.output.endswith('.snet') else a.output + '.snet'
-    write_model_file(out, cfg, sd)
+    write_model_file(out, cfg, sd, modal=a.modal)
     sp = build_model_spec(cfg)
     tags = ', '.join(ls.conv.tag for ls in sp.layers)
     print(f'wrote {out}: {len(sp.layers)} interaction layers, cutoff {sp.cutoff}, tensor-product shapes [{tags}]')

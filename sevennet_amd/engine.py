@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .model_spec import (ACT_CST, ACT_ID, LinearSpec, ModelSpec, build_model_spec,
+from .model_spec import (ACT_CST, ACT_ID, LinearSpec, ModelSpec, build_model_spec, linear_modal_bias,
                          linear_weight_matrices)
 
 
@@ -129,9 +129,11 @@ class _Linear:
     """Device weights of one LinearSpec (per-GEMM [K,N] and [N,K] copies) and its launch plan:
     per-irrep GEMMs that write distinct output blocks are grouped into one launch."""
 
-    def __init__(self, spec: LinearSpec, flat: np.ndarray, dev, split: bool = True):
+    def __init__(self, spec: LinearSpec, flat: np.ndarray, dev, split: bool = True, modal_idx: int = -1):
         self.spec = spec
         self.split = split
+        b = linear_modal_bias(spec, flat, modal_idx)   # multi-modal linear: constant row bias for this channel
+        self.bias = None if b is None else torch.from_numpy(b).to(dev)
         mats = linear_weight_matrices(spec, flat)
         if split:  # bf16 x 6 split-precision MFMA: weights live on the device as packed B fragments
             self.w = [_pack_split(m, dev) for m in mats]
@@ -192,10 +194,12 @@ class _Span:
 
 class HipForceEngine:
     def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6',
-                 linear_mode: str = 'bf16x6', fuse_conv: bool = False):
+                 linear_mode: str = 'bf16x6', fuse_conv: bool = False, modal=None):
         """mlp_mode / linear_mode: 'bf16x6' (split-precision MFMA, fp32-class accuracy, default) or
         'fp32' (exact fp32 MFMA) for the fused radial MLP / the node-level equivariant linears.
         fuse_conv: run the radial MLP's last layer inside the forward tensor-product kernels where the
+        modal: fidelity channel (name from config['_modal_map'] or index) of a multi-modal model; the
+        one-hot inputs of its linears become constant biases, shift/scale rows are selected at load.
         shape has such a kernel (needs mlp_mode 'bf16x6').  Off by default: parity-tested, but at
         8.3 ms per SevenNet-0 middle layer it is still slower than the separate kernels (2.4 + 2.6 ms);
         DESIGN.md section 7 has the analysis."""
@@ -210,6 +214,7 @@ class HipForceEngine:
         self.dev = torch.device(device)
         self.spec: ModelSpec = build_model_spec(config)
         sp = self.spec
+        self.modal_idx = mi = sp.modal_index(modal)
         shapes = sp.param_shapes()
         sd = {}
         for k, shp in shapes.items():
@@ -226,15 +231,17 @@ class HipForceEngine:
         with torch.cuda.device(self.dev):
             emb = linear_weight_matrices(sp.embed, sd[sp.embed.name])
             assert len(emb) == 1
-            self.embed_table = torch.from_numpy(emb[0]).to(self.dev)  # [n_species, dim0]
+            eb = linear_modal_bias(sp.embed, sd[sp.embed.name], mi)
+            table = emb[0] if eb is None else emb[0] + eb[None, :]
+            self.embed_table = torch.from_numpy(np.ascontiguousarray(table, np.float32)).to(self.dev)  # [n_species, dim0]
             self.layers = []
             split = linear_mode == 'bf16x6'
             for ls in sp.layers:
                 L = type('L', (), {})()
                 L.spec = ls
-                L.sc = _Linear(ls.sc, sd[ls.sc.name], self.dev, split) if ls.sc is not None else None
-                L.si1 = _Linear(ls.si1, sd[ls.si1.name], self.dev, split)
-                L.si2 = _Linear(ls.si2, sd[ls.si2.name], self.dev, split)
+                L.sc = _Linear(ls.sc, sd[ls.sc.name], self.dev, split, mi) if ls.sc is not None else None
+                L.si1 = _Linear(ls.si1, sd[ls.si1.name], self.dev, split, mi)
+                L.si2 = _Linear(ls.si2, sd[ls.si2.name], self.dev, split, mi)
                 L.mlp_w, L.mlp_wt = [], []
                 for i in range(len(ls.mlp_dims) - 1):
                     w = sd[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] / np.sqrt(ls.mlp_dims[i])
@@ -267,13 +274,13 @@ class HipForceEngine:
                                            ACT_CST[inv_act[s.act]])
                 L.gate_segs = segs
                 self.layers.append(L)
-            self.ro1 = _Linear(sp.readout1, sd[sp.readout1.name], self.dev, split)
-            self.ro2 = _Linear(sp.readout2, sd[sp.readout2.name], self.dev, split)
-            n_sc = shapes['rescale_atomic_energy.scale'][0]
-            self.n_scale = n_sc
-            self.scale = torch.tensor(sd['rescale_atomic_energy.scale'], dtype=torch.float32, device=self.dev)
-            self.shift = torch.tensor(sd['rescale_atomic_energy.shift'], dtype=torch.float32, device=self.dev)
-            self.scale0 = float(sd['rescale_atomic_energy.scale'][0])
+            self.ro1 = _Linear(sp.readout1, sd[sp.readout1.name], self.dev, split, mi)
+            self.ro2 = _Linear(sp.readout2, sd[sp.readout2.name], self.dev, split, mi)
+            sc_v, sh_v = sp.rescale_vectors(sd, mi)
+            self.n_scale = len(sc_v)
+            self.scale = torch.tensor(sc_v, dtype=torch.float32, device=self.dev)
+            self.shift = torch.tensor(sh_v, dtype=torch.float32, device=self.dev)
+            self.scale0 = float(sc_v[0])
         self.act_radial = ACT_ID[sp.act_radial]
         self.act_cst = ACT_CST[sp.act_radial]
         self.needs_species_rows = any(ls.sc is not None and ls.sc.n_species for ls in sp.layers)
@@ -323,6 +330,8 @@ class HipForceEngine:
         for off, ln in sp.zero_out:
             y[:, off:off + ln].zero_()
         self._run_groups(lin.groups_fwd, x, y, n, sp.dim_in, sp.dim_out, g)
+        if lin.bias is not None and n > 0:
+            _lib.check(self.lib.snet_add_row_bias(_ptr(y), _ptr(lin.bias), n, sp.dim_out, _stream()), 'snet_add_row_bias')
         return y
 
     def _linear_T(self, lin: _Linear, gy, n, g: Graph, out=None, accumulate=False):

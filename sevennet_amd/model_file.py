@@ -7,7 +7,7 @@ all tables of `ModelSpec` plus the weights with every normalisation already fold
 host needs no Python, no torch and no e3nn.
 
 Layout (all ints int32, floats float32 unless noted):
-    magic 'SNETMDL1'
+    magic 'SNETMDL2'
     header  : n_species n_layers lmax normalize n_basis cutoff_kind poly_p act_radial n_scale d0
               cutoff(f32) cutoff_on(f32) act_cst(f32)
     coeffs[n_basis]  embed[n_species*d0]  scale[n_scale]  shift[n_scale]
@@ -27,9 +27,9 @@ from typing import Dict
 
 import numpy as np
 
-from .model_spec import ACT_CST, ACT_ID, LinearSpec, build_model_spec, linear_weight_matrices
+from .model_spec import ACT_CST, ACT_ID, LinearSpec, build_model_spec, linear_modal_bias, linear_weight_matrices
 
-MAGIC = b'SNETMDL1'
+MAGIC = b'SNETMDL2'
 
 _SYMBOLS = ('X H He Li Be B C N O F Ne Na Mg Al Si P S Cl Ar K Ca Sc Ti V Cr Mn Fe Co Ni Cu Zn Ga Ge As Se Br Kr Rb Sr '
             'Y Zr Nb Mo Tc Ru Rh Pd Ag Cd In Sn Sb Te I Xe Cs Ba La Ce Pr Nd Pm Sm Eu Gd Tb Dy Ho Er Tm Yb Lu Hf Ta W '
@@ -60,13 +60,14 @@ def _arr(a):
     return np.ascontiguousarray(a, dtype='<f4').tobytes()
 
 
-def _write_linear(spec: LinearSpec, flat) -> bytes:
+def _write_linear(spec: LinearSpec, flat, modal_idx: int = -1) -> bytes:
     """dim_in dim_out n_species n_blocks n_zero n_zero_in
     | blocks[l in_off mul_in out_off mul_out species accumulate]
     | zero[off len] (output columns no block writes) | zero_in[off len] (input columns no block reads)
-    | weights of every block, [K,N] row-major with alpha folded"""
+    | weights of every block, [K,N] row-major with alpha folded
+    | has_bias, then bias[dim_out] if 1 (multi-modal linear, fidelity channel fixed at deploy time)"""
     if spec is None:
-        return _i(0, 0, 0, 0, 0, 0)
+        return _i(0, 0, 0, 0, 0, 0) + _i(0)
     mats = linear_weight_matrices(spec, flat)
     fed = {b.in_off for b in spec.blocks}
     zero_in = [(off, m * (2 * l + 1)) for off, (m, l, _) in zip(spec.irreps_in.offsets(), spec.irreps_in)
@@ -78,25 +79,36 @@ def _write_linear(spec: LinearSpec, flat) -> bytes:
         out.append(_i(off, ln))
     for m in mats:
         out.append(_arr(m))
+    bias = linear_modal_bias(spec, flat, modal_idx)
+    out.append(_i(0 if bias is None else 1))
+    if bias is not None:
+        out.append(_arr(bias))
     return b''.join(out)
 
 
-def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray]) -> None:
+def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray], modal=None) -> None:
+    """modal: fidelity channel of a multi-modal model, fixed in the file like the reference's
+    `prepare_modal_deploy` (sevenn/scripts/deploy.py:42-47)."""
     sp = build_model_spec(config)
+    mi = sp.modal_index(modal)
     sd = {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, 'detach') else v, dtype=np.float64)
           for k, v in state_dict.items()}
     for k, shp in sp.param_shapes().items():
         if k not in sd:
             raise KeyError(f'state_dict is missing {k}')
         sd[k] = sd[k].reshape(shp)
-    n_scale = sp.param_shapes()['rescale_atomic_energy.scale'][0]
+    scale_v, shift_v = sp.rescale_vectors(sd, mi)
+    n_scale = len(scale_v)
     embed = linear_weight_matrices(sp.embed, sd[sp.embed.name])[0]
+    eb = linear_modal_bias(sp.embed, sd[sp.embed.name], mi)
+    if eb is not None:
+        embed = embed + eb[None, :]
     out = [MAGIC,
            _i(sp.num_species, len(sp.layers), sp.lmax_edge, int(sp.normalize_sph), sp.n_basis, sp.cutoff_kind,
               sp.cutoff_p, ACT_ID[sp.act_radial], n_scale, sp.embed.dim_out),
            _f(sp.cutoff, sp.cutoff_on, ACT_CST[sp.act_radial]),
            _arr(sd['edge_embedding.basis_function.coeffs']), _arr(embed),
-           _arr(sd['rescale_atomic_energy.scale']), _arr(sd['rescale_atomic_energy.shift'])]
+           _arr(scale_v), _arr(shift_v)]
     inv_act = {v: k for k, v in ACT_ID.items()}
     for ls in sp.layers:
         d = ls.mlp_dims
@@ -110,13 +122,13 @@ def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray])
         for i in range(3):
             out.append(_arr(sd[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] / np.sqrt(d[i])))
         out.append(_write_linear(ls.sc, sd[ls.sc.name] if ls.sc is not None else None))
-        out.append(_write_linear(ls.si1, sd[ls.si1.name]))
-        out.append(_write_linear(ls.si2, sd[ls.si2.name]))
+        out.append(_write_linear(ls.si1, sd[ls.si1.name], mi))
+        out.append(_write_linear(ls.si2, sd[ls.si2.name], mi))
         out.append(_i(len(ls.gate.segs)))
         for s in ls.gate.segs:
             out.append(_i(s.kind, s.in_off, s.out_off, s.mul, s.l, s.gate_off, s.act))
             out.append(_f(ACT_CST[inv_act[s.act]]))
-    out.append(_write_linear(sp.readout1, sd[sp.readout1.name]))
+    out.append(_write_linear(sp.readout1, sd[sp.readout1.name], mi))
     out.append(_write_linear(sp.readout2, sd[sp.readout2.name]))
     meta = {'chemical_symbols_to_index': ' '.join(species_symbols(config, sp.num_species)),
             'cutoff': repr(float(sp.cutoff)), 'num_species': str(sp.num_species),

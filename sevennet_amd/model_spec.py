@@ -64,6 +64,11 @@ class LinearSpec:
     zero_out: List[Tuple[int, int]]  # (offset, length) of output blocks nobody writes
     n_species: int = 0         # >0: FullyConnectedTensorProduct with a one-hot operand
     numel: int = 0
+    # multi-modal linear (sevenn/nn/linear.py:66-92): n_modal extra 0e inputs carrying a one-hot of the
+    # fidelity channel.  For a fixed channel they are a constant bias on the 0e outputs:
+    # (out_off, mul_out, w_off, alpha) per 0e output block, weights [n_modal, mul_out] row-major
+    n_modal: int = 0
+    modal_bias: List[Tuple[int, int, int, float]] = field(default_factory=list)
 
     @property
     def dim_in(self):
@@ -74,9 +79,13 @@ class LinearSpec:
         return self.irreps_out.dim
 
 
-def make_linear(name: str, irreps_in: Irreps, irreps_out: Irreps, n_species: int = 0) -> LinearSpec:
+def make_linear(name: str, irreps_in: Irreps, irreps_out: Irreps, n_species: int = 0, n_modal: int = 0) -> LinearSpec:
     """o3.Linear (n_species=0) or FCTP(x, n_species x 0e) -> per-irrep GEMM list.
-    Normalisation: 1/sqrt(total fan-in of the output block)."""
+    Normalisation: 1/sqrt(total fan-in of the output block).
+    n_modal > 0: the reference appends `n_modal x 0e` to the input irreps (a separate last block), so
+    every 0e output block gets n_modal more fan-in and one more weight block at the END of the flat
+    weight (e3nn orders blocks in-major)."""
+    assert not (n_species and n_modal)
     ns = max(n_species, 1)
     in_off, out_off = irreps_in.offsets(), irreps_out.offsets()
     pairs = [(i, j) for i, (_, li, pi) in enumerate(irreps_in)
@@ -84,6 +93,9 @@ def make_linear(name: str, irreps_in: Irreps, irreps_out: Irreps, n_species: int
     fan = [0] * len(irreps_out)
     for i, j in pairs:
         fan[j] += irreps_in[i][0] * ns
+    modal_j = [j for j, (_, l, p) in enumerate(irreps_out) if (l, p) == (0, 1)] if n_modal else []
+    for j in modal_j:
+        fan[j] += n_modal
     blocks, seen, w_off = [], set(), 0
     for i, j in pairs:
         mi, l, _ = irreps_in[i]
@@ -93,9 +105,27 @@ def make_linear(name: str, irreps_in: Irreps, irreps_out: Irreps, n_species: int
                                     accumulate=(j in seen), species=(s if n_species else -1)))
         seen.add(j)
         w_off += mi * ns * mo
+    modal_bias = []
+    for j in modal_j:
+        mo = irreps_out[j][0]
+        modal_bias.append((out_off[j], mo, w_off, 1.0 / math.sqrt(fan[j])))
+        seen.add(j)
+        w_off += n_modal * mo
     zero = [(out_off[j], irreps_out[j][0] * (2 * irreps_out[j][1] + 1))
             for j in range(len(irreps_out)) if j not in seen]
-    return LinearSpec(name, irreps_in, irreps_out, blocks, zero, n_species, w_off)
+    return LinearSpec(name, irreps_in, irreps_out, blocks, zero, n_species, w_off, n_modal, modal_bias)
+
+
+def linear_modal_bias(spec: LinearSpec, flat: np.ndarray, modal_idx: int):
+    """Constant the modal one-hot contributes to every output row for fidelity channel `modal_idx`
+    ([dim_out] float32), or None for a linear without modal inputs."""
+    if not spec.n_modal:
+        return None
+    flat = np.asarray(flat, dtype=np.float64).reshape(-1)
+    bias = np.zeros(spec.dim_out, np.float64)
+    for off, mo, w_off, alpha in spec.modal_bias:
+        bias[off:off + mo] = flat[w_off:w_off + spec.n_modal * mo].reshape(spec.n_modal, mo)[modal_idx] * alpha
+    return bias.astype(np.float32)
 
 
 def linear_weight_matrices(spec: LinearSpec, flat: np.ndarray):
@@ -262,6 +292,7 @@ class ModelSpec:
     readout1: LinearSpec
     readout2: LinearSpec
     type_map: Dict[int, int] = field(default_factory=dict)
+    n_modal: int = 0
 
     def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
         s: Dict[str, Tuple[int, ...]] = {}
@@ -277,10 +308,39 @@ class ModelSpec:
             s[ls.si2.name] = (ls.si2.numel,)
         s[self.readout1.name] = (self.readout1.numel,)
         s[self.readout2.name] = (self.readout2.numel,)
+        if self.n_modal:  # ModalWiseRescale (scale.py:196-363): per species, optionally per modal
+            ns = self.num_species
+            s['rescale_atomic_energy.shift'] = (self.n_modal, ns) if self.config.get('use_modal_wise_shift') else (ns,)
+            s['rescale_atomic_energy.scale'] = (self.n_modal, ns) if self.config.get('use_modal_wise_scale') else (ns,)
+            return s
         n = max(np.asarray(self.config['shift']).size, np.asarray(self.config['scale']).size)
         s['rescale_atomic_energy.shift'] = (n,)
         s['rescale_atomic_energy.scale'] = (n,)
         return s
+
+    def modal_index(self, modal) -> int:
+        """fidelity channel index from its name (config['_modal_map']) or an int; -1 for single-modal models"""
+        if not self.n_modal:
+            return -1
+        if modal is None:
+            raise ValueError('multi-modal model: a modal must be given '
+                             f"(known: {list((self.config.get('_modal_map') or {}).keys())})")
+        idx = int((self.config.get('_modal_map') or {})[modal]) if isinstance(modal, str) else int(modal)
+        if not 0 <= idx < self.n_modal:
+            raise ValueError(f'modal index {idx} out of range (model has {self.n_modal})')
+        return idx
+
+    def rescale_vectors(self, sd, modal_idx: int):
+        """(scale, shift) as flat float arrays for the chosen fidelity channel: [1] global or [n_species]"""
+        sc = np.asarray(sd['rescale_atomic_energy.scale'], np.float64)
+        sh = np.asarray(sd['rescale_atomic_energy.shift'], np.float64)
+        if self.n_modal:
+            sc = sc.reshape(self.param_shapes()['rescale_atomic_energy.scale'])
+            sh = sh.reshape(self.param_shapes()['rescale_atomic_energy.shift'])
+            sc = sc[modal_idx] if sc.ndim == 2 else sc
+            sh = sh[modal_idx] if sh.ndim == 2 else sh
+        n = max(sc.size, sh.size)
+        return np.broadcast_to(sc.reshape(-1), (n,)).copy(), np.broadcast_to(sh.reshape(-1), (n,)).copy()
 
     def num_weights(self) -> int:
         return sum(int(np.prod(v)) for k, v in self.param_shapes().items()
@@ -296,8 +356,15 @@ def build_model_spec(config: dict) -> ModelSpec:
     cfg.update(config)
     if cfg.get('use_bias_in_linear'):
         raise NotImplementedError('use_bias_in_linear=True is not supported by the HIP engine')
-    if cfg.get('use_modality') or cfg.get('readout_as_fcn'):
-        raise NotImplementedError('modal / readout_as_fcn models are not supported by the HIP engine yet')
+    if cfg.get('readout_as_fcn'):
+        raise NotImplementedError('readout_as_fcn models are not supported by the HIP engine yet')
+    n_modal = int(cfg.get('_number_of_modalities', 0)) if cfg.get('use_modality') else 0
+    if cfg.get('use_modality') and n_modal < 2:
+        raise ValueError('use_modality needs _number_of_modalities >= 2')
+    m_embed = n_modal if cfg.get('use_modal_node_embedding') else 0   # model_build.py:213-230
+    m_si1 = n_modal if cfg.get('use_modal_self_inter_intro') else 0
+    m_si2 = n_modal if cfg.get('use_modal_self_inter_outro') else 0
+    m_out = n_modal if cfg.get('use_modal_output_block') else 0
     ns = int(cfg.get('_number_of_species') or cfg.get('num_species') or len(cfg['chemical_species']))
     ch = int(cfg['channel'])
     L = int(cfg['num_convolution_layer'])
@@ -323,7 +390,7 @@ def build_model_spec(config: dict) -> ModelSpec:
     hidden = list(cfg['weight_nn_hidden_neurons'])
 
     irreps_x = Irreps(f'{ch}x0e') if manual is False else manual[0]
-    embed = make_linear('onehot_to_feature_x.linear.weight', Irreps(f'{ns}x0e'), irreps_x)
+    embed = make_linear('onehot_to_feature_x.linear.weight', Irreps(f'{ns}x0e'), irreps_x, n_modal=m_embed)
     layers = []
     for t in range(L):
         parity_mode = 'full'
@@ -345,9 +412,9 @@ def build_model_spec(config: dict) -> ModelSpec:
             raise ValueError(f'Unknown self_connection_type found: {sc_types[t]}')
         layers.append(LayerSpec(
             t, irreps_x, irreps_out, sc,
-            make_linear(f'{t}_self_interaction_1.linear.weight', irreps_x, irreps_x),
+            make_linear(f'{t}_self_interaction_1.linear.weight', irreps_x, irreps_x, n_modal=m_si1),
             conv, [n_basis] + hidden + [conv.weight_numel],
-            make_linear(f'{t}_self_interaction_2.linear.weight', irreps_out_tp, gate.irreps_in),
+            make_linear(f'{t}_self_interaction_2.linear.weight', irreps_out_tp, gate.irreps_in, n_modal=m_si2),
             gate, float(denom[t])))
         irreps_x = irreps_out
     hid = Irreps([((ch if legacy else irreps_x.dim) // 2, 0, 1)])
@@ -356,9 +423,9 @@ def build_model_spec(config: dict) -> ModelSpec:
         cfg, float(cfg['cutoff']), ns, lmax_edge, bool(cfg['_normalize_sph']), irreps_sh, n_basis,
         ckind, int(cf.get('poly_cut_p_value', 6)), float(cf.get('cutoff_on', 0.0)), cfg['act_radial'],
         embed, layers,
-        make_linear('reduce_input_to_hidden.linear.weight', irreps_x, hid),
+        make_linear('reduce_input_to_hidden.linear.weight', irreps_x, hid, n_modal=m_out),
         make_linear('reduce_hidden_to_energy.linear.weight', hid, Irreps('1x0e')),
-        {int(k): int(v) for k, v in tm.items()})
+        {int(k): int(v) for k, v in tm.items()}, n_modal)
 
 
 # --------------------------------------------------------------------------- #

@@ -27,7 +27,7 @@ class _DevRows:
 
 
 class NativeModel:
-    def __init__(self, model, state_dict: Optional[Dict[str, np.ndarray]] = None, device='cuda:0'):
+    def __init__(self, model, state_dict: Optional[Dict[str, np.ndarray]] = None, device='cuda:0', modal=None):
         """model: path of a `.snet` file, or a reference config dict (then `state_dict` is required and
         the file is written to a temporary location first)."""
         self.lib = _lib.load()
@@ -41,7 +41,7 @@ class NativeModel:
                     raise ValueError('state_dict is required with a config dict')
                 with tempfile.TemporaryDirectory() as td:
                     path = os.path.join(td, 'model.snet')
-                    write_model_file(path, model, state_dict)
+                    write_model_file(path, model, state_dict, modal=modal)
                     _lib.check(self.lib.snet_model_load(path.encode(), C.byref(self.handle)), 'snet_model_load')
             else:
                 _lib.check(self.lib.snet_model_load(os.fspath(model).encode(), C.byref(self.handle)), 'snet_model_load')

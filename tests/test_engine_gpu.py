@@ -338,3 +338,34 @@ def test_undirected_pair_map_and_shared_radial_weights(case):
         assert abs(float(a['energy'].cpu()) - float(bb['energy'].cpu())) <= 1e-6 * abs(float(bb['energy'].cpu()))
         _close(a['forces'], bb['forces'], 2e-6, 1e-8, 'forces (pair-shared radial weights)')
         _close(a['dE_dr'], bb['dE_dr'], 2e-6, 1e-8, 'dE_dr (pair-shared radial weights)')
+
+
+@pytest.mark.parametrize('modal', ['x1', 'x2'])
+def test_multi_modal_model_vs_oracle(modal):
+    """multi-fidelity model (all four modal-patched linears, modal-wise shift): Python host and native
+    sequencer against the oracle's literal one-hot concatenation, for both channels"""
+    from sevennet_amd.engine import HipForceEngine, build_graph
+    from sevennet_amd.native_model import NativeModel
+    from sevennet_amd.shapes import unit_test_config
+    from sevennet_amd.synthetic import random_state_dict
+    from oracle.model import OracleModel
+    cfg = unit_test_config(use_modality=True, _number_of_modalities=2, _modal_map={'x1': 0, 'x2': 1},
+                           use_modal_node_embedding=True, use_modal_self_inter_intro=True,
+                           use_modal_self_inter_outro=True, use_modal_output_block=True,
+                           use_modal_wise_shift=True, use_modal_wise_scale=False)
+    sd = random_state_dict(cfg, seed=12)
+    sd['rescale_atomic_energy.shift'] = np.array([[0.1, -0.2, 0.3, 0.0], [1.5, 2.5, -3.5, 0.5]], np.float32)
+    types, pos, cell, ei, ev = synthetic_system((2, 2, 2), sigma=0.08, seed=5, cutoff=4.0, n_species=4)
+    eng = HipForceEngine(cfg, sd, device='cuda:0', modal=modal)
+    g = build_graph(types, ei, ev, device='cuda:0', num_species=eng.spec.num_species)
+    out = eng.compute(g, want_atomic_virial=True, keep=True)
+    nat = NativeModel(cfg, sd, modal=modal).compute(g, want_atomic_virial=True)
+    torch.cuda.synchronize()
+    ref = OracleModel(cfg, sd, dtype=torch.float64, modal=modal).forward(types, ei, ev, keep=True)
+    _compare(eng, out, ref, len(types))
+    for k in ('energy', 'atomic_energy', 'dE_dr', 'forces', 'virial'):
+        assert torch.equal(out[k], nat[k]), k
+    other = OracleModel(cfg, sd, dtype=torch.float64, modal='x2' if modal == 'x1' else 'x1').forward(types, ei, ev)
+    assert abs(float(other['energy']) - float(ref['energy'])) > 1e-3   # the channels really differ
+    with pytest.raises(ValueError, match='modal'):
+        HipForceEngine(cfg, sd, device='cuda:0')

@@ -42,6 +42,70 @@ def test_num_params_pins(cf, ref):
     assert build_model_spec(cfg).num_weights() == ref
 
 
+_MODAL = dict(use_modality=True, _number_of_modalities=2, _modal_map={'x1': 0, 'x2': 1}, use_modal_node_embedding=False,
+              use_modal_self_inter_intro=False, use_modal_self_inter_outro=False, use_modal_output_block=False,
+              use_modal_wise_shift=False, use_modal_wise_scale=False)
+
+
+@pytest.mark.parametrize('cf,ref', [
+    ({}, 20642), ({'use_modal_node_embedding': True}, 20642 + 8), ({'use_modal_self_inter_intro': True}, 20642 + 2 * 4 * 3),
+    ({'use_modal_self_inter_outro': True}, 20642 + 2 * (12 + 20 + 4)), ({'use_modal_output_block': True}, 20642 + 2 * 4 // 2)])
+def test_modal_num_params_pins(cf, ref):
+    """multi-modal variants, tests/unit_tests/test_model.py:185-212 of the reference"""
+    from oracle.model import OracleModel
+    from sevennet_amd.model_spec import build_model_spec
+    from sevennet_amd.shapes import unit_test_config
+    cfg = unit_test_config(**dict(_MODAL, **cf))
+    assert OracleModel(cfg, None, modal='x1').num_weights() == ref
+    assert build_model_spec(cfg).num_weights() == ref
+
+
+def test_modal_onehot_is_a_channel_dependent_bias():
+    """oracle (literal one-hot concatenation, linear.py:72-92) vs the product's load-time folding
+    (bias rows + rescaled alpha, model_spec.linear_modal_bias): same linear map for each channel;
+    modal-wise shift picks its row (scale.py:341-363); a missing / unknown modal is refused"""
+    import torch
+    from oracle.e3 import Irreps as OIrreps
+    from oracle.model import OracleModel, linear_apply
+    from sevennet_amd.irreps import Irreps
+    from sevennet_amd.model_spec import build_model_spec, linear_modal_bias, linear_weight_matrices, make_linear
+    from sevennet_amd.shapes import unit_test_config
+    from sevennet_amd.synthetic import random_state_dict
+    rng = np.random.default_rng(0)
+    irr_in, irr_out, M = '4x0e+3x1o+2x0e', '5x0e+2x1o+1x0o', 3
+    spec = make_linear('w', Irreps(irr_in), Irreps(irr_out), n_modal=M)
+    flat = rng.standard_normal(spec.numel)
+    x = torch.as_tensor(rng.standard_normal((7, Irreps(irr_in).dim)))
+    for m in range(M):
+        oh = torch.zeros(7, M, dtype=torch.float64)
+        oh[:, m] = 1.0
+        ref = linear_apply(torch.cat([x, oh], 1), OIrreps(irr_in) + OIrreps(f'{M}x0e'), OIrreps(irr_out), torch.as_tensor(flat))
+        from helpers import irmul_to_mulir  # noqa: F401  (layouts: oracle mul_ir, product ir_mul)
+        got = np.zeros((7, spec.dim_out))
+        xin = x.numpy()
+        from sevennet_amd.irreps import mulir_to_irmul_index
+        xi = xin[:, mulir_to_irmul_index(Irreps(irr_in))]
+        for b, w in zip(spec.blocks, linear_weight_matrices(spec, flat)):
+            d = 2 * b.l + 1
+            blk = xi[:, b.in_off:b.in_off + d * b.mul_in].reshape(7, d, b.mul_in) @ w.astype(np.float64)
+            got[:, b.out_off:b.out_off + d * b.mul_out] += blk.reshape(7, -1)
+        got += linear_modal_bias(spec, flat, m)[None, :]
+        ref_im = ref.numpy()[:, mulir_to_irmul_index(Irreps(irr_out))]
+        assert np.abs(got - ref_im).max() < 1e-6
+    cfg = unit_test_config(**dict(_MODAL, use_modal_self_inter_intro=True, use_modal_wise_shift=True, shift=0.0, scale=1.0))
+    sd = random_state_dict(cfg, seed=2)
+    sd['rescale_atomic_energy.shift'] = np.array([[0.0, 1.0, 2.0, 3.0], [10.0, 11.0, 12.0, 13.0]], np.float32)
+    sp = build_model_spec(cfg)
+    sc, sh = sp.rescale_vectors(sd, sp.modal_index('x2'))
+    assert np.allclose(sh, [10, 11, 12, 13]) and np.allclose(sc, 1.0)
+    with pytest.raises(ValueError):
+        sp.modal_index(None)
+    with pytest.raises(KeyError):
+        sp.modal_index('nope')
+    with pytest.raises(ValueError):
+        OracleModel(cfg, sd)
+
+
 def test_cp0_state_dict_shapes():
     """every tensor of the reference's test checkpoint has the shape the engine expects"""
     import json
