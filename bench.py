@@ -42,7 +42,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--reps', type=int, default=23, help='diamond cells per axis (23 -> 97 336 atoms)')
-    ap.add_argument('--model', default='sevennet_0', choices=['sevennet_0', 'sevennet_l3i5'])
+    ap.add_argument('--model', default='sevennet_0', choices=['sevennet_0', 'sevennet_l3i5', 'sevennet_mf_ompa'])
     ap.add_argument('--mlp-mode', default='bf16x6', choices=['bf16x6', 'fp32'],
                     help='radial-MLP MFMA mode: bf16 x6 split products (fp32-class accuracy) or exact fp32 MFMA')
     ap.add_argument('--host', default='python', choices=['python', 'native'],
@@ -56,8 +56,16 @@ def parse():
 
 
 def model_config(name):
-    from sevennet_amd.model_spec import sevennet_0_config, sevennet_l3i5_config
-    return {'sevennet_0': sevennet_0_config, 'sevennet_l3i5': sevennet_l3i5_config}[name]()
+    from sevennet_amd.model_spec import sevennet_0_config, sevennet_l3i5_config, sevennet_mf_ompa_config
+    return {'sevennet_0': sevennet_0_config, 'sevennet_l3i5': sevennet_l3i5_config,
+            'sevennet_mf_ompa': sevennet_mf_ompa_config}[name]()
+
+
+def species_of(cfg, n_atoms):
+    """single species, or (119-species models) a seeded 4-species decoration Z in {3, 8, 14, 22}"""
+    if int(cfg.get('_number_of_species', 1)) < 23:
+        return np.zeros(n_atoms, np.int64)
+    return np.random.default_rng(4).choice(np.array([3, 8, 14, 22]), size=n_atoms).astype(np.int64)
 
 
 def kernel_model(ls, n_nodes, n_edges):
@@ -85,8 +93,8 @@ def cpu_baseline(cfg, sd, reps):
     from sevennet_amd.neighbor import diamond_cubic, neighbor_list
     pos, cell = diamond_cubic(5.431, (reps,) * 3, 0.05, 2)
     ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
-    types = np.zeros(len(pos), np.int64)
-    m = OracleModel(cfg, sd, dtype=torch.float32)
+    types = species_of(cfg, len(pos))
+    m = OracleModel(cfg, sd, dtype=torch.float32, modal='mpa' if cfg.get('use_modality') else None)
     best = None
     default_threads = torch.get_num_threads()
     # eager PyTorch on many small ops does not scale to every core: try the default and 32 threads
@@ -133,7 +141,8 @@ def main():
 
     cfg = model_config(a.model)
     sd = random_state_dict(cfg, seed=0)
-    eng = HipForceEngine(cfg, sd, device=dev, mlp_mode=a.mlp_mode, fuse_conv=a.fuse_conv)
+    modal = 'mpa' if cfg.get('use_modality') else None
+    eng = HipForceEngine(cfg, sd, device=dev, mlp_mode=a.mlp_mode, fuse_conv=a.fuse_conv, modal=modal)
 
     pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
     n_atoms = len(pos)
@@ -141,13 +150,14 @@ def main():
     halo = None
     if world == 1:
         ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
-        types = np.zeros(n_atoms, np.int64)
-        graph = build_graph(types, ei, ev, device=dev)
+        types = species_of(cfg, n_atoms)
+        graph = build_graph(types, ei, ev, device=dev, num_species=eng.spec.num_species)
         n_edges_total = graph.n_edges
     else:
         from sevennet_amd.parallel import HaloExchange, build_brick_graph
-        bg = build_brick_graph(pos, cell, np.zeros(n_atoms, np.int64), cfg['cutoff'], world, rank)
-        graph = build_graph(bg.types, bg.edge_index, bg.edge_vec, n_local=bg.n_local, device=dev)
+        bg = build_brick_graph(pos, cell, species_of(cfg, n_atoms), cfg['cutoff'], world, rank)
+        graph = build_graph(bg.types, bg.edge_index, bg.edge_vec, n_local=bg.n_local, device=dev,
+                            num_species=eng.spec.num_species)
         halo = HaloExchange(bg.send_lists, bg.recv_counts, dev)
         ne = torch.tensor([graph.n_edges], device=dev, dtype=torch.int64)
         dist.all_reduce(ne)
@@ -159,7 +169,7 @@ def main():
         if a.mlp_mode != 'bf16x6':
             raise SystemExit('--host native always uses the bf16x6 radial MLP')
         from sevennet_amd.native_model import NativeModel
-        nat = NativeModel(cfg, sd, device=dev)
+        nat = NativeModel(cfg, sd, device=dev, modal=modal)
         nat.set_halo(halo)
 
     def step():

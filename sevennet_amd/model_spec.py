@@ -448,6 +448,24 @@ def sevennet_0_config(num_species: int = 1, conv_denominator: float = 28.0) -> d
         _normalize_sph=False, _number_of_species=num_species, shift=0.0, scale=1.0, version='0.9.5')
 
 
+def sevennet_mf_ompa_config(conv_denominator: float = 46.0) -> dict:
+    """sevenn/presets/mf_ompa_fine_tune.yaml:4-45,83-99: O(3) parity, lmax 3, XPLOR 5.5/6.0, `nequip`
+    self-connection over the universal 119-species table, two fidelity channels (mpa, omat24) feeding
+    self-interaction 1/2 and the output block, modal-wise shift."""
+    return dict(
+        cutoff=6.0, channel=128, is_parity=True, lmax=3, num_convolution_layer=5,
+        irreps_manual=['128x0e', '128x0e+64x1o+32x2e+32x3o', '128x0e+64x1o+64x1e+32x2o+32x2e+32x3o+32x3e',
+                       '128x0o+128x0e+64x1o+64x1e+32x2o+32x2e+32x3o+32x3e', '128x0e+64x1o+32x2e+32x3o', '128x0e'],
+        weight_nn_hidden_neurons=[64, 64],
+        radial_basis={'radial_basis_name': 'bessel', 'bessel_basis_num': 8},
+        cutoff_function={'cutoff_function_name': 'XPLOR', 'cutoff_on': 5.5},
+        conv_denominator=conv_denominator, self_connection_type='nequip',
+        _normalize_sph=True, _number_of_species=119, shift=0.0, scale=1.0, version='0.11.0',
+        use_modality=True, _number_of_modalities=2, _modal_map={'mpa': 0, 'omat24': 1},
+        use_modal_node_embedding=False, use_modal_self_inter_intro=True, use_modal_self_inter_outro=True,
+        use_modal_output_block=True, use_modal_wise_shift=True, use_modal_wise_scale=False)
+
+
 def sevennet_l3i5_config(num_species: int = 1, conv_denominator: float = 28.0) -> dict:
     """sevenn/presets/sevennet-l3i5.yaml:4-40."""
     return dict(

@@ -9,7 +9,7 @@ from __future__ import annotations
 from typing import Dict, List
 
 from .model_spec import (ConvSpec, build_model_spec, sevennet_0_config,
-                         sevennet_l3i5_config)
+                         sevennet_l3i5_config, sevennet_mf_ompa_config)
 
 # the reference's deployed example model (sevenn 0.8.6), used by the golden fixtures
 TS_EXAMPLE_CONFIG = dict(
@@ -52,6 +52,7 @@ def aot_configs() -> Dict[str, dict]:
         'mini_7net0': mini_sevennet_0_config(),
         'sevennet_0': sevennet_0_config(),
         'sevennet_l3i5': sevennet_l3i5_config(),
+        'sevennet_mf_ompa': sevennet_mf_ompa_config(),
     }
 
 

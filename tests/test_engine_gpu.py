@@ -369,3 +369,24 @@ def test_multi_modal_model_vs_oracle(modal):
     assert abs(float(other['energy']) - float(ref['energy'])) > 1e-3   # the channels really differ
     with pytest.raises(ValueError, match='modal'):
         HipForceEngine(cfg, sd, device='cuda:0')
+
+
+def test_sevennet_mf_ompa_shape_vs_oracle_small_cell():
+    """BASELINE config 5 shape: O(3) parity, lmax 3, 119-species `nequip` self-connection, two fidelity
+    channels, modal-wise shift, cutoff 6 (XPLOR 5.5); 4-species decoration of a 64-atom cell,
+    synthetic weights; fp32 GPU vs fp64 oracle"""
+    from sevennet_amd.engine import HipForceEngine, build_graph
+    from sevennet_amd.model_spec import sevennet_mf_ompa_config
+    from sevennet_amd.synthetic import random_state_dict
+    from oracle.model import OracleModel
+    cfg = sevennet_mf_ompa_config()
+    sd = random_state_dict(cfg, seed=0)
+    sd['rescale_atomic_energy.shift'] = np.random.default_rng(1).standard_normal((2, 119)).astype(np.float32)
+    types, pos, cell, ei, ev = synthetic_system((2, 2, 2), sigma=0.05, seed=0, cutoff=6.0)
+    types = np.random.default_rng(4).choice(np.array([3, 8, 14, 22]), size=len(types))
+    eng = HipForceEngine(cfg, sd, device='cuda:0', modal='omat24')
+    g = build_graph(types, ei, ev, device='cuda:0', num_species=119)
+    out = eng.compute(g, want_atomic_virial=True, keep=True)
+    torch.cuda.synchronize()
+    ref = OracleModel(cfg, sd, dtype=torch.float64, modal='omat24').forward(types, ei, ev, keep=True)
+    _compare(eng, out, ref, len(types), rel=5e-5)
