@@ -425,12 +425,19 @@ class HipForceEngine:
                 ls = L.spec
                 n_in = NT if t == 0 else N  # rows of x that are valid
                 with _Span(self, 'node_linear_fwd'):
-                    sc = self._linear(L.sc, x, N, g) if L.sc is not None else None
                     h = self._new(NT, ls.si1.dim_out)
                     self._linear(L.si1, x, n_in, g, out=h)
+                # ghost rows of h travel while the self-connection and the radial MLP (which do not read
+                # them) run: hosts with a split exchange overlap the transfer with that work
+                pending = None
                 if t > 0 and halo is not None:
                     with _Span(self, 'halo_fwd'):
-                        halo.forward(h, N)
+                        if hasattr(halo, 'forward_start'):
+                            pending = halo.forward_start(h, N)
+                        else:
+                            halo.forward(h, N)
+                with _Span(self, 'node_linear_fwd'):
+                    sc = self._linear(L.sc, x, N, g) if L.sc is not None else None
                 dmid = ls.conv.irreps_out.dim
                 m = self._new(N, dmid)
                 if E == 0:
@@ -442,6 +449,9 @@ class HipForceEngine:
                     with _Span(self, 'radial_mlp_hidden_fwd'):
                         _lib.check(lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb), E, _ptr(h2), st),
                                    'snet_radial_mlp_hidden_fwd')
+                    if pending is not None:
+                        with _Span(self, 'halo_fwd'):
+                            halo.forward_finish(pending)
                     with _Span(self, f'conv_fwd_fused[{ls.conv.tag}]'):
                         _lib.check(lib.snet_conv_fwd_fused(L.plan, L.mlp_plan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.row_ptr),
                                                            _ptr(g.src), N, L.scale, _ptr(m), _ptr(w), st),
@@ -451,6 +461,9 @@ class HipForceEngine:
                     with _Span(self, f'radial_mlp_fwd[wn={ls.conv.weight_numel}]'):
                         # one weight row per undirected pair when the graph carries the pair map
                         w, zs = self._mlp_fwd(L, emb_p, g.n_pairs) if pairs else self._mlp_fwd(L, emb, E)
+                    if pending is not None:
+                        with _Span(self, 'halo_fwd'):
+                            halo.forward_finish(pending)
                     with _Span(self, f'conv_fwd[{ls.conv.tag}]'):
                         _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(w_row), _ptr(g.row_ptr),
                                                      _ptr(g.src), N, L.scale, _ptr(m), st), 'snet_conv_fwd')
@@ -499,19 +512,29 @@ class HipForceEngine:
                                                           _ptr(None if L.fused_conv else w_row), _ptr(g.row_ptr),
                                                           _ptr(g.src), N, L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_xe),
                                                           _ptr(g_vec), st), 'snet_conv_bwd_edge_vec')
+                # the source-row gradient goes first so that its ghost rows can travel to their owners while
+                # the radial MLP's reverse pass (independent of them) runs
+                pending = None
+                if t > 0:
+                    g_h = self._new(NT, ls.si1.dim_out)
+                    with _Span(self, 'conv_bwd_node[segment_sum]'):
+                        _lib.check(lib.snet_segment_sum_rows(_ptr(g_xe), _ptr(g.col_ptr), _ptr(g.eperm), NT,
+                                                             ls.si1.dim_out, _ptr(g_h), st), 'snet_segment_sum_rows')
+                    del g_xe
+                    if halo is not None:
+                        with _Span(self, 'halo_rev'):
+                            if hasattr(halo, 'reverse_start'):
+                                pending = halo.reverse_start(g_h, N)
+                            else:
+                                halo.reverse(g_h, N)
                 with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]'):
                     self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
                 del g_w
                 if t == 0:
                     break
-                g_h = self._new(NT, ls.si1.dim_out)
-                with _Span(self, 'conv_bwd_node[segment_sum]'):
-                    _lib.check(lib.snet_segment_sum_rows(_ptr(g_xe), _ptr(g.col_ptr), _ptr(g.eperm), NT, ls.si1.dim_out,
-                                                         _ptr(g_h), st), 'snet_segment_sum_rows')
-                del g_xe
-                if halo is not None:
+                if pending is not None:
                     with _Span(self, 'halo_rev'):
-                        halo.reverse(g_h, N)
+                        halo.reverse_finish(pending, g_h)
                 with _Span(self, 'node_linear_bwd'):
                     g_x = self._linear_T(L.si1, g_h, N, g)
                     if L.sc is not None:

@@ -174,22 +174,44 @@ class HaloExchange:
     def _unpack_add(self, y, idx, rows):
         _scatter_add_rows(y, idx, rows)
 
-    def forward(self, x: torch.Tensor, n_local: int):
-        """Fill ghost rows x[n_local:] with the owners' rows."""
+    # The exchange is split into start / finish so the host can put independent kernels between them:
+    # the collective runs on the backend's own stream (RCCL) while e.g. the radial MLP of the same
+    # layer runs on the compute stream; finish() makes the compute stream wait for the transfer.
+    def forward_start(self, x: torch.Tensor, n_local: int):
+        """Begin filling ghost rows x[n_local:] with the owners' rows; returns a handle for forward_finish."""
         assert x.shape[0] == n_local + self.n_ghost and x.is_contiguous()
         send = self._pack(x, self.send_idx)
-        self.dist.all_to_all_single(x[n_local:], send, self.recv_counts, self.send_counts, group=self.group)
+        work = self.dist.all_to_all_single(x[n_local:], send, self.recv_counts, self.send_counts, group=self.group,
+                                           async_op=True)
+        return work, send  # `send` stays referenced until the transfer has been waited for
 
-    def reverse(self, gx: torch.Tensor, n_local: int):
-        """Accumulate ghost-row gradients gx[n_local:] into their owners' rows
-        (unpack_reverse semantics of pair_e3gnn_parallel.cpp:886-911)."""
+    def forward_finish(self, handle):
+        handle[0].wait()
+
+    def forward(self, x: torch.Tensor, n_local: int):
+        """Fill ghost rows x[n_local:] with the owners' rows."""
+        self.forward_finish(self.forward_start(x, n_local))
+
+    def reverse_start(self, gx: torch.Tensor, n_local: int):
+        """Begin sending ghost-row gradients gx[n_local:] to their owners; returns a handle for reverse_finish."""
         assert gx.shape[0] == n_local + self.n_ghost and gx.is_contiguous()
         recv = torch.empty(sum(self.send_counts), gx.shape[1], dtype=gx.dtype, device=gx.device)
-        self.dist.all_to_all_single(recv, gx[n_local:].contiguous(), self.send_counts, self.recv_counts, group=self.group)
+        out = gx[n_local:].contiguous()
+        work = self.dist.all_to_all_single(recv, out, self.send_counts, self.recv_counts, group=self.group, async_op=True)
+        return work, recv, out
+
+    def reverse_finish(self, handle, gx: torch.Tensor):
+        """Accumulate the received ghost-row gradients into their owners' rows
+        (unpack_reverse semantics of pair_e3gnn_parallel.cpp:886-911)."""
+        work, recv, _ = handle
+        work.wait()
         o = 0
         for idx, c in zip(self.peer_idx, self.send_counts):  # one peer at a time: deterministic sums
             self._unpack_add(gx, idx, recv[o:o + c])
             o += c
+
+    def reverse(self, gx: torch.Tensor, n_local: int):
+        self.reverse_finish(self.reverse_start(gx, n_local), gx)
 
 
 # --------------------------------------------------------------------------- #

@@ -228,6 +228,16 @@ def test_rccl_backend_halo_exchange_world1():
         exp = gref[:n_local].clone()
         exp[send] += gref[n_local:]
         assert torch.allclose(gx[:n_local], exp)
+        # split exchange with independent work on the compute stream in between (what the engine does)
+        x2, gx2 = ref.clone(), gref.clone()
+        hf = halo.forward_start(x2, n_local)
+        busy = torch.randn(2048, 2048, device='cuda:0') @ torch.randn(2048, 2048, device='cuda:0')
+        halo.forward_finish(hf)
+        hr = halo.reverse_start(gx2, n_local)
+        busy = busy @ busy
+        halo.reverse_finish(hr, gx2)
+        torch.cuda.synchronize()
+        assert torch.equal(x2, x) and torch.allclose(gx2[:n_local], exp)
     finally:
         dist.destroy_process_group()
 
