@@ -60,6 +60,16 @@ struct ConvRegistrar {
 };
 
 // ---- device helpers -----------------------------------------------------------
+// Workgroups are dispatched round-robin over the 8 XCDs (block b runs on XCD b % 8), each with its own
+// L2.  One-workgroup-per-node kernels map block b to node xcd_node(b, n) so that every XCD walks a
+// CONTIGUOUS range of nodes: atoms that are close in index are close in space (MD codes keep them
+// sorted), so the source rows and radial-weight rows their edges share are re-read from the same L2
+// instead of being fetched into eight of them.  Bijection of [0, n).
+__device__ __forceinline__ int xcd_node(unsigned b, unsigned n) {
+  const unsigned k = b & 7u, j = b >> 3, q = n >> 3, r = n & 7u;
+  return (int)(k * q + (k < r ? k : r) + j);
+}
+
 // 64-lane wavefront sum; every lane returns the total.
 __device__ __forceinline__ float wave_sum(float v) {
   v += __shfl_xor(v, 32, 64);

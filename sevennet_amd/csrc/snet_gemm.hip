@@ -9,11 +9,15 @@
 // (As[k][row], row stride 129 -> conflict-free ds_write_b32 and ds_read_b32), so the
 // MFMA A fragment (lane l: row l&31, k = 2*kk + (l>>5)) is one ds_read_b32 per step.
 // Weights packed by snet_gemm_split_pack take the split-precision kernel further down instead.
+#include <cstdlib>
 #include <cstring>
 
 #include "snet_common.h"
 #include "snet_split.h"
 
+#ifndef SNET_GEMM_OCC
+#define SNET_GEMM_OCC 4
+#endif
 namespace {
 
 using snet::f32x16;
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupArgs G, const fl
 }
 
 template <int MT>
-__global__ __launch_bounds__(256, 2) void gemm_split_grouped_kernel(GroupArgs G, const float *__restrict__ A,
+__global__ __launch_bounds__(256, MT == 1 ? SNET_GEMM_OCC : 2) void gemm_split_grouped_kernel(GroupArgs G, const float *__restrict__ A,
                                                                     float *__restrict__ C, int64_t n_nodes,
                                                                     int64_t a_node_stride, int64_t c_node_stride,
                                                                     const int32_t *__restrict__ row_idx) {
@@ -376,15 +380,17 @@ extern "C" int snet_gemm_grouped(const snet_gemm_desc *descs_host, int32_t n_des
   GroupArgs G;
   G.n = n_desc;
   int n_split = 0;
-  int64_t rows_max = 0;
+  int64_t rows_max = 0;  (void)rows_max;
   for (int i = 0; i < n_desc; ++i) {
     n_split += descs_host[i].B_split != nullptr;
     rows_max = rows_max > n_nodes * descs_host[i].d ? rows_max : n_nodes * descs_host[i].d;
   }
   SNET_REQUIRE(n_split == 0 || n_split == n_desc, "snet_gemm_grouped: mix of split-packed and fp32 weights in one group");
   const bool split = n_split > 0;
-  // split kernel: 64 rows per wave once that still leaves >= 2 workgroups per CU, else 32
-  const int mt = (split && rows_max >= 256 * 512) ? 2 : 1;
+  static const int mt_env = getenv("SNET_GEMM_MT") ? atoi(getenv("SNET_GEMM_MT")) : 0;  // tuning knob
+  // 32 rows per wave (MT = 1, 3 waves/SIMD) beats 64 (MT = 2, 2 waves/SIMD) at every size measured: the
+  // node linears are HBM-bound and want bytes in flight more than B-fragment reuse
+  const int mt = mt_env ? mt_env : 1;
   const int bm = split ? 128 * mt : BM;
   int64_t total = 0;
   for (int i = 0; i < n_desc; ++i) {

@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--model', default='sevennet_0')
     ap.add_argument('--mlp-mode', default='bf16x6')
     ap.add_argument('--only', default='', help='substring filter on kernel names')
+    ap.add_argument('--order', default='raster', choices=['raster', 'morton', 'random'], help='atom order of the test cell')
     a = ap.parse_args()
     from bench import kernel_model, model_config
     from sevennet_amd import _lib
@@ -38,6 +39,15 @@ def main():
     eng = HipForceEngine(cfg, random_state_dict(cfg, 0), mlp_mode=a.mlp_mode)
     lib = eng.lib
     pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
+    if a.order == 'random':
+        pos = pos[np.random.default_rng(0).permutation(len(pos))]
+    elif a.order == 'morton':
+        q = np.floor(pos / 2.7).astype(np.int64)  # ~half-cell boxes
+        key = np.zeros(len(pos), np.int64)
+        for b in range(8):
+            for d in range(3):
+                key |= ((q[:, d] >> b) & 1) << (3 * b + d)
+        pos = pos[np.argsort(key, kind='stable')]
     ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
     g = build_graph(np.zeros(len(pos), np.int64), ei, ev)
     N, E = g.n_local, g.n_edges
@@ -66,6 +76,9 @@ def main():
         f'radial_mlp_bwd[wn={wn}]': lambda: eng._mlp_bwd(L, emb, None, g_w, g_emb, E),
         f'conv_bwd_node[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_node(L.plan, _ptr(sh), _ptr(w), None, _ptr(g.col_ptr), _ptr(g.eperm), _ptr(g.center), N, L.scale, _ptr(g_m), _ptr(g_h), st),
         'si2_fwd': lambda: eng._linear(L.si2, m, N, g),
+        'si1_fwd': lambda: eng._linear(L.si1, h, N, g),
+        'sc_fwd': lambda: eng._linear(L.sc, h, N, g),
+        'si1_bwd': lambda: eng._linear_T(L.si1, h, N, g),
         'si2_bwd': lambda: eng._linear_T(L.si2, rnd(N, ls.si2.dim_out), N, g),
     }
     print(f'lib={_lib.LIB_PATH} N={N} E={E} layer={a.layer} dx={dx} dmid={dmid} wn={wn}')
