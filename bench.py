@@ -239,6 +239,9 @@ def main():
     except Exception:  # noqa: BLE001
         pass
     step_ms = dt / a.steps * 1e3
+    e_total = out['energy'].clone()
+    if world > 1:  # ranks hold partial energies of their bricks
+        dist.all_reduce(e_total)
     roof['kernel_ms_per_step'] = {k: round(v / a.steps, 4) for k, v in sorted(totals.items(), key=lambda kv: -kv[1])}
 
     if rank == 0:
@@ -255,7 +258,7 @@ def main():
                        'parallelism': 'single GPU' if world == 1 else f'spatial decomposition x{world}, RCCL halo',
                        'graph_build_s': round(t_graph, 3),
                        'host': a.host, 'host_enqueue_ms_per_step': round(t_enq / a.steps * 1e3, 3),
-                       'energy': float(out['energy'].cpu())},
+                       'energy': float(e_total.cpu())},
             'roofline': roof,
         }
         if world == 1 and not a.no_cpu_baseline:

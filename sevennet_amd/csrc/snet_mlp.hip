@@ -440,20 +440,24 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_hidden_split_kernel(const f
 #ifndef SNET_MLP_BWD_OCC
 #define SNET_MLP_BWD_OCC 3
 #endif
+#ifndef SNET_MLP_BWD_WAVES
+#define SNET_MLP_BWD_WAVES 4   // wavefronts (32 edges each) sharing one W2 slab per workgroup
+#endif
 constexpr int GS_STRIDE = 36;               // g_w tile row stride (floats): conflict-free 16-B column reads
 constexpr int GS_TILE = 32 * GS_STRIDE;
 constexpr int SLAB_U4 = 2 * 2 * 3 * 64;     // uint4 per 32-channel slab of W2A: [step(2)][tile(2)][term(3)][lane]
 
-__global__ __launch_bounds__(256, SNET_MLP_BWD_OCC) void radial_mlp_bwd_split_kernel(
+__global__ __launch_bounds__(64 * SNET_MLP_BWD_WAVES, SNET_MLP_BWD_OCC) void radial_mlp_bwd_split_kernel(
     const float *__restrict__ emb, const float *__restrict__ g_w, int64_t E, int nb, int wn,
     const float *__restrict__ W0, const u32x4 *__restrict__ W1A, const u32x4 *__restrict__ W2A,
     const u32x4 *__restrict__ W1A2, const u32x4 *__restrict__ W0A, int act, float cst, float *__restrict__ g_emb) {
-  __shared__ float gws[4 * GS_TILE];
+  constexpr int NWV = SNET_MLP_BWD_WAVES, NTH = 64 * NWV, NSL = (768 + NTH - 1) / NTH;  // slab = 768 uint4
+  __shared__ float gws[NWV * GS_TILE];
   __shared__ u32x4 slab[2][SLAB_U4];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, li = lane & 31;
-  const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const int64_t e0 = ((int64_t)blockIdx.x * NWV + wave) * 32;
   const bool wave_ok = e0 < E;
   const int64_t e_lane = e0 + li;
   const bool e_ok = wave_ok && e_lane < E;
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(256, SNET_MLP_BWD_OCC) void radial_mlp_bwd_split_ke
 
   // two chunks in flight in registers (HBM latency exceeds one 24-MFMA chunk): stage[ck & 1]
   f32x4 st_g[2][4];
-  u32x4 st_w[2][3];
+  u32x4 st_w[2][NSL];
   auto load_chunk = [&](int ck, int sl) {
     const int c0 = ck * CH;
 #pragma unroll
@@ -485,14 +489,16 @@ __global__ __launch_bounds__(256, SNET_MLP_BWD_OCC) void radial_mlp_bwd_split_ke
       st_g[sl][i] = q;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) st_w[sl][i] = W2A[(int64_t)ck * SLAB_U4 + tid + 256 * i];  // slab = 768 uint4
+    for (int i = 0; i < NSL; ++i)
+      if (tid + NTH * i < 768) st_w[sl][i] = W2A[(int64_t)ck * SLAB_U4 + tid + NTH * i];
   };
   auto store_chunk = [&](int buf, int sl) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       *reinterpret_cast<f32x4 *>(tile + (8 * i + srow) * GS_STRIDE + scol) = st_g[sl][i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) slab[buf][tid + 256 * i] = st_w[sl][i];
+    for (int i = 0; i < NSL; ++i)
+      if (tid + NTH * i < 768) slab[buf][tid + NTH * i] = st_w[sl][i];
   };
 
   load_chunk(0, 0);
@@ -738,14 +744,14 @@ extern "C" int snet_radial_mlp_bwd(const snet_mlp_plan *p, const float *emb, con
                                    float *g_emb, void *stream) {
   SNET_REQUIRE(p != nullptr, "snet_radial_mlp_bwd: null plan");
   if (E <= 0) return 0;
-  const int64_t grid = (E + 127) / 128;
+  const int64_t grid = p->mode == 0 ? (E + 127) / 128 : (E + 32 * SNET_MLP_BWD_WAVES - 1) / (32 * SNET_MLP_BWD_WAVES);
   SNET_REQUIRE(grid < (1ll << 31), "snet_radial_mlp_bwd: too many edges");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (p->mode == 0)
     radial_mlp_bwd_kernel<<<(unsigned)grid, 256, 0, st>>>(emb, g_w, E, p->nb, p->wn, p->W0, p->W1, p->W2T, p->act,
                                                           p->cst, g_emb);
   else
-    radial_mlp_bwd_split_kernel<<<(unsigned)grid, 256, 0, st>>>(emb, g_w, E, p->nb, p->wn, p->W0, p->W1A, p->W2A,
+    radial_mlp_bwd_split_kernel<<<(unsigned)grid, 64 * SNET_MLP_BWD_WAVES, 0, st>>>(emb, g_w, E, p->nb, p->wn, p->W0, p->W1A, p->W2A,
                                                                 p->W1A2, p->W0A, p->act, p->cst, g_emb);
   SNET_CHECK_LAUNCH("snet_radial_mlp_bwd");
   return 0;
