@@ -50,6 +50,7 @@ def parse():
                          "snet_model_eval sequencer (same kernels; kernel timers then come from an extra untimed pass)")
     ap.add_argument('--fuse-conv', action='store_true',
                     help='experimental: radial-MLP last layer inside the forward tensor-product kernels')
+    ap.add_argument('--no-overlap', action='store_true', help='radial MLPs on the main stream (no second stream)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-reps', type=int, default=5, help='CPU-baseline sample: cells per axis (5 -> 1000 atoms)')
     return ap.parse_args()
@@ -142,7 +143,7 @@ def main():
     cfg = model_config(a.model)
     sd = random_state_dict(cfg, seed=0)
     modal = 'mpa' if cfg.get('use_modality') else None
-    eng = HipForceEngine(cfg, sd, device=dev, mlp_mode=a.mlp_mode, fuse_conv=a.fuse_conv, modal=modal)
+    eng = HipForceEngine(cfg, sd, device=dev, mlp_mode=a.mlp_mode, fuse_conv=a.fuse_conv, modal=modal, overlap=not a.no_overlap)
 
     pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
     n_atoms = len(pos)
