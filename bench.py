@@ -129,12 +129,19 @@ def main():
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
     if a.gpus > 1 and world == 1:
         raise SystemExit('launch N>1 with torch.distributed.run (one process per GPU)')
-    torch.cuda.set_device(local_rank)
-    dev = f'cuda:{local_rank}'
+    # SNET_DIST_BACKEND=gloo lets a 1-GPU box exercise the N>1 code path (all ranks share cuda:0, transfers
+    # staged by gloo): a functional dry run, never a measurement
+    backend = os.environ.get('SNET_DIST_BACKEND', 'nccl')
+    dev_id = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
+    torch.cuda.set_device(dev_id)
+    dev = f'cuda:{dev_id}'
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device(dev))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     from sevennet_amd.engine import HipForceEngine, build_graph
     from sevennet_amd.neighbor import diamond_cubic, neighbor_list

@@ -400,3 +400,31 @@ def test_sevennet_mf_ompa_shape_vs_oracle_small_cell():
     torch.cuda.synchronize()
     ref = OracleModel(cfg, sd, dtype=torch.float64, modal='omat24').forward(types, ei, ev, keep=True)
     _compare(eng, out, ref, len(types), rel=5e-5)
+
+
+def test_bench_multi_rank_path_dry_run():
+    """`bench.py --gpus N` end to end (brick decomposition, split halo exchange inside the timed step,
+    energy all-reduce) with 2 and 4 ranks sharing this box's one GPU over gloo (SNET_DIST_BACKEND): a
+    functional dry run of the path the 8-GPU RCCL bench takes; the total energy must equal the
+    single-process one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['--reps', '6', '--steps', '1', '--warmup', '1', '--no-cpu-baseline']
+    env = dict(os.environ, SNET_DIST_BACKEND='gloo')
+
+    def run(cmd):
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+        return json.loads(line)
+
+    one = run([sys.executable, 'bench.py'] + common)
+    for n, port in ((2, 29611), (4, 29612)):
+        many = run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+                    '--master-addr', '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', str(n)] + common)
+        assert many['n_gpus'] == n and many['config']['atoms'] == one['config']['atoms']
+        assert many['config']['edges'] == one['config']['edges']
+        assert abs(many['config']['energy'] - one['config']['energy']) <= 1e-9 * abs(one['config']['energy'])
