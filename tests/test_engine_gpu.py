@@ -428,3 +428,45 @@ def test_bench_multi_rank_path_dry_run():
         assert many['n_gpus'] == n and many['config']['atoms'] == one['config']['atoms']
         assert many['config']['edges'] == one['config']['edges']
         assert abs(many['config']['energy'] - one['config']['energy']) <= 1e-9 * abs(one['config']['energy'])
+
+
+def test_sevennet_0_10k_atoms_equals_tiled_small_cell():
+    """BASELINE config 2 size (SevenNet-0 shape, 11^3 x 8 = 10 648 atoms, GPU neighbor list) through a
+    size-independent property: the big cell is an exact 11^3 tiling of a rattled 8-atom cell, so every
+    replica must carry the forces / atomic energies of the 2^3 tiling (64 atoms), which the fp64 oracle
+    can evaluate; the total force must vanish."""
+    from sevennet_amd.engine import HipForceEngine
+    from sevennet_amd.model_spec import sevennet_0_config
+    from sevennet_amd.neighbor import neighbor_list
+    from sevennet_amd.neighbor_gpu import build_graph_gpu
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = sevennet_0_config()
+    sd = random_state_dict(cfg, seed=0)
+    a = 5.431
+    basis = np.array([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0],
+                      [.25, .25, .25], [.25, .75, .75], [.75, .25, .75], [.75, .75, .25]]) * a
+    unit = basis + np.random.default_rng(7).normal(0.0, 0.05, basis.shape)
+
+    def tile(n):
+        g = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing='ij'), -1).reshape(-1, 3) * a
+        return (g[:, None, :] + unit[None, :, :]).reshape(-1, 3), np.eye(3) * n * a
+
+    pos_s, cell_s = tile(2)
+    ei, ev, _ = neighbor_list(pos_s, cell_s, [True] * 3, cfg['cutoff'])
+    ref = oracle_model(cfg, sd).forward(np.zeros(len(pos_s), np.int64), ei, ev)
+    f_unit = ref['forces'].numpy()[:8]          # replica (0,0,0) of the 2^3 tiling
+    e_unit = ref['atomic_energy'].numpy()[:8]
+    pos, cell = tile(11)
+    assert len(pos) == 10648
+    eng = HipForceEngine(cfg, sd, device='cuda:0')
+    g = build_graph_gpu(np.zeros(len(pos), np.int64), pos, cell, cfg['cutoff'], device='cuda:0')
+    assert g.n_edges == ei.shape[1] // 64 * 10648 and g.n_pairs * 2 == g.n_edges
+    out = eng.compute(g)
+    torch.cuda.synchronize()
+    F = out['forces'].cpu().numpy().reshape(-1, 8, 3)
+    Ea = out['atomic_energy'].cpu().numpy().reshape(-1, 8)
+    scale = max(1.0, np.abs(f_unit).max())
+    assert np.abs(F - f_unit[None]).max() < F_TOL * scale
+    assert np.abs(Ea - e_unit[None]).max() < 1e-5 * max(1.0, np.abs(e_unit).max())
+    assert abs(float(out['energy'].cpu()) / 10648 - float(ref['energy']) / 64) < 1e-6
+    assert np.abs(out['forces'].cpu().numpy().astype(np.float64).sum(0)).max() < 1e-3 * scale
