@@ -430,9 +430,11 @@ def test_bench_multi_rank_path_dry_run():
         assert abs(many['config']['energy'] - one['config']['energy']) <= 1e-9 * abs(one['config']['energy'])
 
 
-def test_sevennet_0_10k_atoms_equals_tiled_small_cell():
-    """BASELINE config 2 size (SevenNet-0 shape, 11^3 x 8 = 10 648 atoms, GPU neighbor list) through a
-    size-independent property: the big cell is an exact 11^3 tiling of a rattled 8-atom cell, so every
+@pytest.mark.parametrize('n_tile', [11, 23])
+def test_sevennet_0_full_size_equals_tiled_small_cell(n_tile):
+    """BASELINE config 2 / 3 sizes (SevenNet-0 shape, 11^3 x 8 = 10 648 and 23^3 x 8 = 97 336 atoms, GPU
+    neighbor list) through a
+    size-independent property: the big cell is an exact n^3 tiling of a rattled 8-atom cell, so every
     replica must carry the forces / atomic energies of the 2^3 tiling (64 atoms), which the fp64 oracle
     can evaluate; the total force must vanish."""
     from sevennet_amd.engine import HipForceEngine
@@ -456,11 +458,12 @@ def test_sevennet_0_10k_atoms_equals_tiled_small_cell():
     ref = oracle_model(cfg, sd).forward(np.zeros(len(pos_s), np.int64), ei, ev)
     f_unit = ref['forces'].numpy()[:8]          # replica (0,0,0) of the 2^3 tiling
     e_unit = ref['atomic_energy'].numpy()[:8]
-    pos, cell = tile(11)
-    assert len(pos) == 10648
+    pos, cell = tile(n_tile)
+    n_big = len(pos)
+    assert n_big == 8 * n_tile ** 3
     eng = HipForceEngine(cfg, sd, device='cuda:0')
     g = build_graph_gpu(np.zeros(len(pos), np.int64), pos, cell, cfg['cutoff'], device='cuda:0')
-    assert g.n_edges == ei.shape[1] // 64 * 10648 and g.n_pairs * 2 == g.n_edges
+    assert g.n_edges == ei.shape[1] // 64 * n_big and g.n_pairs * 2 == g.n_edges
     out = eng.compute(g)
     torch.cuda.synchronize()
     F = out['forces'].cpu().numpy().reshape(-1, 8, 3)
@@ -468,5 +471,5 @@ def test_sevennet_0_10k_atoms_equals_tiled_small_cell():
     scale = max(1.0, np.abs(f_unit).max())
     assert np.abs(F - f_unit[None]).max() < F_TOL * scale
     assert np.abs(Ea - e_unit[None]).max() < 1e-5 * max(1.0, np.abs(e_unit).max())
-    assert abs(float(out['energy'].cpu()) / 10648 - float(ref['energy']) / 64) < 1e-6
+    assert abs(float(out['energy'].cpu()) / n_big - float(ref['energy']) / 64) < 1e-6
     assert np.abs(out['forces'].cpu().numpy().astype(np.float64).sum(0)).max() < 1e-3 * scale
