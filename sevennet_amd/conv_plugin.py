@@ -72,59 +72,103 @@ def _st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _EdgePlan:
+    """CSR-by-destination view of one (edge_src, edge_dst) pair plus the grouping by source that the
+    reverse pass needs.  The reference hands the SAME edge tensors to every interaction layer of a step
+    (and they arrive sorted by center from its neighbor-list builders), so the plan is built once and
+    shared by all HipUvuConvolution modules; sorted input needs no row permutation at all."""
+
+    def __init__(self, edge_src, edge_dst, n_nodes: int):
+        dev = edge_dst.device
+        self.keep = (edge_src, edge_dst)  # strong refs: their storage cannot be recycled while this is cached
+        dst = edge_dst.to(torch.int64)
+        E = dst.numel()
+        self.order = None
+        if E > 1 and bool((dst[1:] < dst[:-1]).any()):
+            self.order = torch.sort(dst, stable=True).indices
+            dst = dst[self.order]
+        src = edge_src.to(torch.int64)
+        if self.order is not None:
+            src = src[self.order]
+        self.src = src.to(torch.int32).contiguous()
+        self.dst = dst.to(torch.int32).contiguous()
+        row_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
+        col_ptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
+        if E:
+            row_ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_nodes), 0)
+            col_ptr[1:] = torch.cumsum(torch.bincount(src, minlength=n_nodes), 0)
+            self.eperm = torch.sort(src, stable=True).indices.to(torch.int32)
+        else:
+            self.eperm = torch.zeros(0, dtype=torch.int32, device=dev)
+        self.row_ptr, self.col_ptr = row_ptr.to(torch.int32), col_ptr.to(torch.int32)
+
+
+_PLAN_CACHE: dict = {}
+_PLAN_CACHE_SIZE = 2
+
+
+def _edge_plan(edge_src, edge_dst, n_nodes: int) -> _EdgePlan:
+    key = (edge_src.data_ptr(), edge_dst.data_ptr(), edge_src.numel(), n_nodes, edge_src._version, edge_dst._version,
+           str(edge_dst.device), edge_src.dtype, edge_dst.dtype)
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        plan = _EdgePlan(edge_src, edge_dst, n_nodes)
+        while len(_PLAN_CACHE) >= _PLAN_CACHE_SIZE:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+        _PLAN_CACHE[key] = plan
+    return plan
+
+
 class _UvuConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, sh, w, edge_src, edge_dst, mod):
         lib = mod.lib
         if not (x.is_cuda and sh.is_cuda and w.is_cuda):
             raise RuntimeError('HipUvuConvolution needs ROCm tensors (no CPU path exists)')
-        N, E = x.shape[0], sh.shape[0]
-        dst = edge_dst.to(torch.int64)
-        order = torch.sort(dst, stable=True).indices
-        src_s = edge_src.to(torch.int64)[order].to(torch.int32).contiguous()
-        dst_s = dst[order]
-        row_ptr = torch.zeros(N + 1, dtype=torch.int64, device=x.device)
-        row_ptr[1:] = torch.cumsum(torch.bincount(dst_s, minlength=N), 0)
-        row_ptr = row_ptr.to(torch.int32)
-        sh_s = sh.detach().float()[order].contiguous()
-        w_s = w.detach().float()[order].contiguous()
+        N = x.shape[0]
+        ep = _edge_plan(edge_src, edge_dst, N)
+        sh_s = sh.detach().float()
+        w_s = w.detach().float()
+        if ep.order is not None:
+            sh_s, w_s = sh_s[ep.order], w_s[ep.order]
+        sh_s, w_s = sh_s.contiguous(), w_s.contiguous()
         x_im = torch.empty(N, mod.dx, dtype=torch.float32, device=x.device)
         xc = x.detach().float().contiguous()
         _lib.check(lib.snet_permute_cols(_p(xc), _p(mod.idx_in), _p(x_im), N, mod.dx, _st()), 'snet_permute_cols')
         out_im = torch.empty(N, mod.dout, dtype=torch.float32, device=x.device)
-        _lib.check(lib.snet_conv_fwd(mod.plan, _p(x_im), _p(sh_s), _p(w_s), None, _p(row_ptr), _p(src_s), N, 1.0,
+        _lib.check(lib.snet_conv_fwd(mod.plan, _p(x_im), _p(sh_s), _p(w_s), None, _p(ep.row_ptr), _p(ep.src), N, 1.0,
                                      _p(out_im), _st()), 'snet_conv_fwd')
         out = torch.empty_like(out_im)
         _lib.check(lib.snet_permute_cols(_p(out_im), _p(mod.idx_out_inv), _p(out), N, mod.dout, _st()), 'snet_permute_cols')
-        ctx.mod = mod
-        ctx.save_for_backward(x_im, sh_s, w_s, row_ptr, src_s, dst_s.to(torch.int32).contiguous(), order)
+        ctx.mod, ctx.ep = mod, ep
+        ctx.save_for_backward(x_im, sh_s, w_s)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        mod, lib = ctx.mod, ctx.mod.lib
-        x_im, sh_s, w_s, row_ptr, src_s, dst_s, order = ctx.saved_tensors
+        mod, lib, ep = ctx.mod, ctx.mod.lib, ctx.ep
+        x_im, sh_s, w_s = ctx.saved_tensors
         N, E = x_im.shape[0], sh_s.shape[0]
         dev = x_im.device
         g_im = torch.empty(N, mod.dout, dtype=torch.float32, device=dev)
         g_c = g_out.float().contiguous()
         _lib.check(lib.snet_permute_cols(_p(g_c), _p(mod.idx_out), _p(g_im), N, mod.dout, _st()), 'snet_permute_cols')
-        g_w_s = torch.empty(E, mod.wn, dtype=torch.float32, device=dev)
-        g_sh_s = torch.zeros(E, mod.nsh, dtype=torch.float32, device=dev)
-        _lib.check(lib.snet_conv_bwd_edge(mod.plan, _p(x_im), _p(sh_s), _p(w_s), None, _p(row_ptr), _p(src_s), N, 1.0,
-                                          _p(g_im), _p(g_w_s), None, _p(g_sh_s), _st()), 'snet_conv_bwd_edge')
-        col_ptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
-        col_ptr[1:] = torch.cumsum(torch.bincount(src_s.long(), minlength=N), 0)
-        eperm = torch.sort(src_s.long(), stable=True).indices.to(torch.int32)
+        g_w = torch.empty(E, mod.wn, dtype=torch.float32, device=dev)
+        g_sh = torch.zeros(E, mod.nsh, dtype=torch.float32, device=dev)
+        g_xe = torch.empty(E, mod.dx, dtype=torch.float32, device=dev)
+        # per-edge gradients (incl. each edge's share of d/dx[src]), then one segmented sum per source row
+        _lib.check(lib.snet_conv_bwd_edge(mod.plan, _p(x_im), _p(sh_s), _p(w_s), None, _p(ep.row_ptr), _p(ep.src), N, 1.0,
+                                          _p(g_im), _p(g_w), _p(g_xe), _p(g_sh), _st()), 'snet_conv_bwd_edge')
         g_x_im = torch.empty(N, mod.dx, dtype=torch.float32, device=dev)
-        _lib.check(lib.snet_conv_bwd_node(mod.plan, _p(sh_s), _p(w_s), None, _p(col_ptr.to(torch.int32)), _p(eperm), _p(dst_s),
-                                          N, 1.0, _p(g_im), _p(g_x_im), _st()), 'snet_conv_bwd_node')
+        _lib.check(lib.snet_segment_sum_rows(_p(g_xe), _p(ep.col_ptr), _p(ep.eperm), N, mod.dx, _p(g_x_im), _st()),
+                   'snet_segment_sum_rows')
         g_x = torch.empty_like(g_x_im)
         _lib.check(lib.snet_permute_cols(_p(g_x_im), _p(mod.idx_in_inv), _p(g_x), N, mod.dx, _st()), 'snet_permute_cols')
-        g_w = torch.empty_like(g_w_s)
-        g_sh = torch.empty_like(g_sh_s)
-        g_w[order] = g_w_s
-        g_sh[order] = g_sh_s
+        if ep.order is not None:  # back to the caller's edge order
+            g_w_o, g_sh_o = torch.empty_like(g_w), torch.empty_like(g_sh)
+            g_w_o[ep.order] = g_w
+            g_sh_o[ep.order] = g_sh
+            g_w, g_sh = g_w_o, g_sh_o
         return g_x, g_sh, g_w, None, None, None
 
 

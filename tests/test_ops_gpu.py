@@ -304,6 +304,45 @@ def test_conv_fwd_fused_matches_separate_kernels(layer):
     lib.snet_radial_mlp_plan_destroy(mlp)
 
 
+def test_conv_plugin_edge_plan_cache_and_sorted_input():
+    """the reference passes the same (center-sorted) edge tensors to every layer of a step: the CSR plan
+    is built once and shared between modules, sorted input takes the no-permutation path, an in-place
+    change of the edge tensors invalidates the plan"""
+    from sevennet_amd import conv_plugin
+    from sevennet_amd.conv_plugin import HipUvuConvolution
+    spec = _conv_case('unit_l2')
+    dev = 'cuda:0'
+    ins = [(p.i_x, p.i_sh, k, 'uvu', True) for p, k in zip(spec.paths, _mid_index(spec))]
+    a = HipUvuConvolution(str(spec.irreps_x), str(spec.irreps_sh), str(spec.irreps_mid), ins).to(dev)
+    b = HipUvuConvolution(str(spec.irreps_x), str(spec.irreps_sh), str(spec.irreps_mid), ins).to(dev)
+    g = torch.Generator().manual_seed(9)
+    N, E = 29, 300
+    x = torch.randn(N, spec.irreps_x.dim, generator=g).to(dev)
+    sh = torch.randn(E, spec.irreps_sh.dim, generator=g).to(dev)
+    w = torch.randn(E, spec.weight_numel, generator=g).to(dev)
+    dst = torch.sort(torch.randint(0, N, (E,), generator=g)).values.to(torch.int32).to(dev)   # sorted by center
+    src = torch.randint(0, N, (E,), generator=g).to(torch.int32).to(dev)
+    conv_plugin._PLAN_CACHE.clear()
+    out_a = a(x, sh, w, src, dst)
+    assert len(conv_plugin._PLAN_CACHE) == 1
+    plan = next(iter(conv_plugin._PLAN_CACHE.values()))
+    assert plan.order is None                                    # already sorted: rows are used in place
+    out_b = b(x, sh, w, src[:], dst[:])                          # new view objects of the same storage, other module
+    assert len(conv_plugin._PLAN_CACHE) == 1 and next(iter(conv_plugin._PLAN_CACHE.values())) is plan
+    assert torch.equal(out_a, out_b)
+    # same numbers through the unsorted path
+    perm = torch.randperm(E, generator=g).to(dev)
+    out_p = a(x, sh[perm], w[perm], src[perm].contiguous(), dst[perm].contiguous())
+    assert (out_p - out_a).abs().max() <= 1e-5 * out_a.abs().max()
+    # in-place edit of the edge list -> new plan, different result
+    src2 = src.clone()
+    out_c = a(x, sh, w, src2, dst)
+    src2[0] = (src2[0] + 1) % N
+    out_d = a(x, sh, w, src2, dst)
+    torch.cuda.synchronize()
+    assert torch.equal(out_c, out_a) and not torch.equal(out_d, out_c)
+
+
 def test_segment_sum_rows():
     L, lib = _lib()
     dev = 'cuda:0'

@@ -62,6 +62,24 @@ def main():
     h, w, g_m = rnd(N, dx), rnd(E, wn), rnd(N, dmid)
     m, g_w, g_vec, g_h, g_emb = eng._new(N, dmid), eng._new(E, wn), torch.zeros(E, 3, device=dev), eng._new(N, dx), torch.zeros(E, nb, device=dev)
     g_xe = eng._new(E, dx)
+    from sevennet_amd.conv_plugin import HipUvuConvolution
+    plug = None
+    try:
+        order_ = sorted(range(len(ls.conv.paths)), key=lambda q: (ls.conv.paths[q].out_off, ls.conv.paths[q].out_ch))
+        mid_idx = [0] * len(order_)   # block of irreps_mid (one per path, sorted) that each path fills
+        for k_, q in enumerate(order_):
+            mid_idx[q] = k_
+        ins = [(p_.i_x, p_.i_sh, k_, 'uvu', True) for p_, k_ in zip(ls.conv.paths, mid_idx)]
+        plug = HipUvuConvolution(str(ls.conv.irreps_x), str(ls.conv.irreps_sh), str(ls.conv.irreps_mid), ins).to(dev)
+    except Exception as exc:  # noqa: BLE001
+        print('plugin op unavailable:', exc)
+    xq, shq, wq = rnd(N, dx).requires_grad_(True), sh.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    goq = rnd(N, dmid)
+
+    def plugin_step():
+        out = plug(xq, shq, wq, g.src, g.center)
+        out.backward(goq)
+        xq.grad = shq.grad = wq.grad = None
     km = kernel_model(ls, N, E)
     st = _stream()
     h2 = rnd(E, 64)
@@ -76,6 +94,7 @@ def main():
         'segment_sum_rows': lambda: lib.snet_segment_sum_rows(_ptr(g_xe), _ptr(g.col_ptr), _ptr(g.eperm), N, dx, _ptr(g_h), st),
         f'radial_mlp_bwd[wn={wn}]': lambda: eng._mlp_bwd(L, emb, None, g_w, g_emb, E),
         f'conv_bwd_node[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_node(L.plan, _ptr(sh), _ptr(w), None, _ptr(g.col_ptr), _ptr(g.eperm), _ptr(g.center), N, L.scale, _ptr(g_m), _ptr(g_h), st),
+        'plugin_fwd_bwd(b1 autograd op)': plugin_step,
         'si2_fwd': lambda: eng._linear(L.si2, m, N, g),
         'si1_fwd': lambda: eng._linear(L.si1, h, N, g),
         'sc_fwd': lambda: eng._linear(L.sc, h, N, g),
