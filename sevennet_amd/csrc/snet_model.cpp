@@ -5,6 +5,7 @@
 // (sevennet_amd/engine.py), no torch, no Python.  Ghost-feature exchange is left to the host through
 // two callbacks invoked at the reference's exchange points (pair_e3gnn_parallel.cpp:369,435).
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -190,7 +191,14 @@ struct snet_model {
   int32_t *species_rows = nullptr;                       // device, concatenated
   size_t species_rows_cap = 0;
   std::vector<int64_t> species_off, species_cnt;
+  // second stream for the radial MLPs (graphs of at most OVERLAP_MAX_EDGES edges, see engine.py)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_main = nullptr, ev_bwd[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> ev_w;
+  bool overlap = getenv("SNET_NO_OVERLAP") == nullptr;
 };
+
+constexpr int64_t OVERLAP_MAX_EDGES = 700000;
 
 namespace {
 
@@ -325,6 +333,9 @@ extern "C" void snet_model_destroy(snet_model *m) {
     free_lin(L.sc); free_lin(L.si1); free_lin(L.si2);
   }
   free_lin(m->ro1); free_lin(m->ro2);
+  for (hipEvent_t e : m->ev_w) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {m->ev_main, m->ev_bwd[0], m->ev_bwd[1]}) if (e) (void)hipEventDestroy(e);
+  if (m->side) (void)hipStreamDestroy(m->side);
   for (void *d : {(void *)m->embed, (void *)m->scale, (void *)m->shift, (void *)m->arena.base, (void *)m->species_rows})
     if (d) (void)hipFree(d);
   delete m;
@@ -384,6 +395,16 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   SNET_REQUIRE(!pairs || (pair_edge != nullptr && n_pairs > 0 && n_pairs <= E),
                "snet_model_eval: w_row needs pair_edge and 0 < n_pairs <= n_edges");
   const int64_t WR = pairs ? n_pairs : E;  // rows of each layer's radial-weight matrix
+  bool ov = m->overlap && E > 0 && E <= OVERLAP_MAX_EDGES;
+  if (ov && m->side == nullptr) {  // created on first use; any failure just keeps everything on one stream
+    bool ok = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&m->ev_bwd[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&m->ev_bwd[1], hipEventDisableTiming) == hipSuccess;
+    m->ev_w.resize(m->n_layers, nullptr);
+    for (int t = 0; ok && t < m->n_layers; ++t) ok = hipEventCreateWithFlags(&m->ev_w[t], hipEventDisableTiming) == hipSuccess;
+    if (!ok) m->overlap = ov = false;
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nb = m->n_basis, nsh = (m->lmax + 1) * (m->lmax + 1);
   const int Lc = m->n_layers;
@@ -431,6 +452,9 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
                      (size_t)NT * L.dx * 2 + (size_t)N * L.dout + 4096;
     trans = trans > t ? trans : t;
   }
+  size_t wn_max = 0;
+  for (auto &L : m->layers) wn_max = wn_max > (size_t)L.wn ? wn_max : (size_t)L.wn;
+  if (ov) { add((size_t)E * wn_max); add((size_t)E * wn_max); }  // g_w double buffer (its reader runs on the side stream)
   add((size_t)NT * dmax * 2 + 256); add((size_t)N * (m->ro1.dim_out + 8) * 2); add(trans + 64 * 1024);
   need += 1 << 20;
   if (m->arena.cap < need) {
@@ -464,6 +488,19 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     saved[t].w = A.f((size_t)WR * m->layers[t].wn);
     saved[t].y = A.f((size_t)N * m->layers[t].gin);
   }
+  float *gw_buf[2] = {nullptr, nullptr};
+  bool gw_busy[2] = {false, false};
+  if (ov) {
+    gw_buf[0] = A.f((size_t)E * wn_max);
+    gw_buf[1] = A.f((size_t)E * wn_max);
+    // every layer's radial weights depend on the edge embedding only: enqueue them all on the side stream now
+    SNET_REQUIRE(hipEventRecord(m->ev_main, st) == hipSuccess && hipStreamWaitEvent(m->side, m->ev_main, 0) == hipSuccess,
+                 "snet_model_eval: stream ordering failed");
+    for (int t = 0; t < Lc; ++t) {
+      if ((rc = snet_radial_mlp_fwd(m->layers[t].mlp_plan, emb_w, WR, saved[t].w, m->side))) return rc;
+      SNET_REQUIRE(hipEventRecord(m->ev_w[t], m->side) == hipSuccess, "snet_model_eval: stream ordering failed");
+    }
+  }
   const size_t mark = A.off;  // transient region starts here
 
   // ---------------- forward
@@ -482,7 +519,10 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
         snet::set_error("snet_model_eval: forward halo callback failed");
         return rc;
       }
-    if ((rc = snet_radial_mlp_fwd(L.mlp_plan, emb_w, WR, saved[t].w, st))) return rc;
+    if (ov)
+      SNET_REQUIRE(hipStreamWaitEvent(st, m->ev_w[t], 0) == hipSuccess, "snet_model_eval: stream ordering failed");
+    else if ((rc = snet_radial_mlp_fwd(L.mlp_plan, emb_w, WR, saved[t].w, st)))
+      return rc;
     float *mid = A.f((size_t)N * L.dmid);
     if (E == 0) SNET_REQUIRE(hipMemsetAsync(mid, 0, (size_t)N * L.dmid * 4, st) == hipSuccess, "snet_model_eval: memset");
     if ((rc = snet_conv_fwd(L.conv, h, sh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, N, L.conv_scale, mid, st)))
@@ -528,13 +568,23 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     if ((rc = snet_gate_bwd(saved[t].y, g_x, g_y, N, L.gin, L.dout, L.segs.data(), (int)L.segs.size(), st))) return rc;
     float *g_m = A.f((size_t)N * L.dmid);
     if ((rc = run_linear(m, L.si2, g_y, g_m, N, true, false, st))) return rc;
-    float *g_w = A.f((size_t)E * L.wn);
+    float *g_w = ov ? gw_buf[t & 1] : A.f((size_t)E * L.wn);
+    if (ov && gw_busy[t & 1])  // the MLP reverse of layer t+2 read this buffer on the side stream
+      SNET_REQUIRE(hipStreamWaitEvent(st, m->ev_bwd[t & 1], 0) == hipSuccess, "snet_model_eval: stream ordering failed");
     float *g_xe = t > 0 ? A.f((size_t)E * L.dx) : nullptr;
     if ((rc = snet_conv_bwd_edge_vec(L.conv, saved[t].h, sh, dsh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, N,
                                      L.conv_scale, g_m, g_w,
                                      g_xe, g_vec, st)))
       return rc;
-    if ((rc = snet_radial_mlp_bwd(L.mlp_plan, emb, g_w, E, g_emb, st))) return rc;
+    if (ov) {  // only the final radial gradient needs g_emb: runs beside the rest of the reverse pass
+      SNET_REQUIRE(hipEventRecord(m->ev_main, st) == hipSuccess && hipStreamWaitEvent(m->side, m->ev_main, 0) == hipSuccess,
+                   "snet_model_eval: stream ordering failed");
+      if ((rc = snet_radial_mlp_bwd(L.mlp_plan, emb, g_w, E, g_emb, m->side))) return rc;
+      SNET_REQUIRE(hipEventRecord(m->ev_bwd[t & 1], m->side) == hipSuccess, "snet_model_eval: stream ordering failed");
+      gw_busy[t & 1] = true;
+    } else if ((rc = snet_radial_mlp_bwd(L.mlp_plan, emb, g_w, E, g_emb, st))) {
+      return rc;
+    }
     if (t == 0) break;  // layer-0 inputs depend on species only
     float *g_h = A.f((size_t)NT * L.dx);
     if ((rc = snet_segment_sum_rows(g_xe, col_ptr, eperm, NT, L.dx, g_h, st))) return rc;
@@ -549,6 +599,9 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
       if ((rc = run_linear(m, L.sc, g_y, gx_next, N, true, true, st))) return rc;
     std::swap(g_x, gx_next);
   }
+  for (int b = 0; b < 2; ++b)
+    if (gw_busy[b])
+      SNET_REQUIRE(hipStreamWaitEvent(st, m->ev_bwd[b], 0) == hipSuccess, "snet_model_eval: stream ordering failed");
   if ((rc = snet_edge_embed_bwd(&ep, m->coeffs.data(), edge_vec, E, g_emb, nullptr, g_vec, 1, st))) return rc;
   A.off = mark2;
   float *F = forces ? forces : A.f((size_t)NT * 3);
