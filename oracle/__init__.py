@@ -22,5 +22,9 @@ Parity pins (see tests/test_oracle_golden.py, oracle/tools/make_golden.py):
   * UNPINNED here (no data, no executable): l=3 Wigner-3j / spherical
     harmonics, normalised-SH path, XPLOR cutoff, `linear` self-connection.
     Those follow the same generators validated on l<=2 and are checked by
-    equivariance + fp64 finite differences only.
+    equivariance + fp64 finite differences only.  Multi-modal linears and
+    modal-wise rescale (sevenn/nn/linear.py:66-92, scale.py:196-363) restate the
+    in-tree Python literally; their STRUCTURE is pinned by the reference's
+    parameter counts (tests/unit_tests/test_model.py:185-212), their numerics
+    are unpinned.
 """
