@@ -166,6 +166,13 @@ class HaloExchange:
         self.send_idx = torch.as_tensor(cat, dtype=torch.int32, device=self.dev)
         self.peer_idx = [torch.as_tensor(np.asarray(s), dtype=torch.int32, device=self.dev) for s in send_lists]
         self.n_ghost = sum(self.recv_counts)
+        # reverse unpack in two launches for any number of peers: received rows grouped by the local row they
+        # add into (stable: contributions of one row keep their peer order, so the sum order is fixed)
+        order = np.argsort(cat, kind='stable')
+        rows, counts = np.unique(cat, return_counts=True)
+        self.red_rows = torch.as_tensor(rows, dtype=torch.int32, device=self.dev)
+        self.red_perm = torch.as_tensor(order, dtype=torch.int32, device=self.dev)
+        self.red_ptr = torch.as_tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device=self.dev)
 
     # pack / unpack primitives (overridable: the CPU tests of the exchange plan use host tensors)
     def _pack(self, x, idx):
@@ -173,6 +180,20 @@ class HaloExchange:
 
     def _unpack_add(self, y, idx, rows):
         _scatter_add_rows(y, idx, rows)
+
+    def _reduce_add(self, y, recv):
+        """y[red_rows[s]] += sum_k recv[red_perm[k]], k in segment s (one segmented sum + one scatter-add)."""
+        n_seg = self.red_rows.numel()
+        if n_seg == 0:
+            return
+        from . import _lib
+        lib = _lib.load()
+        tmp = torch.empty(n_seg, y.shape[1], dtype=y.dtype, device=y.device)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.snet_segment_sum_rows(C.c_void_p(recv.data_ptr()), C.c_void_p(self.red_ptr.data_ptr()),
+                                             C.c_void_p(self.red_perm.data_ptr()), n_seg, y.shape[1],
+                                             C.c_void_p(tmp.data_ptr()), st), 'snet_segment_sum_rows')
+        self._unpack_add(y, self.red_rows, tmp)
 
     # The exchange is split into start / finish so the host can put independent kernels between them:
     # the collective runs on the backend's own stream (RCCL) while e.g. the radial MLP of the same
@@ -205,10 +226,7 @@ class HaloExchange:
         (unpack_reverse semantics of pair_e3gnn_parallel.cpp:886-911)."""
         work, recv, _ = handle
         work.wait()
-        o = 0
-        for idx, c in zip(self.peer_idx, self.send_counts):  # one peer at a time: deterministic sums
-            self._unpack_add(gx, idx, recv[o:o + c])
-            o += c
+        self._reduce_add(gx, recv)
 
     def reverse(self, gx: torch.Tensor, n_local: int):
         self.reverse_finish(self.reverse_start(gx, n_local), gx)

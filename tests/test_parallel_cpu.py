@@ -42,6 +42,14 @@ def _host_halo(send_lists, recv_counts):
         def _unpack_add(self, y, idx, rows):
             y.index_add_(0, idx.long(), rows)
 
+        def _reduce_add(self, y, recv):  # same grouping and order as the device version
+            for s in range(self.red_rows.numel()):
+                k0, k1 = int(self.red_ptr[s]), int(self.red_ptr[s + 1])
+                acc = recv[int(self.red_perm[k0])].clone()
+                for k in range(k0 + 1, k1):
+                    acc += recv[int(self.red_perm[k])]
+                y[int(self.red_rows[s])] += acc
+
     return HostHalo(send_lists, recv_counts, 'cpu')
 
 
