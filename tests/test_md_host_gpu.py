@@ -237,3 +237,22 @@ def test_md_host_ghost_nodes_two_ranks_equal_single_process():
     assert np.abs(Ea - ref['atomic_energy']).max() <= max(1e-6, 2e-5 * np.abs(ref['atomic_energy']).max())
     v = ref['virial'][[0, 1, 2, 3, 5, 4]]
     assert np.abs(vir - v).max() <= max(1e-6, 2e-5 * np.abs(v).max())
+
+
+def test_md_host_isolated_atoms_no_edges():
+    """two atoms farther apart than the cutoff (non-periodic box, neighbor rows hold only the out-of-range
+    partner): no edge survives the filter, energies are the bare atomic terms, forces are zero"""
+    from helpers import oracle_model
+    from sevennet_amd.shapes import unit_test_config
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = unit_test_config()
+    sd = random_state_dict(cfg, seed=5)
+    x = np.array([[0.0, 0.0, 0.0], [4.5, 0.0, 0.0]])           # cutoff 4.0 < 4.5 < cutoff + skin
+    rows = [np.array([1], np.int32), np.array([0], np.int32)]
+    host = MdHost(cfg, sd)
+    out = host.compute(x, np.array([1, 2]), 2, rows, np.array([2, 0]))
+    assert out['n_edges'] == 0 and out['n_nodes'] == 2
+    assert np.abs(out['f']).max() == 0.0 and np.abs(out['virial']).max() == 0.0
+    ref = oracle_model(cfg, sd).forward(np.array([2, 0]), np.zeros((2, 0), np.int64), np.zeros((0, 3)))
+    assert np.abs(out['eatom'] - ref['atomic_energy'].numpy()).max() < 1e-5
+    assert abs(out['energy'] - float(ref['energy'])) < 1e-5
