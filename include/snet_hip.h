@@ -192,7 +192,10 @@ typedef struct snet_gate_seg {
   float cst;        /* normalize2mom constant of act */
 } snet_gate_seg;
 #define SNET_MAX_GATE_SEGS 16
-int snet_gate_fwd(const float *y, float *out, int64_t n_nodes, int32_t dim_in, int32_t dim_out,
+/* addend (nullable, [n_nodes, dim_in]): the self-connection term of SelfConnectionOutro
+ * (self_connection.py:118-138); y += addend is applied in place before the gate, so y holds the gate
+ * input that snet_gate_bwd needs. */
+int snet_gate_fwd(float *y, const float *addend, float *out, int64_t n_nodes, int32_t dim_in, int32_t dim_out,
                   const snet_gate_seg *segs_host, int32_t n_segs, void *stream);
 int snet_gate_bwd(const float *y, const float *g_out, float *g_y, int64_t n_nodes, int32_t dim_in,
                   int32_t dim_out, const snet_gate_seg *segs_host, int32_t n_segs, void *stream);

@@ -75,7 +75,7 @@ SIGNATURES = {
     'snet_segment_sum_rows': (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, c_f32p, c_stream]),
     'snet_conv_bwd_node': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_float,
                                      c_f32p, c_f32p, c_stream]),
-    'snet_gate_fwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(GateSeg), C.c_int32,
+    'snet_gate_fwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(GateSeg), C.c_int32,
                                 c_stream]),
     'snet_gate_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(GateSeg),
                                 C.c_int32, c_stream]),

@@ -529,8 +529,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
       return rc;
     float *y = saved[t].y;
     if ((rc = run_linear(m, L.si2, mid, y, N, false, false, st))) return rc;
-    if (sc && (rc = snet_add_inplace(y, sc, N * (int64_t)L.gin, st))) return rc;
-    if ((rc = snet_gate_fwd(y, x2, N, L.gin, L.dout, L.segs.data(), (int)L.segs.size(), st))) return rc;
+    if ((rc = snet_gate_fwd(y, sc, x2, N, L.gin, L.dout, L.segs.data(), (int)L.segs.size(), st))) return rc;
     std::swap(x, x2);
   }
   A.off = mark;

@@ -13,35 +13,48 @@ struct GateTable {
 
 // One lane per (node, segment channel u); a gated lane handles its 2l+1 components so the
 // gate scalar's gradient needs no cross-lane reduction.
-__global__ __launch_bounds__(256) void gate_fwd_kernel(GateTable T, const float *__restrict__ y,
-                                                       float *__restrict__ out, int64_t n_nodes, int dim_in,
-                                                       int dim_out) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t node = gid / T.total_ch;
-  if (node >= n_nodes) return;
-  const int c = (int)(gid - node * T.total_ch);
+// A workgroup of max(256, total_ch) lanes takes npb = lanes / total_ch whole nodes.  `addend` (nullable, same shape as y) is the
+// self-connection term: y += addend is done here, in place (every y element belongs to exactly one lane),
+// so the separate add pass over y disappears and the reverse pass finds the summed gate input in y.
+__global__ __launch_bounds__(1024) void gate_fwd_kernel(GateTable T, float *__restrict__ y,
+                                                       const float *__restrict__ addend, float *__restrict__ out,
+                                                       int64_t n_nodes, int dim_in, int dim_out, int npb) {
+  const int q = threadIdx.x / T.total_ch;  // node inside the workgroup
+  const int c = threadIdx.x - q * T.total_ch;
+  const int64_t node = (int64_t)blockIdx.x * npb + q;
+  if (q >= npb || node >= n_nodes) return;
   int s = 0;
   while (s + 1 < T.n && c >= T.ch0[s + 1]) ++s;
   const snet_gate_seg sg = T.seg[s];
   const int u = c - T.ch0[s];
-  const float *yr = y + node * dim_in;
+  float *yr = y + node * dim_in;
+  const float *ar = addend ? addend + node * dim_in : nullptr;
   float *orow = out + node * dim_out;
   if (sg.kind == 0) {
-    orow[sg.out_off + u] = snet::act_fwd(yr[sg.in_off + u], sg.act) * sg.cst;
+    float v = yr[sg.in_off + u];
+    if (ar) { v += ar[sg.in_off + u]; yr[sg.in_off + u] = v; }
+    orow[sg.out_off + u] = snet::act_fwd(v, sg.act) * sg.cst;
   } else {
-    const float g = snet::act_fwd(yr[sg.gate_off + u], sg.act) * sg.cst;
+    float z = yr[sg.gate_off + u];
+    if (ar) { z += ar[sg.gate_off + u]; yr[sg.gate_off + u] = z; }
+    const float g = snet::act_fwd(z, sg.act) * sg.cst;
     const int d = 2 * sg.l + 1;
-    for (int m = 0; m < d; ++m) orow[sg.out_off + m * sg.mul + u] = yr[sg.in_off + m * sg.mul + u] * g;
+    for (int m = 0; m < d; ++m) {
+      const int k = sg.in_off + m * sg.mul + u;
+      float v = yr[k];
+      if (ar) { v += ar[k]; yr[k] = v; }
+      orow[sg.out_off + m * sg.mul + u] = v * g;
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void gate_bwd_kernel(GateTable T, const float *__restrict__ y,
+__global__ __launch_bounds__(1024) void gate_bwd_kernel(GateTable T, const float *__restrict__ y,
                                                        const float *__restrict__ g_out, float *__restrict__ g_y,
-                                                       int64_t n_nodes, int dim_in, int dim_out) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t node = gid / T.total_ch;
-  if (node >= n_nodes) return;
-  const int c = (int)(gid - node * T.total_ch);
+                                                       int64_t n_nodes, int dim_in, int dim_out, int npb) {
+  const int q = threadIdx.x / T.total_ch;
+  const int c = threadIdx.x - q * T.total_ch;
+  const int64_t node = (int64_t)blockIdx.x * npb + q;
+  if (q >= npb || node >= n_nodes) return;
   int s = 0;
   while (s + 1 < T.n && c >= T.ch0[s + 1]) ++s;
   const snet_gate_seg sg = T.seg[s];
@@ -199,14 +212,16 @@ void launch_final_sum(const double *partial, int n, int stride, int ncomp, doubl
 }
 }  // namespace snet
 
-extern "C" int snet_gate_fwd(const float *y, float *out, int64_t n_nodes, int32_t dim_in, int32_t dim_out,
-                             const snet_gate_seg *segs, int32_t n_segs, void *stream) {
+extern "C" int snet_gate_fwd(float *y, const float *addend, float *out, int64_t n_nodes, int32_t dim_in,
+                             int32_t dim_out, const snet_gate_seg *segs, int32_t n_segs, void *stream) {
   GateTable T;
   if (int rc = build_gate_table(segs, n_segs, T)) return rc;
   if (n_nodes <= 0) return 0;
-  const int64_t total = n_nodes * T.total_ch;
-  gate_fwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(T, y, out, n_nodes,
-                                                                                                  dim_in, dim_out);
+  SNET_REQUIRE(T.total_ch <= 1024, "snet_gate_fwd: more than 1024 gate channels per node");
+  const int tb = T.total_ch <= 256 ? 256 : (T.total_ch + 63) / 64 * 64;
+  const int npb = tb / T.total_ch;
+  gate_fwd_kernel<<<(unsigned)((n_nodes + npb - 1) / npb), tb, 0, static_cast<hipStream_t>(stream)>>>(
+      T, y, addend, out, n_nodes, dim_in, dim_out, npb);
   SNET_CHECK_LAUNCH("snet_gate_fwd");
   return 0;
 }
@@ -215,9 +230,11 @@ extern "C" int snet_gate_bwd(const float *y, const float *g_out, float *g_y, int
   GateTable T;
   if (int rc = build_gate_table(segs, n_segs, T)) return rc;
   if (n_nodes <= 0) return 0;
-  const int64_t total = n_nodes * T.total_ch;
-  gate_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
-      T, y, g_out, g_y, n_nodes, dim_in, dim_out);
+  SNET_REQUIRE(T.total_ch <= 1024, "snet_gate_bwd: more than 1024 gate channels per node");
+  const int tb = T.total_ch <= 256 ? 256 : (T.total_ch + 63) / 64 * 64;
+  const int npb = tb / T.total_ch;
+  gate_bwd_kernel<<<(unsigned)((n_nodes + npb - 1) / npb), tb, 0, static_cast<hipStream_t>(stream)>>>(
+      T, y, g_out, g_y, n_nodes, dim_in, dim_out, npb);
   SNET_CHECK_LAUNCH("snet_gate_bwd");
   return 0;
 }

@@ -501,11 +501,10 @@ class HipForceEngine:
                                                      _ptr(g.src), N, L.scale, _ptr(m), st), 'snet_conv_fwd')
                 with _Span(self, 'node_linear_fwd'):
                     y = self._linear(L.si2, m, N, g)
-                if sc is not None:
-                    _lib.check(lib.snet_add_inplace(_ptr(y), _ptr(sc), y.numel(), st), 'snet_add_inplace')
                 xo = self._new(N, ls.gate.irreps_out.dim)
-                _lib.check(lib.snet_gate_fwd(_ptr(y), _ptr(xo), N, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim,
-                                             L.gate_segs, len(ls.gate.segs), st), 'snet_gate_fwd')
+                # y += self-connection happens inside the gate kernel (in place: y is kept for the reverse pass)
+                _lib.check(lib.snet_gate_fwd(_ptr(y), _ptr(sc), _ptr(xo), N, ls.gate.irreps_in.dim,
+                                             ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st), 'snet_gate_fwd')
                 saved.append((h, w, zs, y))
                 if keep:
                     inter[f'{t}_si1'], inter[f'{t}_conv'], inter[f'{t}_gate_in'], inter[f'{t}_x'] = h[:N], m, y, xo

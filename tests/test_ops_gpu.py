@@ -403,7 +403,7 @@ def test_gate_and_halo_kernels():
     to_im_out = torch.as_tensor(mulir_to_irmul_index(gs.irreps_out))
     yd = y[:, to_im_in].contiguous().to(dev)
     out = torch.empty(N, gs.irreps_out.dim, device=dev)
-    L.check(lib.snet_gate_fwd(_p(yd), _p(out), N, gs.irreps_in.dim, gs.irreps_out.dim, segs, len(gs.segs), None))
+    L.check(lib.snet_gate_fwd(_p(yd), None, _p(out), N, gs.irreps_in.dim, gs.irreps_out.dim, segs, len(gs.segs), None))
     gy = torch.empty_like(yd)
     god = go[:, to_im_out].contiguous().to(dev)
     L.check(lib.snet_gate_bwd(_p(yd), _p(god), _p(gy), N, gs.irreps_in.dim, gs.irreps_out.dim, segs, len(gs.segs), None))
@@ -412,6 +412,12 @@ def test_gate_and_halo_kernels():
     back_in = torch.as_tensor(irmul_to_mulir_index(gs.irreps_in))
     assert (out.cpu()[:, back_out].double() - ref.detach()).abs().max() < 2e-6
     assert (gy.cpu()[:, back_in].double() - gref).abs().max() < 5e-6
+    # fused self-connection add: gate(y + a), and y is updated in place to y + a
+    a_ = torch.randn(N, gs.irreps_in.dim, generator=g).to(dev)
+    y2, out2 = (yd - a_).contiguous(), torch.empty_like(out)
+    L.check(lib.snet_gate_fwd(_p(y2), _p(a_), _p(out2), N, gs.irreps_in.dim, gs.irreps_out.dim, segs, len(gs.segs), None))
+    torch.cuda.synchronize()
+    assert (y2 - yd).abs().max() < 1e-6 and (out2 - out).abs().max() < 1e-5
     # halo pack / unpack
     x = torch.randn(50, 7, generator=g).to(dev)
     idx = torch.randperm(50, generator=g)[:20].to(torch.int32).to(dev)
