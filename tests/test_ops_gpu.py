@@ -431,3 +431,63 @@ def test_gate_and_halo_kernels():
     mask = torch.ones(50, dtype=torch.bool, device=dev)
     mask[idx.long()] = False
     assert yb[mask].abs().max() == 0
+
+
+@pytest.mark.parametrize('cfg_name', ['7net0_mid', 'unit_l3'])
+def test_conv_bwd_edge_ragged_degrees_vs_autograd(cfg_name):
+    """reverse per-edge kernels on nodes with 0, 1, 2, 3, 31..33, 63..65, 70 and 129 edges (odd counts
+    and > 64-edge multi-pass rows matter for the blocks that run two edges per wavefront): g_w, g_xe and
+    d/dY against autograd of the oracle's tensor product, and the Jacobian-contracted variant against it"""
+    from oracle.e3 import Irreps as OIrreps
+    from oracle.model import tp_uvu
+    from sevennet_amd.irreps import irmul_to_mulir_index, mulir_to_irmul_index
+    L, lib = _lib()
+    dev = 'cuda:0'
+    spec = _conv_case(cfg_name)
+    dx, dout, nsh, wn = spec.irreps_x.dim, spec.irreps_out.dim, spec.irreps_sh.dim, spec.weight_numel
+    g = torch.Generator().manual_seed(17)
+    deg = torch.tensor([0, 1, 2, 3, 31, 32, 33, 63, 64, 65, 70, 129, 0, 5])
+    N = len(deg)
+    row_ptr = torch.zeros(N + 1, dtype=torch.int32)
+    row_ptr[1:] = torch.cumsum(deg, 0)
+    E = int(row_ptr[-1])
+    NT = N + 3
+    src = torch.randint(0, NT, (E,), generator=g).to(torch.int32)
+    dst = torch.repeat_interleave(torch.arange(N), deg)
+    x = torch.randn(NT, dx, generator=g)
+    sh = torch.randn(E, nsh, generator=g)
+    w = torch.randn(E, wn, generator=g)
+    go = torch.randn(N, dout, generator=g)
+    dsh = torch.randn(E, nsh, 3, generator=g)
+    dsh[:, 0] = 0.0                                    # Y_0 is constant: the kernel skips its Jacobian row
+    # oracle (mul_ir layouts) -> convert to the engine's ir_mul
+    to_x = torch.as_tensor(mulir_to_irmul_index(spec.irreps_x))
+    to_o = torch.as_tensor(mulir_to_irmul_index(spec.irreps_out))
+    from_x, from_o = torch.as_tensor(irmul_to_mulir_index(spec.irreps_x)), torch.as_tensor(irmul_to_mulir_index(spec.irreps_out))
+    x64 = x[:, from_x].double().requires_grad_(True)   # x given in ir_mul; oracle wants mul_ir
+    sh64, w64 = sh.double().requires_grad_(True), w.double().requires_grad_(True)
+    ins = [(p.i_x, p.i_sh, k) for p, k in zip(spec.paths, _mid_index(spec))]
+    msg = tp_uvu(x64[src.long()], sh64, w64, OIrreps(str(spec.irreps_x)), OIrreps(str(spec.irreps_sh)),
+                 OIrreps(str(spec.irreps_mid)), ins)
+    out = torch.zeros(N, dout, dtype=torch.float64).index_add_(0, dst, msg)
+    (out * go[:, from_o].double()).sum().backward()
+    plan = C.c_void_p()
+    L.check(lib.snet_conv_plan_create(spec.tag.encode(), C.byref(plan)))
+    xd, shd, wd, god, dshd = x.to(dev), sh.to(dev), w.to(dev), go.to(dev), dsh.reshape(E, nsh * 3).contiguous().to(dev)
+    rp, sr = row_ptr.to(dev), src.to(dev)
+    g_w, g_xe, g_sh = torch.empty(E, wn, device=dev), torch.empty(E, dx, device=dev), torch.zeros(E, nsh, device=dev)
+    L.check(lib.snet_conv_bwd_edge(plan, _p(xd), _p(shd), _p(wd), None, _p(rp), _p(sr), N, 1.0, _p(god), _p(g_w), _p(g_xe),
+                                   _p(g_sh), None))
+    g_w2, g_xe2, g_vec = torch.empty_like(g_w), torch.empty_like(g_xe), torch.zeros(E, 3, device=dev)
+    L.check(lib.snet_conv_bwd_edge_vec(plan, _p(xd), _p(shd), _p(dshd), _p(wd), None, _p(rp), _p(sr), N, 1.0, _p(god),
+                                       _p(g_w2), _p(g_xe2), _p(g_vec), None))
+    torch.cuda.synchronize()
+    tol = lambda ref: 3e-5 * max(1.0, ref.abs().max().item())  # noqa: E731
+    assert (g_w.cpu().double() - w64.grad).abs().max() < tol(w64.grad)
+    assert (g_sh.cpu().double() - sh64.grad).abs().max() < tol(sh64.grad)
+    gx_ref = torch.zeros(NT, dx, dtype=torch.float64).index_add_(0, src.long(), g_xe.cpu().double())
+    assert (gx_ref - x64.grad[:, to_x]).abs().max() < tol(x64.grad)
+    assert torch.equal(g_w, g_w2) and torch.equal(g_xe, g_xe2)
+    gv_ref = torch.einsum('ei,eia->ea', sh64.grad, dsh.double())
+    assert (g_vec.cpu().double() - gv_ref).abs().max() < tol(gv_ref)
+    lib.snet_conv_plan_destroy(plan)
