@@ -193,7 +193,7 @@ class _Span:
 
 
 class HipForceEngine:
-    OVERLAP_MAX_EDGES = 700_000
+    OVERLAP_MAX_EDGES = 1 << 40  # no limit (a knob for experiments)
 
     def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6',
                  linear_mode: str = 'bf16x6', fuse_conv: bool = False, modal=None, overlap: bool = True):
@@ -203,9 +203,9 @@ class HipForceEngine:
         overlap: run the radial MLPs on a second HIP stream -- forward: all layers' weights are produced
         from the edge embedding while the node-level work of earlier layers runs; reverse: the MLP reverse of
         layer t (which only feeds the final radial gradient) runs beside the rest of the reverse pass.
-        Applied to graphs of at most OVERLAP_MAX_EDGES edges: measured +3..6 % up to 6e5 edges (the
-        per-GPU share of the 100k-atom cell on 4-8 GPUs), neutral at 9e5, and a 4x SLOWDOWN at 1.5e6 edges
-        where the two streams' large grids evict each other's workgroups.
+        Worth 1-2 % of the step.  Every buffer the side stream touches is allocated on the main stream and
+        reused explicitly (double-buffered g_w): `record_stream`-deferred frees of 10-GB blocks made the
+        caching allocator fall back to hipMalloc/hipFree, a 3x slowdown at 100k atoms.
         modal: fidelity channel (name from config['_modal_map'] or index) of a multi-modal model; the
         one-hot inputs of its linears become constant biases, shift/scale rows are selected at load.
         shape has such a kernel (needs mlp_mode 'bf16x6').  Off by default: parity-tested, but at
@@ -357,11 +357,11 @@ class HipForceEngine:
         self._run_groups(lin.groups_T, gy, gx, n, sp.dim_out, sp.dim_in, g, force_acc=accumulate)
         return gx
 
-    def _mlp_fwd(self, L, emb, E):
+    def _mlp_fwd(self, L, emb, E, out=None):
         """radial weights w[E,wn]; returns (w, saved) where saved feeds _mlp_bwd."""
         dims = L.spec.mlp_dims
         if L.fused_mlp:
-            w = self._new(E, dims[3])
+            w = self._new(E, dims[3]) if out is None else out
             _lib.check(self.lib.snet_radial_mlp_fwd(L.mlp_plan, _ptr(emb), E, _ptr(w), _stream()), 'snet_radial_mlp_fwd')
             return w, None
         zs, a = [], emb
@@ -433,15 +433,22 @@ class HipForceEngine:
                     self._side = torch.cuda.Stream(device=self.dev)
                 side = self._side
                 main = torch.cuda.current_stream()
+                # every buffer the side stream touches is allocated on the MAIN stream and stays referenced until
+                # the main stream has waited for the side stream again: no record_stream, hence no deferred frees
+                # (with 10-GB blocks those made the caching allocator fall back to hipMalloc / hipFree)
+                rows_w = g.n_pairs if pairs else E
+                w_bufs = [self._new(rows_w, L_.spec.conv.weight_numel) for L_ in self.layers]
+                wn_max = max(L_.spec.conv.weight_numel for L_ in self.layers)
+                gw_bufs = [self._new(E * wn_max), self._new(E * wn_max)]
+                gw_done = [None, None]
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     for t_, L_ in enumerate(self.layers):
                         with _Span(self, f'radial_mlp_fwd[wn={L_.spec.conv.weight_numel}]'):
-                            w_, _z = self._mlp_fwd(L_, emb_p, g.n_pairs) if pairs else self._mlp_fwd(L_, emb, E)
+                            self._mlp_fwd(L_, emb_p if pairs else emb, rows_w, out=w_bufs[t_])
                         ev = torch.cuda.Event()
                         ev.record(side)
-                        w_.record_stream(main)  # allocated on the side stream, read by the main one
-                        w_ready[t_] = (w_, ev)
+                        w_ready[t_] = (w_bufs[t_], ev)
             d0 = sp.embed.dim_out
             x = self._new(NT, d0)  # ghost layer-0 features depend only on species (model_build.py:383-421)
             _lib.check(lib.snet_embed_rows(_ptr(self.embed_table), _ptr(g.types), _ptr(x), NT, d0, st),
@@ -535,7 +542,12 @@ class HipForceEngine:
                                              ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st), 'snet_gate_bwd')
                 with _Span(self, 'node_linear_bwd'):
                     g_m = self._linear_T(L.si2, g_y, N, g)
-                g_w = self._new(E, ls.conv.weight_numel)
+                if side is not None:  # double-buffered: the MLP reverse of layer t+2 may still be reading this one
+                    if gw_done[t & 1] is not None:
+                        torch.cuda.current_stream().wait_event(gw_done[t & 1])
+                    g_w = gw_bufs[t & 1][:E * ls.conv.weight_numel].view(E, ls.conv.weight_numel)
+                else:
+                    g_w = self._new(E, ls.conv.weight_numel)
                 # layer 0: inputs depend on species only -> no source-row gradient needed
                 g_xe = self._new(E, ls.si1.dim_out) if t > 0 else None
                 with _Span(self, f'conv_bwd_edge[{ls.conv.tag}]'):
@@ -563,7 +575,8 @@ class HipForceEngine:
                     with torch.cuda.stream(side):
                         with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]'):
                             self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
-                    g_w.record_stream(side)
+                        gw_done[t & 1] = torch.cuda.Event()
+                        gw_done[t & 1].record(side)
                 else:
                     with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]'):
                         self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
