@@ -198,7 +198,7 @@ struct snet_model {
   bool overlap = getenv("SNET_NO_OVERLAP") == nullptr;
 };
 
-constexpr int64_t OVERLAP_MAX_EDGES = 1ll << 40;  // no limit (kept as a knob)
+constexpr int64_t OVERLAP_MAX_EDGES = 1000000;  // same policy as engine.py
 
 namespace {
 

@@ -193,7 +193,7 @@ class _Span:
 
 
 class HipForceEngine:
-    OVERLAP_MAX_EDGES = 1 << 40  # no limit (a knob for experiments)
+    OVERLAP_MAX_EDGES = 1_000_000
 
     def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6',
                  linear_mode: str = 'bf16x6', fuse_conv: bool = False, modal=None, overlap: bool = True):
@@ -203,7 +203,10 @@ class HipForceEngine:
         overlap: run the radial MLPs on a second HIP stream -- forward: all layers' weights are produced
         from the edge embedding while the node-level work of earlier layers runs; reverse: the MLP reverse of
         layer t (which only feeds the final radial gradient) runs beside the rest of the reverse pass.
-        Worth 1-2 % of the step.  Every buffer the side stream touches is allocated on the main stream and
+        Applied to graphs of at most OVERLAP_MAX_EDGES edges (the per-GPU share of a 100k-atom cell on
+        4-8 GPUs, and mid-size single-GPU systems).  Above that every kernel fills the GPU by itself: the
+        measured gain shrinks to 0.5-2 % (2.7e6 edges: 58.9 -> 56.9 ms) while per-kernel timings stop being
+        exclusive, so large graphs stay on one stream.  Every buffer the side stream touches is allocated on the main stream and
         reused explicitly (double-buffered g_w): `record_stream`-deferred frees of 10-GB blocks made the
         caching allocator fall back to hipMalloc/hipFree, a 3x slowdown at 100k atoms.
         modal: fidelity channel (name from config['_modal_map'] or index) of a multi-modal model; the
@@ -305,7 +308,9 @@ class HipForceEngine:
             pass
 
     def kernel_times_ms(self) -> Dict[str, List[float]]:
-        """Elapsed ms of every recorded span, grouped by kernel class (call after a device sync)."""
+        """Elapsed ms of every recorded span, grouped by kernel class (call after a device sync).  Classes
+        suffixed '@side' ran on the second stream: their brackets overlap main-stream kernels, so their
+        times are not exclusive and do not add up with the others to the step time."""
         out: Dict[str, List[float]] = {}
         for name, a, b in self.events or []:
             out.setdefault(name, []).append(a.elapsed_time(b))
@@ -444,7 +449,7 @@ class HipForceEngine:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     for t_, L_ in enumerate(self.layers):
-                        with _Span(self, f'radial_mlp_fwd[wn={L_.spec.conv.weight_numel}]'):
+                        with _Span(self, f'radial_mlp_fwd[wn={L_.spec.conv.weight_numel}]@side'):
                             self._mlp_fwd(L_, emb_p if pairs else emb, rows_w, out=w_bufs[t_])
                         ev = torch.cuda.Event()
                         ev.record(side)
@@ -573,7 +578,7 @@ class HipForceEngine:
                 if side is not None:  # g_w is complete on the main stream; its consumer runs beside what follows
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
-                        with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]'):
+                        with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]@side'):
                             self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
                         gw_done[t & 1] = torch.cuda.Event()
                         gw_done[t & 1].record(side)

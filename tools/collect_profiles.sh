@@ -11,8 +11,10 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o r -- $BENCH > $OUT/${TAG}_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -o r -- $BENCH > $OUT/${TAG}_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -o r -- $BENCH > $OUT/${TAG}_write.log 2>&1
+# counter passes with the radial MLPs on the main stream: TCC counters are device-wide, concurrent kernels
+# of a second stream would be charged to whichever dispatch is being sampled
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch -o r -- $BENCH --no-overlap > $OUT/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_write -o r -- $BENCH --no-overlap > $OUT/${TAG}_write.log 2>&1
 cd $ROOT
 cp $(find $OUT/${TAG}_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats.csv
 python tools/pmc_reduce.py $(find $OUT/${TAG}_fetch -name "*counter_collection.csv" | head -1) \
