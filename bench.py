@@ -48,8 +48,11 @@ def parse():
     ap.add_argument('--host', default='python', choices=['python', 'native'],
                     help="who sequences the kernels: the Python host (per-kernel HIP-event timers) or the native "
                          "snet_model_eval sequencer (same kernels; kernel timers then come from an extra untimed pass)")
-    ap.add_argument('--fuse-conv', action='store_true',
-                    help='experimental: radial-MLP last layer inside the forward tensor-product kernels')
+    ap.add_argument('--fused', default='auto', choices=['auto', 'off', 'fwd', 'bwd'],
+                    help="radial-MLP last layer inside the tensor-product kernels (w / g_w never materialised): "
+                         "'auto' = forward and reverse (default), 'off' = separate kernels")
+    ap.add_argument('--terms', type=int, default=3, choices=[1, 2, 3],
+                    help='bf16 terms per operand of the fused in-kernel products (3 = bf16x6, fp32-rounding class)')
     ap.add_argument('--no-overlap', action='store_true', help='radial MLPs on the main stream (no second stream)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-reps', type=int, default=5, help='CPU-baseline sample: cells per axis (5 -> 1000 atoms)')
@@ -150,7 +153,7 @@ def main():
     cfg = model_config(a.model)
     sd = random_state_dict(cfg, seed=0)
     modal = 'mpa' if cfg.get('use_modality') else None
-    eng = HipForceEngine(cfg, sd, device=dev, mlp_mode=a.mlp_mode, fuse_conv=a.fuse_conv, modal=modal, overlap=not a.no_overlap)
+    eng = HipForceEngine(cfg, sd, device=dev, mlp_mode=a.mlp_mode, fused=(False if a.fused == 'off' else a.fused), fused_terms=a.terms, modal=modal, overlap=not a.no_overlap)
 
     pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
     n_atoms = len(pos)

@@ -139,19 +139,37 @@ int snet_conv_plan_dims(const snet_conv_plan *plan, int32_t *dx, int32_t *dout, 
 int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, const float *w, const int32_t *w_row,
                   const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, float *out,
                   void *stream);
-/* Radial MLP's last layer fused into the forward: w = h2 @ W2 is formed on the matrix cores inside the
- * tensor-product kernel (one wavefront per node x 32-channel tile x path group; w lands with
- * lane = channel, accumulator register = edge, exactly the tensor product's operand layout) instead
- * of being written by snet_radial_mlp_fwd and read back -- E*wn*4 bytes less HBM traffic per layer.
- *   h2[E,64]  hidden activations of the MLP (snet_radial_mlp_hidden_fwd, split-precision plan)
- *   w_out     nullable: the weights are also streamed out once for the reverse kernels
- * snet_conv_plan_fused() != 0 iff the shape has such a kernel (every channel multiplicity and path
- * weight offset a multiple of 32); results equal snet_radial_mlp_fwd + snet_conv_fwd to fp32 rounding. */
+/* ---- fused radial weights + tensor product: w[E,wn] and g_w[E,wn] never exist in memory ----------
+ * The contract of the reference's own accelerator plug-ins (flash_helper.py:43, convolution.py:118-141:
+ * no `weight` / `message` tensor survives) taken one step further: the radial MLP's LAST layer
+ * w_e = h2_e @ W2 (64 -> weight_numel, the largest FLOP term of the model) runs on the matrix cores
+ * inside the tensor-product kernels (v_mfma_f32_16x16x32_bf16 tiles whose accumulator layout is the
+ * tensor product's operand layout), and the reverse kernel contracts the weight gradient with W2^T on
+ * the fly.  What crosses HBM per edge is h2[64] in and g_h2[64] out instead of w[wn] and g_w[wn].
+ *   h2[R,64]   hidden activations a2 of the MLP (snet_radial_mlp_hidden_fwd), R = edges or undirected
+ *              pairs; edge e reads row w_row[e] (NULL: row e)
+ *   terms      bf16 terms per operand of the in-kernel products: 3 = bf16x6 (fp32-rounding class,
+ *              default), 2 = bf16x3 (~2^-16 relative), 1 = plain bf16
+ *   tile_ptr   int32[n_dst+1], exclusive scan of ceil(degree/16) (snet_edge_tiles): the reverse kernel
+ *              gives each 16-edge tile of a node's CSR segment to one wavefront
+ * reverse outputs: g_xe[E,dx] (nullable; sum per source with snet_segment_sum_rows), g_h2[E,64]
+ * (overwritten; feed to snet_radial_mlp_hidden_bwd), g_vec[E,3] ACCUMULATED (as snet_conv_bwd_edge_vec).
+ * snet_conv_fused_available() != 0 iff the shape has these kernels (channel multiplicities % 16 == 0). */
+typedef struct snet_fused_plan snet_fused_plan;
 int snet_radial_mlp_hidden_fwd(const snet_mlp_plan *plan, const float *emb, int64_t n_edges, float *h2, void *stream);
-int snet_conv_plan_fused(const snet_conv_plan *plan);
-int snet_conv_fwd_fused(const snet_conv_plan *plan, const snet_mlp_plan *mlp, const float *x, const float *sh,
-                        const float *h2, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
-                        float *out, float *w_out, void *stream);
+int snet_radial_mlp_hidden_bwd(const snet_mlp_plan *plan, const float *emb, const float *g_h2, int64_t n_edges,
+                               float *g_emb, void *stream);
+int snet_conv_fused_available(const snet_conv_plan *plan);
+int snet_fused_plan_create(const snet_conv_plan *plan, const snet_mlp_plan *mlp, int32_t terms, snet_fused_plan **out);
+void snet_fused_plan_destroy(snet_fused_plan *plan);
+int snet_edge_tiles(const int32_t *row_ptr, int64_t n_dst, int32_t *tile_ptr, int64_t *n_tiles, void *stream);
+int snet_conv_fwd_fused(const snet_fused_plan *plan, const float *x, const float *sh, const float *h2,
+                        const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
+                        float *out, void *stream);
+int snet_conv_bwd_fused(const snet_fused_plan *plan, const float *x, const float *sh, const float *dsh,
+                        const float *h2, const int32_t *w_row, const int32_t *row_ptr, const int32_t *src,
+                        const int32_t *tile_ptr, int64_t n_dst, int64_t n_tiles, float scale, const float *g_out,
+                        float *g_xe, float *g_h2, float *g_vec, void *stream);
 /* per-edge gradients given g_out[n_dst,dout]: g_w[E,wn] (overwritten), g_sh[E,nsh] (ACCUMULATED,
  * so one buffer collects all layers) and, if g_xe != NULL, this edge's contribution to the gradient
  * of its source row, g_xe[E,dx] (overwritten; sum it per source node with snet_segment_sum_rows --

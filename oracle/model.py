@@ -458,13 +458,7 @@ class OracleModel:
                          self.p['reduce_input_to_hidden.linear.weight'])
         e = linear_apply(h, self.irreps_hidden, Irreps('1x0e'), self.p['reduce_hidden_to_energy.linear.weight'])
         sc, sh = self.p['rescale_atomic_energy.scale'], self.p['rescale_atomic_energy.shift']
-        if self.n_modal:  # ModalWiseRescale.forward, scale.py:341-363
-            sc = sc[self.modal_idx] if sc.dim() == 2 else sc
-            sh = sh[self.modal_idx] if sh.dim() == 2 else sh
-            return e * sc[types].view(-1, 1) + sh[types].view(-1, 1)
-        if sc.numel() == 1:
-            return e * sc + sh  # Rescale, sevenn/nn/scale.py:53-56
-        return e * sc[types].view(-1, 1) + sh[types].view(-1, 1)  # SpeciesWiseRescale :155-162
+        return rescale_apply(e, types, sc, sh, self.modal_idx if self.n_modal else None)
 
     # ------------------------------------------------------- one brick of a decomposition
     def forward_brick(self, types_all, edge_index, edge_vec, n_local, exchange):
@@ -539,6 +533,18 @@ class OracleModel:
         if keep:
             out['inter'] = {k: v.detach() for k, v in inter.items()}
         return out
+
+
+def rescale_apply(e, types, scale, shift, modal_idx=None):
+    """Rescale (sevenn/nn/scale.py:53-56), SpeciesWiseRescale (:155-162), ModalWiseRescale (:341-363):
+    e[N,1] -> e * scale[(modal,) type] + shift[(modal,) type]; a 2-D table is indexed by the modal first."""
+    if modal_idx is not None:
+        scale = scale[modal_idx] if scale.dim() == 2 else scale
+        shift = shift[modal_idx] if shift.dim() == 2 else shift
+        return e * scale[types].view(-1, 1) + shift[types].view(-1, 1)
+    if scale.numel() == 1:
+        return e * scale + shift
+    return e * scale[types].view(-1, 1) + shift[types].view(-1, 1)
 
 
 def force_virial_from_edge(g, rij, edge_index, n_atoms):

@@ -18,7 +18,7 @@ import subprocess
 import sys
 from typing import List
 
-from . import codegen
+from . import codegen, codegen_fused
 from .shapes import aot_conv_specs
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -85,8 +85,13 @@ def build(jobs: int = 0, force: bool = False, extra_configs=(), verbose: bool = 
         codegen.write_if_changed(path, codegen.gen_conv(spec))
         sources.append(path)
         keep.add(os.path.basename(path))
+        if codegen_fused.fusable(spec):  # fused radial-weight + tensor-product kernels: their own TU
+            fpath = os.path.join(GEN, f'convf_{tag}.hip')
+            codegen.write_if_changed(fpath, codegen_fused.gen_conv_fused(spec))
+            sources.append(fpath)
+            keep.add(os.path.basename(fpath))
     for f in os.listdir(GEN):  # drop stale generated shapes
-        if f.startswith('conv_') and f not in keep:
+        if (f.startswith('conv_') or f.startswith('convf_') or f.startswith('_conv')) and f not in keep:
             os.remove(os.path.join(GEN, f))
     jobs = jobs or min(16, os.cpu_count() or 4)
     if verbose:

@@ -86,20 +86,75 @@ def patch_old_config(cfg: dict) -> dict:
     return cfg
 
 
+W3J_KEY = '{t}_convolution.convolution._compiled_main_left_right._w3j_{l1}_{l2}_{l3}'
+
+
+def fix_old_convolution_signs(cfg: dict, sd: dict) -> dict:
+    """Second half of the reference's `sort_old_convolution` (scripts/backward_compatibility.py:119-137).
+
+    Checkpoints with the pre-0.11 convolution (version < 0.11.0 or 0.11.0.dev0) carry the real Wigner-3j
+    tensors their e3nn build compiled into the tensor product, as buffers
+    `{t}_convolution.convolution._compiled_main_left_right._w3j_{l1}_{l2}_{l3}`.  Some e3nn builds stored a
+    tensor with the opposite global sign of today's `o3.wigner_3j`.  The engine always contracts with
+    today's tensor (its generator is pinned to it, tests/golden/w3j_cp0.npz), so for every path with
+    l1, l2, l3 > 0 whose stored buffer is the negative of the generator's, the path's columns of the
+    radial MLP's last layer are negated (w * (-C) == (-w) * C) -- the weight-column *permutation* half of
+    `sort_old_convolution` is not needed: the column offsets follow the checkpoint's instruction order
+    (model_spec.build_model_spec, `old_convolution_order`).  A buffer that is neither +C nor -C raises.
+
+    Deliberate difference from the reference: a buffer is shared by all paths of one (l1, l2, l3)
+    (O(3) models have e.g. 1o x 1o -> 1e and 1e x 1o -> 1o on `_w3j_1_1_1`); the reference negates the
+    buffer IN PLACE after fixing the first such path (`stct[conv_w3j_key] *= -1` aliases `w3j_old`),
+    so later paths of the same key keep their weights while their tensor has changed sign.  Here every
+    path that reads a flipped buffer is fixed, which preserves the function the checkpoint was trained as.
+    All released checkpoints (SO(3)-only, one path per key) are unaffected by the difference.
+    Returns a state dict without the `_w3j_*` buffers."""
+    from .irreps import real_wigner_3j
+    from .model_spec import build_model_spec, old_convolution_order
+    out = {k: v for k, v in sd.items() if '._w3j_' not in k}
+    if not old_convolution_order(cfg.get('version', '0.0.0')) or len(out) == len(sd):
+        return out   # current instruction order, or a checkpoint stripped of its buffers: nothing to compare
+    spec = build_model_spec(cfg)   # paths in the checkpoint's own (unsorted) instruction order
+    for ls in spec.layers:
+        ww_key = f'{ls.t}_convolution.weight_nn.layer{len(ls.mlp_dims) - 2}.weight'
+        ww = None
+        for p in ls.conv.paths:
+            if not (p.l1 > 0 and p.l2 > 0 and p.l3 > 0):
+                continue
+            key = W3J_KEY.format(t=ls.t, l1=p.l1, l2=p.l2, l3=p.l3)
+            if key not in sd:
+                continue   # checkpoint stripped of buffers: nothing to compare with
+            old = np.asarray(sd[key], dtype=np.float64)
+            now = real_wigner_3j(p.l1, p.l2, p.l3)
+            if old.shape != now.shape:
+                raise ValueError(f'{key}: shape {old.shape} != {now.shape}')
+            if np.allclose(old, now, rtol=1e-5, atol=1e-6):
+                continue
+            if not np.allclose(old, -now, rtol=1e-5, atol=1e-6):
+                raise ValueError(f'{key} is neither +wigner_3j nor -wigner_3j: the checkpoint was written with an '
+                                 'incompatible Clebsch-Gordan convention (e3nn < 0.4?)')
+            if ww is None:
+                ww = np.array(out[ww_key], copy=True)
+            ww[:, p.w_off:p.w_off + p.mul] *= -1.0
+        if ww is not None:
+            out[ww_key] = ww
+    return out
+
+
 def load_reference_checkpoint(path: str):
     """(config, state_dict) from a reference checkpoint file (sevenn/checkpoint.py:286-308:
     a torch pickle holding 'config' and 'model_state_dict'), with the reference's own
-    backward-compatibility steps: old config defaults and old module names.  The third step of the
-    reference, `sort_old_convolution` (weight-column permutation for < 0.11 instruction order), is not
-    needed here: the engine derives the radial-weight column offsets from the instruction order the
-    checkpoint's version implies (model_spec.build_model_spec) instead of re-sorting the weights."""
+    backward-compatibility steps (patch_state_dict_if_old, scripts/backward_compatibility.py:165-184):
+    old config defaults, old module names, and `sort_old_convolution` -- its weight-column permutation is
+    absorbed by deriving the column offsets from the checkpoint's instruction order
+    (model_spec.old_convolution_order), its Wigner-3j sign fix is `fix_old_convolution_signs`."""
     cp = torch.load(path, map_location='cpu', weights_only=False)
     if not isinstance(cp, dict) or 'config' not in cp or 'model_state_dict' not in cp:
         raise ValueError(f'{path} is not a SevenNet checkpoint (config + model_state_dict expected)')
     cfg = patch_old_config(dict(cp['config']))
     sd = {k: v.detach().cpu().numpy() for k, v in map_old_state_dict(cp['model_state_dict']).items()
           if hasattr(v, 'detach')}
-    return cfg, sd
+    return cfg, fix_old_convolution_signs(cfg, sd)
 
 
 class SevenNetCalculator(Calculator):

@@ -15,6 +15,17 @@ static std::vector<const ConvKernels *> &registry() {
 }
 void register_conv(const ConvKernels *k) { registry().push_back(k); }
 
+static std::vector<const FusedKernels *> &fused_registry() {
+  static std::vector<const FusedKernels *> r;
+  return r;
+}
+void register_fused(const FusedKernels *k) { fused_registry().push_back(k); }
+const FusedKernels *find_fused(const char *tag) {
+  for (const FusedKernels *k : fused_registry())
+    if (std::string(k->tag) == tag) return k;
+  return nullptr;
+}
+
 // Small scratch for deterministic two-stage reductions, per host thread and device (grown on
 // demand, never shrunk).  Per-thread because the partial-sum kernel and its final-sum kernel are
 // two launches: two host threads sharing one stream must not interleave on one buffer.
@@ -40,6 +51,11 @@ double *reduce_scratch(int64_t n_doubles, hipStream_t st) {
 
 struct snet_conv_plan {
   const snet::ConvKernels *k;
+};
+struct snet_fused_plan {
+  const snet::FusedKernels *k;
+  int terms;
+  void *slabs;  // device: W2 as pre-split MFMA fragments in the kernels' sub-step order
 };
 
 extern "C" {
@@ -84,20 +100,52 @@ int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, c
   SNET_CHECK_LAUNCH("snet_conv_fwd");
   return 0;
 }
-int snet_conv_plan_fused(const snet_conv_plan *plan) { return plan != nullptr && plan->k->fwd_fused != nullptr; }
-int snet_conv_fwd_fused(const snet_conv_plan *plan, const snet_mlp_plan *mlp, const float *x, const float *sh,
-                        const float *h2, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
-                        float *out, float *w_out, void *stream) {
-  SNET_REQUIRE(plan != nullptr && mlp != nullptr, "snet_conv_fwd_fused: null plan");
-  SNET_REQUIRE(plan->k->fwd_fused != nullptr, "snet_conv_fwd_fused: this tensor-product shape has no fused kernel "
-                                              "(channel multiplicities must be multiples of 32)");
-  SNET_REQUIRE(snet::mlp_plan_w2_split(mlp) != nullptr && snet::mlp_plan_wn(mlp) == plan->k->wn,
-               "snet_conv_fwd_fused: radial-MLP plan must be split-precision with the shape's weight_numel");
-  SNET_REQUIRE(n_dst < (1ll << 31), "snet_conv_fwd_fused: too many nodes");
+int snet_conv_fused_available(const snet_conv_plan *plan) {
+  return plan != nullptr && snet::find_fused(plan->k->tag) != nullptr;
+}
+
+int snet_fused_plan_create(const snet_conv_plan *plan, const snet_mlp_plan *mlp, int32_t terms, snet_fused_plan **out) {
+  SNET_REQUIRE(plan != nullptr && mlp != nullptr && out != nullptr, "snet_fused_plan_create: null argument");
+  SNET_REQUIRE(terms >= 1 && terms <= 3, "snet_fused_plan_create: terms must be 1 (bf16), 2 (bf16x3) or 3 (bf16x6)");
+  const snet::FusedKernels *k = snet::find_fused(plan->k->tag);
+  SNET_REQUIRE(k != nullptr, "snet_fused_plan_create: this tensor-product shape has no fused kernels (channel "
+                             "multiplicities must be multiples of 16)");
+  SNET_REQUIRE(snet::mlp_plan_wn(mlp) == k->wn && snet::mlp_plan_w2_host(mlp) != nullptr,
+               "snet_fused_plan_create: the radial-MLP plan does not match the shape's weight_numel");
+  void *dev = nullptr;
+  if (snet::pack_fused_slabs(snet::mlp_plan_w2_host(mlp), k->wn, k->n_sub, k->sub_cols, terms, &dev) != 0) {
+    snet::set_error("snet_fused_plan_create: device allocation / upload of the W2 fragment stream failed");
+    return 1;
+  }
+  *out = new snet_fused_plan{k, terms, dev};
+  return 0;
+}
+void snet_fused_plan_destroy(snet_fused_plan *p) {
+  if (!p) return;
+  if (p->slabs) (void)hipFree(p->slabs);
+  delete p;
+}
+
+int snet_conv_fwd_fused(const snet_fused_plan *fp, const float *x, const float *sh, const float *h2,
+                        const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
+                        float *out, void *stream) {
+  SNET_REQUIRE(fp != nullptr, "snet_conv_fwd_fused: null plan");
+  SNET_REQUIRE(n_dst < (1ll << 31) / 4, "snet_conv_fwd_fused: too many nodes");
   if (n_dst <= 0) return 0;
-  plan->k->fwd_fused(x, sh, h2, snet::mlp_plan_w2_split(mlp), row_ptr, src, n_dst, scale, out, w_out,
-                     static_cast<hipStream_t>(stream));
+  fp->k->fwd(fp->terms, x, sh, h2, w_row, row_ptr, src, n_dst, fp->slabs, scale, out, static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_conv_fwd_fused");
+  return 0;
+}
+int snet_conv_bwd_fused(const snet_fused_plan *fp, const float *x, const float *sh, const float *dsh, const float *h2,
+                        const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr,
+                        int64_t n_dst, int64_t n_tiles, float scale, const float *g_out, float *g_xe, float *g_h2,
+                        float *g_vec, void *stream) {
+  SNET_REQUIRE(fp != nullptr, "snet_conv_bwd_fused: null plan");
+  SNET_REQUIRE(n_dst < (1ll << 31) && n_tiles < (1ll << 31), "snet_conv_bwd_fused: too many nodes / tiles");
+  if (n_dst <= 0 || n_tiles <= 0) return 0;
+  fp->k->bwd(fp->terms, x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, n_dst, n_tiles, fp->slabs, scale, g_out, g_xe,
+             g_h2, g_vec, static_cast<hipStream_t>(stream));
+  SNET_CHECK_LAUNCH("snet_conv_bwd_fused");
   return 0;
 }
 int snet_conv_bwd_edge(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,

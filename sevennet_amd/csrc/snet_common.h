@@ -44,16 +44,44 @@ struct ConvKernels {
   void (*bwd_node)(const float *sh, const float *w, const int32_t *w_row, const int32_t *col_ptr, const int32_t *eperm,
                    const int32_t *dst, int64_t n_src, float scale, const float *g_out, float *g_x,
                    hipStream_t st);
-  // radial-MLP last layer fused into the forward (nullptr when the shape has no such kernel):
-  // h2[E,64] hidden activations, W2p = snet_gemm_split_pack(W2[64,wn]); w_out nullable
-  void (*fwd_fused)(const float *x, const float *sh, const float *h2, const void *W2p, const int32_t *row_ptr,
-                    const int32_t *src, int64_t n_dst, float scale, float *out, float *w_out, hipStream_t st);
 };
 void register_conv(const ConvKernels *k);
 
-// radial-MLP plan internals needed by the fused tensor-product launch (snet_mlp.hip)
-const void *mlp_plan_w2_split(const snet_mlp_plan *plan);  // nullptr unless the plan is split-precision
+// radial-MLP plan internals needed by the fused tensor-product kernels (snet_mlp.hip)
 int mlp_plan_wn(const snet_mlp_plan *plan);
+
+
+// ---- fused radial-weight + tensor-product kernels (generated convf_<tag>.hip) ------------------------
+// The radial MLP's last layer w = h2 @ W2 is evaluated inside the tensor-product kernels on
+// v_mfma_f32_16x16x32_bf16 (lane & 15 = edge, registers = channels), so neither w[E,wn] nor its
+// gradient g_w[E,wn] exists in memory.  A kernel walks the weight columns in `n_sub` sub-steps of two
+// 16-column tiles; `sub_cols[2 s + tp]` is the first weight column of tile tp of sub-step s (-1: padding).
+// W2 reaches the kernels as a stream of pre-split MFMA A fragments in that order (snet_fused_plan).
+struct FusedKernels {
+  const char *tag;
+  int dx, dout, nsh, wn;
+  int n_sub;
+  const int32_t *sub_cols;
+  // reverse pass of one tile list (snet_edge_tiles): g_xe[E,dx] (nullable), g_h2[E,64], g_vec[E,3] +=
+  void (*bwd)(int nt, const float *x, const float *sh, const float *dsh, const float *h2, const int32_t *w_row,
+              const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, int64_t n_dst, int64_t n_tiles,
+              const void *slabs, float scale, const float *g_out, float *g_xe, float *g_h2, float *g_vec,
+              hipStream_t st);
+  // forward: out[n_dst, dout]
+  void (*fwd)(int nt, const float *x, const float *sh, const float *h2, const int32_t *w_row, const int32_t *row_ptr,
+              const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, hipStream_t st);
+};
+void register_fused(const FusedKernels *k);
+const FusedKernels *find_fused(const char *tag);
+struct FusedRegistrar {
+  explicit FusedRegistrar(const FusedKernels *k) { register_fused(k); }
+};
+// host copy of the radial MLP's pre-normalised last-layer weights W2'[64, wn] (row-major)
+const float *mlp_plan_w2_host(const snet_mlp_plan *plan);
+// W2'[64, wn] -> device stream of 1-KB fragment lines, per sub-step: [tile(2)][kstep(2)][term(nt)] (the
+// 16-column tile as A/B operand of w = h2 @ W2) then [mtile(4)][term(nt)] (W2 rows as A operand of
+// g_h2 = g_w @ W2^T over the sub-step's 32 columns).  Returns 0 on success.
+int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols, int nt, void **dev_out);
 
 struct ConvRegistrar {
   explicit ConvRegistrar(const ConvKernels *k) { register_conv(k); }

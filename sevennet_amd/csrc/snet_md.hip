@@ -224,6 +224,47 @@ extern "C" int snet_edge_pairs(const int32_t *row_ptr, const int32_t *src, const
                          static_cast<hipStream_t>(stream));
 }
 
+// ---- 16-edge tiles of the destination nodes' CSR segments (work list of the fused reverse kernel) --------
+namespace {
+__global__ void tile_count_kernel(const int32_t *__restrict__ row_ptr, int64_t n, int32_t *__restrict__ cnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cnt[i] = (row_ptr[i + 1] - row_ptr[i] + 15) >> 4;
+  else if (i == n) cnt[n] = 0;
+}
+struct TileScratch {
+  DevBuf<int32_t> cnt;
+  DevBuf<char> tmp;
+};
+int edge_tiles_impl(TileScratch &S, const int32_t *row_ptr, int64_t n_dst, int32_t *tile_ptr, int64_t *n_tiles,
+                    hipStream_t st) {
+  *n_tiles = 0;
+  if (n_dst <= 0) return 0;
+  SNET_REQUIRE(n_dst < (1LL << 31) - 1, "snet_edge_tiles: too many nodes");
+  SNET_REQUIRE(S.cnt.ensure(n_dst + 1), "snet_edge_tiles: allocation failed");
+  tile_count_kernel<<<(unsigned)((n_dst + 1 + 255) / 256), 256, 0, st>>>(row_ptr, n_dst, S.cnt.p);
+  SNET_CHECK_LAUNCH("tile_count_kernel");
+  size_t bytes = 0;
+  SNET_REQUIRE(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, S.cnt.p, tile_ptr, (int)(n_dst + 1), st) == hipSuccess,
+               "snet_edge_tiles: scan sizing failed");
+  SNET_REQUIRE(S.tmp.ensure(bytes), "snet_edge_tiles: allocation failed");
+  bytes = S.tmp.cap;
+  SNET_REQUIRE(hipcub::DeviceScan::ExclusiveSum(S.tmp.p, bytes, S.cnt.p, tile_ptr, (int)(n_dst + 1), st) == hipSuccess,
+               "snet_edge_tiles: scan failed");
+  int32_t nt = 0;
+  SNET_REQUIRE(hipMemcpyAsync(&nt, tile_ptr + n_dst, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                   hipStreamSynchronize(st) == hipSuccess,
+               "snet_edge_tiles: readback failed");
+  *n_tiles = nt;
+  return 0;
+}
+}  // namespace
+
+extern "C" int snet_edge_tiles(const int32_t *row_ptr, int64_t n_dst, int32_t *tile_ptr, int64_t *n_tiles, void *stream) {
+  SNET_REQUIRE(row_ptr && tile_ptr && n_tiles, "snet_edge_tiles: null argument");
+  static thread_local TileScratch scratch;  // grow-only, one per host thread
+  return edge_tiles_impl(scratch, row_ptr, n_dst, tile_ptr, n_tiles, static_cast<hipStream_t>(stream));
+}
+
 struct snet_md_host {
   snet_model *model = nullptr;
   DevBuf<double> x;

@@ -584,6 +584,73 @@ __global__ __launch_bounds__(64 * SNET_MLP_BWD_WAVES, SNET_MLP_BWD_OCC) void rad
   }
 }
 
+
+// reverse of the two hidden layers only: g_h2[E,64] = dE/d(h2) (produced by the fused tensor-product reverse
+// kernels, which contract g_w with W2^T on the fly) -> g_emb[E,nb] +=
+__global__ __launch_bounds__(256, 2) void radial_mlp_hidden_bwd_split_kernel(
+    const float *__restrict__ emb, const float *__restrict__ g_h2, int64_t E, int nb, const float *__restrict__ W0,
+    const u32x4 *__restrict__ W1A, const u32x4 *__restrict__ W1A2, const u32x4 *__restrict__ W0A, int act, float cst,
+    float *__restrict__ g_emb) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, li = lane & 31;
+  const int64_t e_lane = ((int64_t)blockIdx.x * 4 + wave) * 32 + li;
+  const bool e_ok = e_lane < E;
+  // transposed layout: lane & 31 = edge, registers = hidden units 32 t + (r & 3) + 8 (r >> 2) + 4 half
+  f32x16 ga2[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e_ok) v = *reinterpret_cast<const f32x4 *>(g_h2 + e_lane * H + 32 * t + 8 * g + 4 * half);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ga2[t][4 * g + i] = v[i];
+    }
+  f32x16 z1[2], z2[2];
+  hidden_forward_split(emb, e_ok ? e_lane : 0, e_ok, nb, W0, W1A, act, cst, lane, z1, z2);
+  f32x16 ga1[2];
+  ga1[0] = zero16();
+  ga1[1] = zero16();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 8 * (q & 1) + i;
+      v[i] = ga2[q >> 1][r] * cst * snet::act_grad(z2[q >> 1][r], act);
+    }
+    const Split3 b = split8(v);
+#pragma unroll
+    for (int to = 0; to < 2; ++to) {
+      bf16x8 a[3];
+      load_frag3(W1A2, to * 4 + q, lane, a);
+      ga1[to] = mfma6(a, b, ga1[to]);
+    }
+  }
+  f32x16 ge = zero16();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 8 * (q & 1) + i;
+      v[i] = ga1[q >> 1][r] * cst * snet::act_grad(z1[q >> 1][r], act);
+    }
+    const Split3 b = split8(v);
+    bf16x8 a[3];
+    load_frag3(W0A, q, lane, a);
+    ge = mfma6(a, b, ge);
+  }
+  if (e_ok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k0 = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (k0 < nb) g_emb[e_lane * nb + k0] += ge[r];
+    }
+  }
+}
+
 }  // namespace
 
 // ---- plan: device copies of the (pre-normalised) weights, fp32 and split/packed -----------------
@@ -592,7 +659,7 @@ struct snet_mlp_plan {
   float cst;
   float *W0 = nullptr, *W1 = nullptr, *W2 = nullptr, *W2T = nullptr;               // fp32 mode
   u32x4 *W1A = nullptr, *W2B = nullptr, *W2A = nullptr, *W1A2 = nullptr, *W0A = nullptr;  // split mode
-  void *W2S = nullptr;  // split mode: W2 as snet_gemm_split_pack fragments (natural k order) for the fused conv
+  std::vector<float> w2_host;  // W2'[64, wn]: source of the fused tensor-product kernels' fragment stream
 };
 
 namespace {
@@ -686,10 +753,8 @@ extern "C" int snet_radial_mlp_plan_create(int32_t nb, int32_t h1, int32_t h2, i
                     const int k0 = lane & 31;
                     return k0 < nb ? w0[(size_t)k0 * H + kmap(f, lane >> 5, i)] : 0.f;
                   }), (void **)&p->W0A);
-    std::vector<unsigned char> packed((size_t)snet_gemm_split_size(H, wn));
-    bad |= snet_gemm_split_pack(w2.data(), H, wn, packed.data());
-    bad |= upload(packed, &p->W2S);
   }
+  p->w2_host = w2;
   if (bad) {
     snet::set_error("snet_radial_mlp_plan_create: device allocation / upload failed");
     delete p;
@@ -702,7 +767,7 @@ extern "C" int snet_radial_mlp_plan_create(int32_t nb, int32_t h1, int32_t h2, i
 extern "C" void snet_radial_mlp_plan_destroy(snet_mlp_plan *p) {
   if (!p) return;
   for (void *d : {(void *)p->W0, (void *)p->W1, (void *)p->W2, (void *)p->W2T, (void *)p->W1A, (void *)p->W2B,
-                  (void *)p->W2A, (void *)p->W1A2, (void *)p->W0A, p->W2S})
+                  (void *)p->W2A, (void *)p->W1A2, (void *)p->W0A})
     if (d) (void)hipFree(d);
   delete p;
 }
@@ -736,8 +801,44 @@ extern "C" int snet_radial_mlp_hidden_fwd(const snet_mlp_plan *p, const float *e
 }
 
 namespace snet {
-const void *mlp_plan_w2_split(const snet_mlp_plan *plan) { return plan ? plan->W2S : nullptr; }
 int mlp_plan_wn(const snet_mlp_plan *plan) { return plan ? plan->wn : 0; }
+const float *mlp_plan_w2_host(const snet_mlp_plan *plan) {
+  return (plan && !plan->w2_host.empty()) ? plan->w2_host.data() : nullptr;
+}
+
+int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols, int nt, void **dev_out) {
+  const int lps = 8 * nt;  // 1-KB lines per sub-step
+  std::vector<uint16_t> out((size_t)n_sub * lps * 64 * 8, 0);
+  auto put = [&](size_t line, int lane, int slot, float v, int term) {
+    uint16_t sp[3];
+    split3(v, sp);
+    out[((line + term) * 64 + lane) * 8 + slot] = sp[term];
+  };
+  for (int s = 0; s < n_sub; ++s) {
+    const size_t base = (size_t)s * lps;
+    for (int lane = 0; lane < 64; ++lane) {
+      const int i = lane & 15, gg = lane >> 4;
+      // w part: tile tp, k-step q: operand row/column i = weight column c0 + i, k slot (gg, t) = hidden 32 q + 8 gg + t
+      for (int tp = 0; tp < 2; ++tp) {
+        const int c0 = sub_cols[2 * s + tp];
+        if (c0 < 0) continue;
+        for (int q = 0; q < 2; ++q)
+          for (int t = 0; t < 8; ++t)
+            for (int term = 0; term < nt; ++term)
+              put(base + (size_t)(tp * 2 + q) * nt, lane, t, w2[(size_t)(32 * q + 8 * gg + t) * wn + c0 + i], term);
+      }
+      // g part: A[i = hidden 16 m + i][k slot (gg, t)] = W2[16 m + i][column of slot], slot t -> tile t >> 2, channel 4 gg + (t & 3)
+      for (int m = 0; m < 4; ++m)
+        for (int t = 0; t < 8; ++t) {
+          const int c0 = sub_cols[2 * s + (t >> 2)];
+          if (c0 < 0) continue;
+          for (int term = 0; term < nt; ++term)
+            put(base + (size_t)4 * nt + (size_t)m * nt, lane, t, w2[(size_t)(16 * m + i) * wn + c0 + 4 * gg + (t & 3)], term);
+        }
+    }
+  }
+  return upload(out, dev_out);
+}
 }  // namespace snet
 
 extern "C" int snet_radial_mlp_bwd(const snet_mlp_plan *p, const float *emb, const float *g_w, int64_t E,
@@ -754,5 +855,18 @@ extern "C" int snet_radial_mlp_bwd(const snet_mlp_plan *p, const float *emb, con
     radial_mlp_bwd_split_kernel<<<(unsigned)grid, 64 * SNET_MLP_BWD_WAVES, 0, st>>>(emb, g_w, E, p->nb, p->wn, p->W0, p->W1A, p->W2A,
                                                                 p->W1A2, p->W0A, p->act, p->cst, g_emb);
   SNET_CHECK_LAUNCH("snet_radial_mlp_bwd");
+  return 0;
+}
+
+extern "C" int snet_radial_mlp_hidden_bwd(const snet_mlp_plan *p, const float *emb, const float *g_h2, int64_t E,
+                                          float *g_emb, void *stream) {
+  SNET_REQUIRE(p != nullptr, "snet_radial_mlp_hidden_bwd: null plan");
+  SNET_REQUIRE(p->mode == 1, "snet_radial_mlp_hidden_bwd: split-precision plans only (mode 1)");
+  if (E <= 0) return 0;
+  const int64_t grid = (E + 127) / 128;
+  SNET_REQUIRE(grid < (1ll << 31), "snet_radial_mlp_hidden_bwd: too many edges");
+  radial_mlp_hidden_bwd_split_kernel<<<(unsigned)grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
+      emb, g_h2, E, p->nb, p->W0, p->W1A, p->W1A2, p->W0A, p->act, p->cst, g_emb);
+  SNET_CHECK_LAUNCH("snet_radial_mlp_hidden_bwd");
   return 0;
 }

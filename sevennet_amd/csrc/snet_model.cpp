@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <string>
 #include <vector>
 
 #include "snet_common.h"
@@ -35,7 +37,12 @@ struct Reader {
     return v;
   }
   std::vector<float> farr(size_t n) {
-    std::vector<float> v(ok ? n : 0);
+    // bounds first: a corrupt count must not reach the allocator (bad_alloc / length_error would cross the C ABI)
+    if (!ok || n > (size_t)(end - p) / 4) {
+      ok = false;
+      return {};
+    }
+    std::vector<float> v(n);
     if (n) get(v.data(), 4 * n);
     return v;
   }
@@ -102,6 +109,7 @@ struct Layer {
   int mlp[4];
   snet_conv_plan *conv = nullptr;
   snet_mlp_plan *mlp_plan = nullptr;
+  snet_fused_plan *fused = nullptr;  // radial-MLP last layer inside the tensor-product kernels (where the shape has them)
   Linear sc, si1, si2;
   std::vector<snet_gate_seg> segs;
 };
@@ -132,6 +140,9 @@ bool read_linear(Reader &r, Linear &L) {
   for (auto &b : L.blocks) {
     b.l = r.i32(); b.in_off = r.i32(); b.mul_in = r.i32(); b.out_off = r.i32(); b.mul_out = r.i32();
     b.species = r.i32(); b.accumulate = r.i32();
+    if (!r.ok || b.l < 0 || b.l > 8 || b.mul_in <= 0 || b.mul_out <= 0 || b.mul_in > (1 << 16) || b.mul_out > (1 << 16) ||
+        b.in_off < 0 || b.out_off < 0 || b.species < -1)
+      return false;
   }
   for (int i = 0; i < nz; ++i) {
     const int off = r.i32(), len = r.i32();
@@ -246,10 +257,15 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
   r.get(magic, 8);
   SNET_REQUIRE(r.ok && memcmp(magic, "SNETMDL2", 8) == 0, "snet_model_load: not a .snet model file");
   auto *m = new snet_model;
+  bool good = false;
+  try {
   m->n_species = r.i32(); m->n_layers = r.i32(); m->lmax = r.i32(); m->normalize = r.i32(); m->n_basis = r.i32();
   m->cutoff_kind = r.i32(); m->poly_p = r.i32(); m->act_radial = r.i32(); m->n_scale = r.i32(); m->d0 = r.i32();
   m->cutoff = r.f32(); m->cutoff_on = r.f32(); m->act_cst = r.f32();
-  bool good = r.ok && m->n_layers > 0 && m->n_layers < 64 && m->n_basis > 0 && m->n_basis <= 16 && m->n_species > 0;
+  good = r.ok && m->n_layers > 0 && m->n_layers < 64 && m->n_basis > 0 && m->n_basis <= 16 && m->n_species > 0 &&
+         m->n_species <= 4096 && m->lmax >= 0 && m->lmax <= 3 && (m->normalize == 0 || m->normalize == 1) &&
+         (m->act_radial == 0 || m->act_radial == 1) && (m->cutoff_kind == 0 || m->cutoff_kind == 1) &&
+         (m->n_scale == 1 || m->n_scale == m->n_species) && m->d0 > 0 && m->d0 <= (1 << 16) && m->cutoff > 0.f;
   if (good) {
     m->coeffs = r.farr(m->n_basis);
     std::vector<float> emb = r.farr((size_t)m->n_species * m->d0), sc = r.farr(m->n_scale), sh = r.farr(m->n_scale);
@@ -264,12 +280,19 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
     L.conv_scale = r.f32();
     for (int i = 0; i < 4; ++i) L.mlp[i] = r.i32();
     if (!r.ok) { good = false; break; }
+    bool dims_ok = L.dx > 0 && L.dmid > 0 && L.gin > 0 && L.dout > 0 && L.wn > 0;
+    for (int i = 0; i < 4; ++i) dims_ok = dims_ok && L.mlp[i] > 0 && L.mlp[i] <= (1 << 16);
+    for (int v : {L.dx, L.dmid, L.gin, L.dout, L.wn}) dims_ok = dims_ok && v <= (1 << 20);
+    if (!dims_ok) { good = false; break; }
     std::vector<float> w0 = r.farr((size_t)L.mlp[0] * L.mlp[1]), w1 = r.farr((size_t)L.mlp[1] * L.mlp[2]),
                        w2 = r.farr((size_t)L.mlp[2] * L.mlp[3]);
     good = r.ok && L.mlp[3] == L.wn;
     if (good && snet_radial_mlp_plan_create(L.mlp[0], L.mlp[1], L.mlp[2], L.mlp[3], w0.data(), w1.data(), w2.data(),
                                             m->act_radial, m->act_cst, 1, &L.mlp_plan)) good = false;
     if (good && snet_conv_plan_create(L.tag, &L.conv)) good = false;
+    if (good && getenv("SNET_NO_FUSED") == nullptr && snet_conv_fused_available(L.conv) &&
+        snet_fused_plan_create(L.conv, L.mlp_plan, 3, &L.fused))
+      good = false;
     good = good && read_linear(r, L.sc) && read_linear(r, L.si1) && read_linear(r, L.si2);
     if (good) {
       const int ns = r.i32();
@@ -290,11 +313,15 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
     good = r.ok && nm >= 0 && nm <= (1 << 20) && (int64_t)(r.end - r.p) == nm;
     if (good) m->meta.assign(reinterpret_cast<const char *>(r.p), (size_t)nm);
   }
+  } catch (const std::exception &e) {  // nothing may propagate through an extern "C" entry point
+    snet::set_error(std::string("exception: ") + e.what());
+    good = false;
+  }
   if (!good) {
     const std::string prev = snet_last_error();
     snet::set_error("snet_model_load: malformed model file or device upload failed" +
                     (prev.empty() ? std::string() : " (" + prev + ")"));
-    delete m;
+    snet_model_destroy(m);  // releases the device allocations and plans created so far
     return 1;
   }
   *out = m;
@@ -328,6 +355,7 @@ extern "C" void snet_model_destroy(snet_model *m) {
     if (L.bias) (void)hipFree(L.bias);
   };
   for (auto &L : m->layers) {
+    snet_fused_plan_destroy(L.fused);
     snet_conv_plan_destroy(L.conv);
     snet_radial_mlp_plan_destroy(L.mlp_plan);
     free_lin(L.sc); free_lin(L.si1); free_lin(L.si2);
@@ -395,7 +423,10 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   SNET_REQUIRE(!pairs || (pair_edge != nullptr && n_pairs > 0 && n_pairs <= E),
                "snet_model_eval: w_row needs pair_edge and 0 < n_pairs <= n_edges");
   const int64_t WR = pairs ? n_pairs : E;  // rows of each layer's radial-weight matrix
-  bool ov = m->overlap && E > 0 && E <= OVERLAP_MAX_EDGES;
+  bool any_fused = false;
+  for (auto &L : m->layers) any_fused |= L.fused != nullptr;
+  // the second stream only carries the separate radial-MLP kernels (same policy as engine.py)
+  bool ov = m->overlap && E > 0 && E <= OVERLAP_MAX_EDGES && !any_fused;
   if (ov && m->side == nullptr) {  // created on first use; any failure just keeps everything on one stream
     bool ok = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming) == hipSuccess &&
@@ -447,14 +478,15 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   add((size_t)WR * nb);
   for (auto &L : m->layers) {
     dmax = dmax > (size_t)L.dout ? dmax : (size_t)L.dout;
-    add((size_t)NT * L.dx); add((size_t)WR * L.wn); add((size_t)N * L.gin);  // saved h, w, y
-    const size_t t = ((size_t)N * L.gin + 64) * 2 + (size_t)N * L.dmid * 2 + (size_t)E * L.wn + (size_t)E * L.dx +
+    add((size_t)NT * L.dx); add(L.fused ? (size_t)WR * 64 : (size_t)WR * L.wn); add((size_t)N * L.gin);  // saved h, w | h2, y
+    const size_t t = ((size_t)N * L.gin + 64) * 2 + (size_t)N * L.dmid * 2 + (size_t)E * (L.fused ? 64 : L.wn) + (size_t)E * L.dx +
                      (size_t)NT * L.dx * 2 + (size_t)N * L.dout + 4096;
     trans = trans > t ? trans : t;
   }
   size_t wn_max = 0;
   for (auto &L : m->layers) wn_max = wn_max > (size_t)L.wn ? wn_max : (size_t)L.wn;
   if (ov) { add((size_t)E * wn_max); add((size_t)E * wn_max); }  // g_w double buffer (its reader runs on the side stream)
+  if (any_fused) add((size_t)N + 64);  // tile_ptr
   add((size_t)NT * dmax * 2 + 256); add((size_t)N * (m->ro1.dim_out + 8) * 2); add(trans + 64 * 1024);
   need += 1 << 20;
   if (m->arena.cap < need) {
@@ -481,12 +513,18 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   float *x = A.f((size_t)NT * dmax), *x2 = A.f((size_t)NT * dmax);
   if ((rc = snet_embed_rows(m->embed, types, x, NT, m->d0, st))) return rc;
 
-  struct Saved { float *h, *w, *y; };
+  struct Saved { float *h, *w, *y; };  // w: radial weights [WR, wn], or (fused layers) hidden activations h2 [WR, 64]
   std::vector<Saved> saved(Lc);
   for (int t = 0; t < Lc; ++t) {
     saved[t].h = A.f((size_t)NT * m->layers[t].dx);
-    saved[t].w = A.f((size_t)WR * m->layers[t].wn);
+    saved[t].w = A.f(m->layers[t].fused ? (size_t)WR * 64 : (size_t)WR * m->layers[t].wn);
     saved[t].y = A.f((size_t)N * m->layers[t].gin);
+  }
+  int32_t *tile_ptr = nullptr;
+  int64_t n_tiles = 0;
+  if (any_fused && E > 0) {  // 16-edge tiles of the CSR segments: work list of the fused reverse kernels
+    tile_ptr = reinterpret_cast<int32_t *>(A.f((size_t)N + 64));
+    if ((rc = snet_edge_tiles(row_ptr, N, tile_ptr, &n_tiles, st))) return rc;
   }
   float *gw_buf[2] = {nullptr, nullptr};
   bool gw_busy[2] = {false, false};
@@ -519,14 +557,20 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
         snet::set_error("snet_model_eval: forward halo callback failed");
         return rc;
       }
-    if (ov)
-      SNET_REQUIRE(hipStreamWaitEvent(st, m->ev_w[t], 0) == hipSuccess, "snet_model_eval: stream ordering failed");
-    else if ((rc = snet_radial_mlp_fwd(L.mlp_plan, emb_w, WR, saved[t].w, st)))
-      return rc;
     float *mid = A.f((size_t)N * L.dmid);
     if (E == 0) SNET_REQUIRE(hipMemsetAsync(mid, 0, (size_t)N * L.dmid * 4, st) == hipSuccess, "snet_model_eval: memset");
-    if ((rc = snet_conv_fwd(L.conv, h, sh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, N, L.conv_scale, mid, st)))
-      return rc;
+    if (L.fused) {  // w = h2 @ W2 is formed inside the tensor-product kernel
+      if ((rc = snet_radial_mlp_hidden_fwd(L.mlp_plan, emb_w, WR, saved[t].w, st))) return rc;
+      if ((rc = snet_conv_fwd_fused(L.fused, h, sh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, N, L.conv_scale, mid, st)))
+        return rc;
+    } else {
+      if (ov)
+        SNET_REQUIRE(hipStreamWaitEvent(st, m->ev_w[t], 0) == hipSuccess, "snet_model_eval: stream ordering failed");
+      else if ((rc = snet_radial_mlp_fwd(L.mlp_plan, emb_w, WR, saved[t].w, st)))
+        return rc;
+      if ((rc = snet_conv_fwd(L.conv, h, sh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, N, L.conv_scale, mid, st)))
+        return rc;
+    }
     float *y = saved[t].y;
     if ((rc = run_linear(m, L.si2, mid, y, N, false, false, st))) return rc;
     if ((rc = snet_gate_fwd(y, sc, x2, N, L.gin, L.dout, L.segs.data(), (int)L.segs.size(), st))) return rc;
@@ -567,10 +611,33 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     if ((rc = snet_gate_bwd(saved[t].y, g_x, g_y, N, L.gin, L.dout, L.segs.data(), (int)L.segs.size(), st))) return rc;
     float *g_m = A.f((size_t)N * L.dmid);
     if ((rc = run_linear(m, L.si2, g_y, g_m, N, true, false, st))) return rc;
+    float *g_xe = t > 0 ? A.f((size_t)E * L.dx) : nullptr;
+    if (L.fused) {  // g_w is contracted with W2^T inside the kernel: only g_h2[E,64] leaves it
+      float *g_h2 = A.f((size_t)E * 64);
+      if (E > 0 && (rc = snet_conv_bwd_fused(L.fused, saved[t].h, sh, dsh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src,
+                                             tile_ptr, N, n_tiles, L.conv_scale, g_m, g_xe, g_h2, g_vec, st)))
+        return rc;
+      if (t > 0) {
+        float *g_h = A.f((size_t)NT * L.dx);
+        if ((rc = snet_segment_sum_rows(g_xe, col_ptr, eperm, NT, L.dx, g_h, st))) return rc;
+        if (NT > N)
+          if ((rc = m->halo_rev(m->halo_user, g_h, NT, N, L.dx, stream))) {
+            snet::set_error("snet_model_eval: reverse halo callback failed");
+            return rc;
+          }
+        if ((rc = snet_radial_mlp_hidden_bwd(L.mlp_plan, emb, g_h2, E, g_emb, st))) return rc;
+        if ((rc = run_linear(m, L.si1, g_h, gx_next, N, true, false, st))) return rc;
+        if (L.sc.present())
+          if ((rc = run_linear(m, L.sc, g_y, gx_next, N, true, true, st))) return rc;
+        std::swap(g_x, gx_next);
+        continue;
+      }
+      if ((rc = snet_radial_mlp_hidden_bwd(L.mlp_plan, emb, g_h2, E, g_emb, st))) return rc;
+      break;  // layer-0 inputs depend on species only
+    }
     float *g_w = ov ? gw_buf[t & 1] : A.f((size_t)E * L.wn);
     if (ov && gw_busy[t & 1])  // the MLP reverse of layer t+2 read this buffer on the side stream
       SNET_REQUIRE(hipStreamWaitEvent(st, m->ev_bwd[t & 1], 0) == hipSuccess, "snet_model_eval: stream ordering failed");
-    float *g_xe = t > 0 ? A.f((size_t)E * L.dx) : nullptr;
     if ((rc = snet_conv_bwd_edge_vec(L.conv, saved[t].h, sh, dsh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, N,
                                      L.conv_scale, g_m, g_w,
                                      g_xe, g_vec, st)))

@@ -78,4 +78,63 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
+// ---- N-term variants for the 16x16x32 tiles of the fused tensor-product kernels --------------------
+// NT = 3: six products of order <= 2 (fp32-rounding class); NT = 2: a0b0 + a0b1 + a1b0 (about 2^-16
+// relative, "bf16x3"); NT = 1: plain bf16 operands.
+template <int NT>
+struct SplitN {
+  bf16x8 t[NT];
+};
+
+template <int NT>
+__device__ __forceinline__ SplitN<NT> splitn8(const float (&v)[8]) {
+  bf16x2 q[NT][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    f32x2 r = {v[2 * p], v[2 * p + 1]};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      q[t][p] = __builtin_convertvector(r, bf16x2);
+      if (t + 1 < NT) r = r - __builtin_convertvector(q[t][p], f32x2);
+    }
+  }
+  SplitN<NT> s;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) s.t[t] = cat4(q[t][0], q[t][1], q[t][2], q[t][3]);
+  return s;
+}
+
+// acc += A * B on v_mfma_f32_16x16x32_bf16, A given as NT packed fragments, B as an NT-term split;
+// smallest products first
+template <int NT>
+__device__ __forceinline__ f32x4 mfma16_split(const bf16x8 (&a)[NT], const SplitN<NT> &b, f32x4 acc) {
+  if constexpr (NT == 3) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b.t[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b.t[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b.t[1], acc, 0, 0, 0);
+  }
+  if constexpr (NT >= 2) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b.t[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b.t[0], acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b.t[0], acc, 0, 0, 0);
+  return acc;
+}
+
+// the same with A as the device-side split and B as packed fragments
+template <int NT>
+__device__ __forceinline__ f32x4 mfma16_split(const SplitN<NT> &a, const bf16x8 (&b)[NT], f32x4 acc) {
+  if constexpr (NT == 3) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.t[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.t[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.t[1], b[1], acc, 0, 0, 0);
+  }
+  if constexpr (NT >= 2) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.t[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.t[1], b[0], acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.t[0], b[0], acc, 0, 0, 0);
+  return acc;
+}
+
 }  // namespace snet

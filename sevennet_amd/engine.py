@@ -59,6 +59,22 @@ class Graph:
     w_row: Optional[torch.Tensor] = None
     pair_edge: Optional[torch.Tensor] = None
     n_pairs: int = 0
+    # 16-edge tiles of the CSR segments (snet_edge_tiles): work list of the fused reverse kernels
+    tile_ptr: Optional[torch.Tensor] = None
+    n_tiles: int = 0
+
+    def tiles(self):
+        """(tile_ptr, n_tiles), built on first use"""
+        if self.tile_ptr is None:
+            lib = _lib.load()
+            dev = self.edge_vec.device
+            with torch.cuda.device(dev):
+                tp = torch.empty(self.n_local + 1, dtype=torch.int32, device=dev)
+                n = C.c_int64()
+                _lib.check(lib.snet_edge_tiles(_ptr(self.row_ptr), self.n_local, _ptr(tp), C.byref(n), _stream()),
+                           'snet_edge_tiles')
+            self.tile_ptr, self.n_tiles = tp, int(n.value)
+        return self.tile_ptr, self.n_tiles
 
     def share_pairs(self):
         """Number the undirected pairs so the radial MLP runs once per pair (in place; returns self)."""
@@ -196,10 +212,14 @@ class HipForceEngine:
     OVERLAP_MAX_EDGES = 1_000_000
 
     def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6',
-                 linear_mode: str = 'bf16x6', fuse_conv: bool = False, modal=None, overlap: bool = True):
+                 linear_mode: str = 'bf16x6', fused='auto', fused_terms: int = 3, modal=None, overlap: bool = True):
         """mlp_mode / linear_mode: 'bf16x6' (split-precision MFMA, fp32-class accuracy, default) or
         'fp32' (exact fp32 MFMA) for the fused radial MLP / the node-level equivariant linears.
-        fuse_conv: run the radial MLP's last layer inside the forward tensor-product kernels where the
+        fused: 'auto' (default) / True / False / 'fwd' / 'bwd' -- run the radial MLP's last layer INSIDE the
+        tensor-product kernels (snet_conv_fwd_fused / snet_conv_bwd_fused): neither w[E,wn] nor g_w[E,wn] is
+        materialised; what is kept per layer is h2[pairs,64].  Needs mlp_mode 'bf16x6' and a shape whose channel
+        multiplicities are multiples of 16 ('auto': used where available; True: required).
+        fused_terms: bf16 terms per operand of the in-kernel products (3 = bf16x6, 2 = bf16x3, 1 = bf16).
         overlap: run the radial MLPs on a second HIP stream -- forward: all layers' weights are produced
         from the edge embedding while the node-level work of earlier layers runs; reverse: the MLP reverse of
         layer t (which only feeds the final radial gradient) runs beside the rest of the reverse pass.
@@ -211,13 +231,14 @@ class HipForceEngine:
         caching allocator fall back to hipMalloc/hipFree, a 3x slowdown at 100k atoms.
         modal: fidelity channel (name from config['_modal_map'] or index) of a multi-modal model; the
         one-hot inputs of its linears become constant biases, shift/scale rows are selected at load.
-        shape has such a kernel (needs mlp_mode 'bf16x6').  Off by default: parity-tested, but at
-        8.3 ms per SevenNet-0 middle layer it is still slower than the separate kernels (2.4 + 2.6 ms);
-        DESIGN.md section 7 has the analysis."""
+        """
         if mlp_mode not in ('bf16x6', 'fp32') or linear_mode not in ('bf16x6', 'fp32'):
             raise ValueError("mlp_mode / linear_mode must be 'bf16x6' or 'fp32'")
+        if fused not in ('auto', True, False, 'fwd', 'bwd'):
+            raise ValueError("fused must be 'auto', True, False, 'fwd' or 'bwd'")
         self.mlp_mode = mlp_mode
         self.linear_mode = linear_mode
+        self.fused_terms = int(fused_terms)
         self.overlap = bool(overlap)
         self._side = None  # second stream, created on first use
         self.events = None  # set to [] to collect (name, start, end) HIP events per kernel class
@@ -278,8 +299,17 @@ class HipForceEngine:
                 plan = C.c_void_p()
                 _lib.check(self.lib.snet_conv_plan_create(ls.conv.tag.encode(), C.byref(plan)), 'snet_conv_plan_create')
                 L.plan = plan
-                L.fused_conv = bool(fuse_conv and L.fused_mlp and mlp_mode == 'bf16x6'
-                                    and self.lib.snet_conv_plan_fused(plan))
+                L.fplan = None
+                can = bool(L.fused_mlp and mlp_mode == 'bf16x6' and self.lib.snet_conv_fused_available(plan))
+                if fused is True and not can:
+                    raise RuntimeError(f'layer {ls.t}: no fused tensor-product kernels for this shape / mlp_mode')
+                if fused is not False and can:
+                    fpl = C.c_void_p()
+                    _lib.check(self.lib.snet_fused_plan_create(plan, L.mlp_plan, self.fused_terms, C.byref(fpl)),
+                               'snet_fused_plan_create')
+                    L.fplan = fpl
+                L.fused_fwd = L.fplan is not None and fused in ('auto', True, 'fwd')
+                L.fused_bwd = L.fplan is not None and fused in ('auto', True, 'bwd')
                 segs = (_lib.GateSeg * len(ls.gate.segs))()
                 inv_act = {v: k for k, v in ACT_ID.items()}
                 for i, s in enumerate(ls.gate.segs):
@@ -301,6 +331,8 @@ class HipForceEngine:
     def __del__(self):
         try:
             for L in getattr(self, 'layers', []):
+                if getattr(L, 'fplan', None) is not None:
+                    self.lib.snet_fused_plan_destroy(L.fplan)
                 self.lib.snet_conv_plan_destroy(L.plan)
                 if getattr(L, 'mlp_plan', None) is not None:
                     self.lib.snet_radial_mlp_plan_destroy(L.mlp_plan)
@@ -433,7 +465,9 @@ class HipForceEngine:
             # enqueued now and the main stream waits for layer t's event right before its tensor product
             side = None
             w_ready = {}
-            if self.overlap and E <= self.OVERLAP_MAX_EDGES and all(L.fused_mlp and not L.fused_conv for L in self.layers):
+            any_fused = any(L.fused_fwd or L.fused_bwd for L in self.layers)
+            tile_ptr, n_tiles = g.tiles() if any(L.fused_bwd for L in self.layers) and E > 0 else (None, 0)
+            if self.overlap and E <= self.OVERLAP_MAX_EDGES and not any_fused and all(L.fused_mlp for L in self.layers):
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=self.dev)
                 side = self._side
@@ -482,22 +516,14 @@ class HipForceEngine:
                 m = self._new(N, dmid)
                 if E == 0:
                     m.zero_()
-                if L.fused_conv:
-                    # last MLP layer inside the tensor-product kernel: w is written once, never read back here
-                    h2 = self._new(E, 64)
-                    w, zs = self._new(E, ls.conv.weight_numel), None
+                h2 = w = zs = None
+                rows_w = g.n_pairs if pairs else E
+                if L.fused_fwd or L.fused_bwd:  # hidden activations of the radial MLP, one row per pair
+                    h2 = self._new(rows_w, 64)
                     with _Span(self, 'radial_mlp_hidden_fwd'):
-                        _lib.check(lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb), E, _ptr(h2), st),
-                                   'snet_radial_mlp_hidden_fwd')
-                    if pending is not None:
-                        with _Span(self, 'halo_fwd'):
-                            halo.forward_finish(pending)
-                    with _Span(self, f'conv_fwd_fused[{ls.conv.tag}]'):
-                        _lib.check(lib.snet_conv_fwd_fused(L.plan, L.mlp_plan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.row_ptr),
-                                                           _ptr(g.src), N, L.scale, _ptr(m), _ptr(w), st),
-                                   'snet_conv_fwd_fused')
-                    del h2
-                else:
+                        _lib.check(lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb_p if pairs else emb), rows_w,
+                                                                  _ptr(h2), st), 'snet_radial_mlp_hidden_fwd')
+                if not (L.fused_fwd and L.fused_bwd):  # someone still reads w[rows, wn]
                     if side is not None:
                         (w, ev), zs = w_ready.pop(t), None
                         torch.cuda.current_stream().wait_event(ev)
@@ -505,19 +531,26 @@ class HipForceEngine:
                         with _Span(self, f'radial_mlp_fwd[wn={ls.conv.weight_numel}]'):
                             # one weight row per undirected pair when the graph carries the pair map
                             w, zs = self._mlp_fwd(L, emb_p, g.n_pairs) if pairs else self._mlp_fwd(L, emb, E)
-                    if pending is not None:
-                        with _Span(self, 'halo_fwd'):
-                            halo.forward_finish(pending)
+                if pending is not None:
+                    with _Span(self, 'halo_fwd'):
+                        halo.forward_finish(pending)
+                if L.fused_fwd:
+                    with _Span(self, f'conv_fwd_fused[{ls.conv.tag}]'):
+                        _lib.check(lib.snet_conv_fwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(w_row), _ptr(g.row_ptr),
+                                                           _ptr(g.src), N, L.scale, _ptr(m), st), 'snet_conv_fwd_fused')
+                else:
                     with _Span(self, f'conv_fwd[{ls.conv.tag}]'):
                         _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(w_row), _ptr(g.row_ptr),
                                                      _ptr(g.src), N, L.scale, _ptr(m), st), 'snet_conv_fwd')
+                if L.fused_bwd:
+                    w = None  # the reverse pass rebuilds its weight tiles from h2
                 with _Span(self, 'node_linear_fwd'):
                     y = self._linear(L.si2, m, N, g)
                 xo = self._new(N, ls.gate.irreps_out.dim)
                 # y += self-connection happens inside the gate kernel (in place: y is kept for the reverse pass)
                 _lib.check(lib.snet_gate_fwd(_ptr(y), _ptr(sc), _ptr(xo), N, ls.gate.irreps_in.dim,
                                              ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st), 'snet_gate_fwd')
-                saved.append((h, w, zs, y))
+                saved.append((h, w, zs, y, h2))
                 if keep:
                     inter[f'{t}_si1'], inter[f'{t}_conv'], inter[f'{t}_gate_in'], inter[f'{t}_x'] = h[:N], m, y, xo
                 x = xo
@@ -541,25 +574,34 @@ class HipForceEngine:
             for t in range(len(self.layers) - 1, -1, -1):
                 L = self.layers[t]
                 ls = L.spec
-                h, w, zs, y = saved[t]
+                h, w, zs, y, h2 = saved[t]
                 g_y = self._new(N, ls.gate.irreps_in.dim)
                 _lib.check(lib.snet_gate_bwd(_ptr(y), _ptr(g_x), _ptr(g_y), N, ls.gate.irreps_in.dim,
                                              ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st), 'snet_gate_bwd')
                 with _Span(self, 'node_linear_bwd'):
                     g_m = self._linear_T(L.si2, g_y, N, g)
-                if side is not None:  # double-buffered: the MLP reverse of layer t+2 may still be reading this one
-                    if gw_done[t & 1] is not None:
-                        torch.cuda.current_stream().wait_event(gw_done[t & 1])
-                    g_w = gw_bufs[t & 1][:E * ls.conv.weight_numel].view(E, ls.conv.weight_numel)
-                else:
-                    g_w = self._new(E, ls.conv.weight_numel)
                 # layer 0: inputs depend on species only -> no source-row gradient needed
                 g_xe = self._new(E, ls.si1.dim_out) if t > 0 else None
-                with _Span(self, f'conv_bwd_edge[{ls.conv.tag}]'):
-                    _lib.check(lib.snet_conv_bwd_edge_vec(L.plan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(w),
-                                                          _ptr(None if L.fused_conv else w_row), _ptr(g.row_ptr),
-                                                          _ptr(g.src), N, L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_xe),
-                                                          _ptr(g_vec), st), 'snet_conv_bwd_edge_vec')
+                g_w = g_h2 = None
+                if L.fused_bwd:
+                    g_h2 = self._new(E, 64)
+                    with _Span(self, f'conv_bwd_fused[{ls.conv.tag}]'):
+                        if E > 0:
+                            _lib.check(lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(w_row),
+                                                               _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), N, n_tiles, L.scale,
+                                                               _ptr(g_m), _ptr(g_xe), _ptr(g_h2), _ptr(g_vec), st),
+                                       'snet_conv_bwd_fused')
+                else:
+                    if side is not None:  # double-buffered: the MLP reverse of layer t+2 may still be reading this one
+                        if gw_done[t & 1] is not None:
+                            torch.cuda.current_stream().wait_event(gw_done[t & 1])
+                        g_w = gw_bufs[t & 1][:E * ls.conv.weight_numel].view(E, ls.conv.weight_numel)
+                    else:
+                        g_w = self._new(E, ls.conv.weight_numel)
+                    with _Span(self, f'conv_bwd_edge[{ls.conv.tag}]'):
+                        _lib.check(lib.snet_conv_bwd_edge_vec(L.plan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(w), _ptr(w_row),
+                                                              _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(g_m), _ptr(g_w),
+                                                              _ptr(g_xe), _ptr(g_vec), st), 'snet_conv_bwd_edge_vec')
                 # the source-row gradient goes first so that its ghost rows can travel to their owners while
                 # the radial MLP's reverse pass (independent of them) runs
                 pending = None
@@ -575,7 +617,11 @@ class HipForceEngine:
                                 pending = halo.reverse_start(g_h, N)
                             else:
                                 halo.reverse(g_h, N)
-                if side is not None:  # g_w is complete on the main stream; its consumer runs beside what follows
+                if L.fused_bwd:
+                    with _Span(self, 'radial_mlp_hidden_bwd'):
+                        _lib.check(lib.snet_radial_mlp_hidden_bwd(L.mlp_plan, _ptr(emb), _ptr(g_h2), E, _ptr(g_emb), st),
+                                   'snet_radial_mlp_hidden_bwd')
+                elif side is not None:  # g_w is complete on the main stream; its consumer runs beside what follows
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
                         with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]@side'):
@@ -585,7 +631,7 @@ class HipForceEngine:
                 else:
                     with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]'):
                         self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
-                del g_w
+                del g_w, g_h2
                 if t == 0:
                     break
                 if pending is not None:

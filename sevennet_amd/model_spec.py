@@ -351,6 +351,16 @@ def _vt(v: str):
     return tuple(int(t) for t in str(v).split('.')[:3] if t.isdigit())
 
 
+def old_convolution_order(version) -> bool:
+    """True for checkpoints whose convolution instructions (and radial-weight columns) are in the
+    pre-0.11 generation order: version < 0.11.0, or exactly `0.11.0.dev0`
+    (patch_state_dict_if_old, sevenn/scripts/backward_compatibility.py:165-184)."""
+    toks = str(version).split('.')
+    vs = _vt(version)
+    suffix = toks[3] if len(toks) == 4 else ''
+    return vs < (0, 11, 0) or (vs == (0, 11, 0) and suffix == 'dev0')
+
+
 def build_model_spec(config: dict) -> ModelSpec:
     cfg = dict(DEFAULT_CONFIG)
     cfg.update(config)
@@ -372,7 +382,7 @@ def build_model_spec(config: dict) -> ModelSpec:
     lmax_node = cfg['lmax_node'] if cfg['lmax_node'] > 0 else cfg['lmax']
     irreps_sh = Irreps.spherical_harmonics(lmax_edge, -1 if cfg['is_parity'] else 1)
     legacy = bool(cfg.get('_legacy_v08', False))
-    sort_by_out = _vt(cfg['version']) >= (0, 11, 0)
+    sort_by_out = not old_convolution_order(cfg['version'])
     manual = cfg['irreps_manual']
     if manual is not False:
         manual = [Irreps(s) for s in manual]

@@ -7,7 +7,13 @@ from helpers import irmul_to_mulir, load_ts_golden, oracle_model, synthetic_syst
 
 pytestmark = pytest.mark.gpu
 
-F_TOL = 1e-4  # eV/A, BASELINE.json north_star tolerance
+F_TOL = 1e-4  # eV/A, BASELINE.json north_star tolerance (absolute)
+
+
+def f_tol(scale):
+    """absolute 1e-4 eV/A up to 30 eV/A force scale (fp32 rounding of the reference's own path is
+    ~3e-6 relative); only synthetic-weight systems with larger forces get the proportional bound"""
+    return F_TOL * max(1.0, float(scale) / 30.0)
 
 
 def _engine(cfg, sd):
@@ -39,7 +45,7 @@ def _compare(eng, out, ref, n, rel=3e-5, check_inter=True):
     _close(out['atomic_energy'], ref['atomic_energy'], rel, 5e-6, 'atomic_energy')
     _close(out['dE_dr'], ref['dE_dr'], rel, 1e-8, 'dE_dr')
     _close(out['forces'], ref['forces'], rel, 1e-8, 'forces')
-    assert np.abs(out['forces'].cpu().numpy() - ref['forces'].numpy()).max() < F_TOL * max(1.0, ref['forces'].abs().max().item())
+    assert np.abs(out['forces'].cpu().numpy() - ref['forces'].numpy()).max() < f_tol(ref['forces'].abs().max().item())
     _close(out['virial'], ref['virial'], rel, 1e-7, 'virial')
     _close(out['atomic_virial'], ref['atomic_virial'], rel, 1e-8, 'atomic_virial')
     if check_inter and 'inter' in out:
@@ -469,7 +475,37 @@ def test_sevennet_0_full_size_equals_tiled_small_cell(n_tile):
     F = out['forces'].cpu().numpy().reshape(-1, 8, 3)
     Ea = out['atomic_energy'].cpu().numpy().reshape(-1, 8)
     scale = max(1.0, np.abs(f_unit).max())
-    assert np.abs(F - f_unit[None]).max() < F_TOL * scale
+    assert np.abs(F - f_unit[None]).max() < f_tol(scale)
     assert np.abs(Ea - e_unit[None]).max() < 1e-5 * max(1.0, np.abs(e_unit).max())
     assert abs(float(out['energy'].cpu()) / n_big - float(ref['energy']) / 64) < 1e-6
     assert np.abs(out['forces'].cpu().numpy().astype(np.float64).sum(0)).max() < 1e-3 * scale
+
+
+@pytest.mark.parametrize('model', ['sevennet_0', 'sevennet_l3i5'])
+def test_fused_engine_equals_separate_kernels(model):
+    """whole step with the radial MLP's last layer inside the tensor-product kernels (no w / g_w in memory)
+    == the separate-kernel path on the same graph: energy, forces, dE/dr, virial"""
+    from bench import model_config
+    from sevennet_amd.engine import HipForceEngine, build_graph
+    from sevennet_amd.neighbor import diamond_cubic, neighbor_list
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = model_config(model)
+    sd = random_state_dict(cfg, 3)
+    pos, cell = diamond_cubic(5.431, (3, 3, 3), 0.08, 5)
+    ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
+    g = build_graph(np.zeros(len(pos), np.int64), ei, ev, device='cuda:0')
+    a = HipForceEngine(cfg, sd, device='cuda:0', fused=True)
+    assert all(L.fused_fwd and L.fused_bwd for L in a.layers)
+    b = HipForceEngine(cfg, sd, device='cuda:0', fused=False)
+    ra, rb = a.compute(g), b.compute(g)
+    torch.cuda.synchronize()
+    n = len(pos)
+    assert abs(ra['energy'].item() - rb['energy'].item()) / n < 2e-6
+    fs = max(1.0, rb['forces'].abs().max().item())
+    assert (ra['forces'] - rb['forces']).abs().max().item() < 2e-5 * fs
+    assert (ra['dE_dr'] - rb['dE_dr']).abs().max().item() < 2e-5 * max(1.0, rb['dE_dr'].abs().max().item())
+    assert (ra['virial'] - rb['virial']).abs().max().item() < 2e-5 * max(1.0, rb['virial'].abs().max().item())
+    # mixed modes agree too
+    for mode in ('fwd', 'bwd'):
+        rc = HipForceEngine(cfg, sd, device='cuda:0', fused=mode).compute(g)
+        assert (rc['forces'] - rb['forces']).abs().max().item() < 2e-5 * fs

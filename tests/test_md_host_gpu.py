@@ -1,5 +1,6 @@
 """GPU: snet_md_compute -- the LAMMPS-facing host (neighbor list in, forces accumulated out) --
-against the Python-hosted engine on the same periodic system.  The fake LAMMPS domain below has
+against the fp64 CPU oracle on the same periodic system (energies, forces, LAMMPS-order virials of
+pair_e3gnn.cpp:206-270: xx,yy,zz,xy,xz,yz = model components [0,1,2,3,5,4], :254-255).  The fake LAMMPS domain below has
 what a pair style sees: owned atoms, ghost images with the owners' tags, a FULL neighbor list
 built with a skin (so it holds pairs beyond the cutoff), special-bond bits, a permuted ilist."""
 import ctypes as C
@@ -90,12 +91,15 @@ class MdHost:
                     n_nodes=nn.value, n_edges=ne.value)
 
 
+F_TOL = 1e-4  # eV/A, absolute (BASELINE.json north_star)
+
+
 def _reference(cfg, sd, types, ei, ev):
-    from sevennet_amd.engine import HipForceEngine, build_graph
-    eng = HipForceEngine(cfg, sd, device='cuda:0')
-    out = eng.compute(build_graph(types, ei, ev, device='cuda:0', num_species=eng.spec.num_species), want_atomic_virial=True)
-    torch.cuda.synchronize()
-    return {k: v.cpu().numpy() for k, v in out.items()}
+    """fp64 oracle: OracleModel.forward + force_virial_from_edge (force_output.py:171-230 restated)"""
+    from helpers import oracle_model
+    out = oracle_model(cfg, sd).forward(np.asarray(types), np.asarray(ei), np.asarray(ev, np.float64))
+    return {k: (v.detach().numpy().reshape(1) if k == 'energy' else v.detach().numpy()) for k, v in out.items()
+            if k in ('energy', 'forces', 'atomic_energy', 'virial', 'atomic_virial')}
 
 
 def _setup(case):
@@ -127,13 +131,13 @@ def test_md_host_serial_matches_engine(case):
         assert out['n_edges'] == ei.shape[1] and out['n_nodes'] == n
         fs = np.abs(ref['forces']).max()
         assert abs(out['energy'] - float(ref['energy'][0])) <= 2e-6 * abs(float(ref['energy'][0])) + 1e-6
-        assert np.abs(out['f'][:n] - ref['forces']).max() <= max(1e-6, 2e-5 * fs)
+        assert np.abs(out['f'][:n] - ref['forces']).max() <= min(F_TOL, max(1e-6, 3e-5 * fs))
         assert np.abs(out['f'][n:]).max() == 0.0        # ghosts are aliased, never written
         v = ref['virial'][[0, 1, 2, 3, 5, 4]]           # model xx yy zz xy yz zx -> LAMMPS xx yy zz xy xz yz
-        assert np.abs(out['virial'] - v).max() <= max(1e-6, 2e-5 * np.abs(v).max())
-        assert np.abs(out['eatom'][:n] - ref['atomic_energy']).max() <= max(1e-6, 2e-5 * np.abs(ref['atomic_energy']).max())
+        assert np.abs(out['virial'] - v).max() <= max(1e-6, 3e-5 * np.abs(v).max())
+        assert np.abs(out['eatom'][:n] - ref['atomic_energy']).max() <= max(5e-6, 3e-5 * np.abs(ref['atomic_energy']).max())
         va = ref['atomic_virial'][:, [0, 1, 2, 3, 5, 4]]
-        assert np.abs(out['vatom'][:n] - va).max() <= max(1e-6, 2e-5 * np.abs(va).max())
+        assert np.abs(out['vatom'][:n] - va).max() <= max(1e-6, 3e-5 * np.abs(va).max())
     # results are ADDED to the host arrays, and a second call out of the same workspace is identical
     again = host.compute(x, tag, nlocal, rows, ty_all)
     first = host.compute(x, tag, nlocal, rows, ty_all)
@@ -233,10 +237,10 @@ def test_md_host_ghost_nodes_two_ranks_equal_single_process():
         np.add.at(Ea, tag[:nlocal] - 1, out['eatom'][:nlocal])
         e_tot += out['energy']; vir += out['virial']
     assert abs(e_tot - float(ref['energy'][0])) <= 2e-6 * abs(float(ref['energy'][0]))
-    assert np.abs(F - ref['forces']).max() <= max(1e-6, 2e-5 * np.abs(ref['forces']).max())
-    assert np.abs(Ea - ref['atomic_energy']).max() <= max(1e-6, 2e-5 * np.abs(ref['atomic_energy']).max())
+    assert np.abs(F - ref['forces']).max() <= min(F_TOL, max(1e-6, 3e-5 * np.abs(ref['forces']).max()))
+    assert np.abs(Ea - ref['atomic_energy']).max() <= max(5e-6, 3e-5 * np.abs(ref['atomic_energy']).max())
     v = ref['virial'][[0, 1, 2, 3, 5, 4]]
-    assert np.abs(vir - v).max() <= max(1e-6, 2e-5 * np.abs(v).max())
+    assert np.abs(vir - v).max() <= max(1e-6, 3e-5 * np.abs(v).max())
 
 
 def test_md_host_isolated_atoms_no_edges():

@@ -109,3 +109,61 @@ def test_old_checkpoint_names_and_config_defaults(tmp_path):
     torch.save({'config': dict(cfg, optimize_by_reduce=False), 'model_state_dict': old}, p)
     with pytest.raises(ValueError, match='optimize_by_reduce'):
         load_reference_checkpoint(str(p))
+
+
+def test_old_checkpoint_w3j_sign_fix(tmp_path):
+    """sort_old_convolution's Wigner-3j sign fix (scripts/backward_compatibility.py:119-137): a pre-0.11
+    checkpoint whose stored `_w3j_l1_l2_l3` buffer is the negative of today's tensor gets the radial-weight
+    columns of the paths that read it negated -- so a checkpoint with (buffer, columns) both negated loads to
+    the SAME weights as the original; `0.11.0.dev0` counts as old (:176-183); a buffer that is neither
+    +C nor -C is refused."""
+    import json
+    import torch
+    from helpers import GOLDEN
+    from sevennet_amd.calculator import W3J_KEY, fix_old_convolution_signs, load_reference_checkpoint
+    from sevennet_amd.model_spec import build_model_spec, old_convolution_order
+    assert old_convolution_order('0.10.0') and old_convolution_order('0.9.3') and old_convolution_order('0.11.0.dev0')
+    assert not old_convolution_order('0.11.0') and not old_convolution_order('0.11.0.dev1') and not old_convolution_order('0.12.1')
+    d = np.load(f'{GOLDEN}/cp0_state.npz')
+    w3 = np.load(f'{GOLDEN}/w3j_cp0.npz')
+    cfg = json.loads(str(d['__config__']))
+    assert old_convolution_order(cfg['version'])           # cp_0.pth is 0.10.0
+    spec = build_model_spec(cfg)
+    sd = {k: d[k] for k in d.files if not k.startswith('__')}
+    for ls in spec.layers:                                  # the buffers e3nn stored, as in the real file
+        for key in w3.files:
+            l1, l2, l3 = key.split('_')
+            sd[W3J_KEY.format(t=ls.t, l1=l1, l2=l2, l3=l3)] = w3[key]
+    base = fix_old_convolution_signs(cfg, sd)
+    assert not any('_w3j_' in k for k in base)
+    for k in base:                                          # stored tensors == today's: nothing changes
+        assert np.array_equal(base[k], sd[k]), k
+    # flip one tensor of layer 1 together with the columns of every path that reads it
+    flipped = {k: np.array(v, copy=True) for k, v in sd.items()}
+    ls = spec.layers[1]
+    key = W3J_KEY.format(t=ls.t, l1=1, l2=1, l3=1)
+    flipped[key] *= -1
+    ww = f'{ls.t}_convolution.weight_nn.layer2.weight'
+    hit = [p for p in ls.conv.paths if (p.l1, p.l2, p.l3) == (1, 1, 1)]
+    assert len(hit) >= 1                                    # every path that reads the buffer (O(3) models can have several)
+    for p in hit:
+        flipped[ww][:, p.w_off:p.w_off + p.mul] *= -1
+    assert not np.array_equal(flipped[ww], sd[ww])
+    fixed = fix_old_convolution_signs(cfg, flipped)
+    for k in base:
+        assert np.array_equal(fixed[k], base[k]), k         # bit-identical weights -> bit-identical forces
+    # through the file loader, and the version gate
+    ck = tmp_path / 'flipped.pth'
+    torch.save({'config': cfg, 'model_state_dict': {k: torch.as_tensor(v) for k, v in flipped.items()}}, ck)
+    _, sd2 = load_reference_checkpoint(str(ck))
+    assert np.array_equal(sd2[ww], base[ww])
+    torch.save({'config': dict(cfg, version='0.11.0.dev0'), 'model_state_dict': {k: torch.as_tensor(v) for k, v in flipped.items()}}, ck)
+    _, sd3 = load_reference_checkpoint(str(ck))
+    assert np.array_equal(sd3[ww], base[ww])
+    torch.save({'config': dict(cfg, version='0.11.0'), 'model_state_dict': {k: torch.as_tensor(v) for k, v in flipped.items()}}, ck)
+    _, sd4 = load_reference_checkpoint(str(ck))
+    assert np.array_equal(sd4[ww], flipped[ww])             # current order: buffers are not consulted
+    bad = dict(flipped)
+    bad[key] = bad[key] * 0.5
+    with pytest.raises(ValueError, match='neither'):
+        fix_old_convolution_signs(cfg, bad)

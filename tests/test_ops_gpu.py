@@ -247,59 +247,113 @@ def test_conv_plugin_vs_oracle_autograd(cfg_name):
         assert err < 3e-5 * max(1.0, b.abs().max().item()), (name, err)
 
 
-@pytest.mark.parametrize('layer', [0, 1, 4])
-def test_conv_fwd_fused_matches_separate_kernels(layer):
-    """radial-MLP last layer inside the tensor-product kernel == snet_radial_mlp_fwd + snet_conv_fwd
-    (same split-precision products, so w agrees to the last bits and out to fp32 summation order);
-    nodes with 0, 1, 31, 32, 33 and 70 edges exercise the 32-row passes"""
-    from sevennet_amd.model_spec import build_model_spec, sevennet_0_config
-    L, lib = _lib()
-    dev = 'cuda:0'
-    ls = build_model_spec(sevennet_0_config()).layers[layer]
-    spec = ls.conv
+def _fused_case(model, layer, seed, pairs):
+    """random inputs for one convolution shape: ragged degrees (0, 1, 15, 16, 17, 31, 32, 33, 70 ...),
+    ghost source rows, optional pair-shared radial rows (w_row)"""
+    from sevennet_amd.model_spec import build_model_spec, sevennet_0_config, sevennet_l3i5_config
+    cfg = {'sevennet_0': sevennet_0_config, 'sevennet_l3i5': sevennet_l3i5_config}[model]()
+    ms = build_model_spec(cfg)
+    spec = ms.layers[layer].conv
     nb, wn, dx, dout, nsh = 8, spec.weight_numel, spec.irreps_x.dim, spec.irreps_out.dim, spec.irreps_sh.dim
-    g = torch.Generator().manual_seed(40 + layer)
-    deg = torch.tensor([0, 1, 31, 32, 33, 70, 0, 28, 28, 5] + [28] * 30)
+    g = torch.Generator().manual_seed(seed)
+    deg = torch.tensor([0, 1, 15, 16, 17, 31, 32, 33, 70, 0, 28, 28, 5] + [28] * 23 + [0])
     N = len(deg)
     row_ptr = torch.zeros(N + 1, dtype=torch.int32)
     row_ptr[1:] = torch.cumsum(deg, 0)
     E = int(row_ptr[-1])
     NT = N + 7  # ghost rows: sources only
     src = torch.randint(0, NT, (E,), generator=g).to(torch.int32)
-    x = torch.randn(NT, dx, generator=g).to(dev)
-    sh = torch.randn(E, nsh, generator=g).to(dev)
-    emb = torch.randn(E, nb, generator=g).to(dev)
-    W0 = (torch.randn(nb, 64, generator=g) / nb ** 0.5).contiguous()
-    W1 = (torch.randn(64, 64, generator=g) / 8).contiguous()
-    W2 = (torch.randn(64, wn, generator=g) / 8).contiguous()
+    R = E
+    w_row = None
+    if pairs:  # several edges share one radial row, in scrambled order
+        R = E // 2 + 3
+        w_row = torch.randint(0, R, (E,), generator=g).to(torch.int32)
+    return dict(spec=spec, nb=nb, wn=wn, dx=dx, dout=dout, nsh=nsh, N=N, NT=NT, E=E, R=R, row_ptr=row_ptr, src=src,
+                w_row=w_row, x=torch.randn(NT, dx, generator=g), sh=torch.randn(E, nsh, generator=g),
+                dsh=torch.randn(E, nsh * 3, generator=g), emb=torch.randn(R, nb, generator=g),
+                g_out=torch.randn(N, dout, generator=g),
+                W0=(torch.randn(nb, 64, generator=g) / nb ** 0.5).contiguous(),
+                W1=(torch.randn(64, 64, generator=g) / 8).contiguous(),
+                W2=(torch.randn(64, wn, generator=g) / 8).contiguous())
+
+
+@pytest.mark.parametrize('model,layer,pairs,terms', [('sevennet_0', 0, False, 3), ('sevennet_0', 1, True, 3),
+                                                     ('sevennet_0', 4, True, 3), ('sevennet_0', 1, False, 2),
+                                                     ('sevennet_0', 1, True, 1), ('sevennet_l3i5', 1, True, 3),
+                                                     ('sevennet_l3i5', 0, False, 3)])
+def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms):
+    """Radial-MLP last layer inside the tensor-product kernels (w and g_w never in memory) ==
+    snet_radial_mlp_fwd + snet_conv_fwd and snet_conv_bwd_edge_vec + snet_radial_mlp_bwd:
+    forward rows, per-edge source-row gradients, dE/d(edge_vec) and the radial-embedding gradient.
+    terms = 3 (bf16x6) must agree to fp32 rounding; 2 and 1 to their stated precision."""
+    L, lib = _lib()
+    dev = 'cuda:0'
+    c = _fused_case(model, layer, 40 + layer, pairs)
+    spec, nb, wn, dx, dout, nsh, N, E, R = (c[k] for k in ('spec', 'nb', 'wn', 'dx', 'dout', 'nsh', 'N', 'E', 'R'))
     fp = lambda t: t.numpy().ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
-    mlp, plan = C.c_void_p(), C.c_void_p()
-    L.check(lib.snet_radial_mlp_plan_create(nb, 64, 64, wn, fp(W0), fp(W1), fp(W2), 0, 1.6791767923989418, 1, C.byref(mlp)))
+    mlp, plan, fplan = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    cst = 1.6791767923989418
+    L.check(lib.snet_radial_mlp_plan_create(nb, 64, 64, wn, fp(c['W0']), fp(c['W1']), fp(c['W2']), 0, cst, 1, C.byref(mlp)))
     L.check(lib.snet_conv_plan_create(spec.tag.encode(), C.byref(plan)))
-    assert lib.snet_conv_plan_fused(plan) == 1
-    rp, sr = row_ptr.to(dev), src.to(dev)
-    w_ref = torch.empty(E, wn, device=dev)
+    assert lib.snet_conv_fused_available(plan) == 1
+    L.check(lib.snet_fused_plan_create(plan, mlp, terms, C.byref(fplan)))
+    rp, sr = c['row_ptr'].to(dev), c['src'].to(dev)
+    wr = None if c['w_row'] is None else c['w_row'].to(dev)
+    x, sh, dsh, emb, g_out = (c[k].to(dev) for k in ('x', 'sh', 'dsh', 'emb', 'g_out'))
+    scale = 0.25
+    # ---- separate kernels (reference)
+    w_ref = torch.empty(R, wn, device=dev)
     out_ref = torch.empty(N, dout, device=dev)
-    L.check(lib.snet_radial_mlp_fwd(mlp, _p(emb), E, _p(w_ref), None))
-    L.check(lib.snet_conv_fwd(plan, _p(x), _p(sh), _p(w_ref), None, _p(rp), _p(sr), N, 0.25, _p(out_ref), None))
-    h2 = torch.empty(E, 64, device=dev)
-    w = torch.full((E, wn), float('nan'), device=dev)
+    L.check(lib.snet_radial_mlp_fwd(mlp, _p(emb), R, _p(w_ref), None))
+    L.check(lib.snet_conv_fwd(plan, _p(x), _p(sh), _p(w_ref), _p(wr), _p(rp), _p(sr), N, scale, _p(out_ref), None))
+    g_w = torch.empty(E, wn, device=dev)
+    g_xe_ref = torch.empty(E, dx, device=dev)
+    g_vec_ref = torch.ones(E, 3, device=dev)   # accumulated into
+    L.check(lib.snet_conv_bwd_edge_vec(plan, _p(x), _p(sh), _p(dsh), _p(w_ref), _p(wr), _p(rp), _p(sr), N, scale,
+                                       _p(g_out), _p(g_w), _p(g_xe_ref), _p(g_vec_ref), None))
+    emb_e = emb if wr is None else emb[wr.long()].contiguous()   # per directed edge
+    g_emb_ref = torch.ones(E, nb, device=dev)
+    L.check(lib.snet_radial_mlp_bwd(mlp, _p(emb_e), _p(g_w), E, _p(g_emb_ref), None))
+    # ---- fused kernels
+    h2 = torch.empty(R, 64, device=dev)
+    L.check(lib.snet_radial_mlp_hidden_fwd(mlp, _p(emb), R, _p(h2), None))
     out = torch.full((N, dout), float('nan'), device=dev)
-    L.check(lib.snet_radial_mlp_hidden_fwd(mlp, _p(emb), E, _p(h2), None))
-    L.check(lib.snet_conv_fwd_fused(plan, mlp, _p(x), _p(sh), _p(h2), _p(rp), _p(sr), N, 0.25, _p(out), _p(w), None))
+    L.check(lib.snet_conv_fwd_fused(fplan, _p(x), _p(sh), _p(h2), _p(wr), _p(rp), _p(sr), N, scale, _p(out), None))
+    tile_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    n_tiles = C.c_int64()
+    L.check(lib.snet_edge_tiles(_p(rp), N, _p(tile_ptr), C.byref(n_tiles), None))
+    deg = (c['row_ptr'][1:] - c['row_ptr'][:-1]).long()
+    assert n_tiles.value == int(((deg + 15) // 16).sum())
+    assert torch.equal(tile_ptr.cpu()[1:].long(), torch.cumsum((deg + 15) // 16, 0))
+    g_xe = torch.full((E, dx), float('nan'), device=dev)
+    g_h2 = torch.full((E, 64), float('nan'), device=dev)
+    g_vec = torch.ones(E, 3, device=dev)
+    L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), N,
+                                    n_tiles.value, scale, _p(g_out), _p(g_xe), _p(g_h2), _p(g_vec), None))
+    g_emb = torch.ones(E, nb, device=dev)
+    L.check(lib.snet_radial_mlp_hidden_bwd(mlp, _p(emb_e), _p(g_h2), E, _p(g_emb), None))
     torch.cuda.synchronize()
-    a1 = torch.nn.functional.silu(emb.double().cpu() @ W0.double()) * 1.6791767923989418
-    a2 = torch.nn.functional.silu(a1 @ W1.double()) * 1.6791767923989418
+    a1 = torch.nn.functional.silu(c['emb'].double() @ c['W0'].double()) * cst
+    a2 = torch.nn.functional.silu(a1 @ c['W1'].double()) * cst
     assert (h2.cpu().double() - a2).abs().max() < 5e-6 * a2.abs().max()
-    assert not torch.isnan(w).any() and not torch.isnan(out).any()
-    assert (w - w_ref).abs().max() <= 2e-6 * w_ref.abs().max()
-    assert (out - out_ref).abs().max() <= 2e-5 * out_ref.abs().max()
-    assert out[0].abs().max() == 0 and out[6].abs().max() == 0   # nodes without edges
-    # w_out is optional
-    out2 = torch.empty_like(out)
-    L.check(lib.snet_conv_fwd_fused(plan, mlp, _p(x), _p(sh), _p(h2), _p(rp), _p(sr), N, 0.25, _p(out2), None, None))
+    for t in (out, g_xe, g_h2, g_vec, g_emb):
+        assert not torch.isnan(t).any()
+    tol = {3: 2e-5, 2: 3e-4, 1: 4e-2}[terms]
+    # g_h2 against the fp64 contraction of the separate kernel's g_w with W2^T
+    g_h2_ref = g_w.double().cpu() @ c['W2'].double().T
+    for name, a, b in (('out', out, out_ref), ('g_xe', g_xe, g_xe_ref), ('g_vec', g_vec, g_vec_ref),
+                       ('g_h2', g_h2.cpu().double(), g_h2_ref), ('g_emb', g_emb, g_emb_ref)):
+        err = (a.double().cpu() - b.double().cpu()).abs().max().item()
+        assert err <= tol * max(1.0, b.abs().max().item()), (name, err, b.abs().max().item())
+    assert out[0].abs().max() == 0 and out[9].abs().max() == 0 and out[N - 1].abs().max() == 0   # nodes without edges
+    # g_xe is optional (first layer: inputs depend on species only)
+    g_h2b = torch.empty_like(g_h2)
+    g_vecb = torch.ones(E, 3, device=dev)
+    L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), N,
+                                    n_tiles.value, scale, _p(g_out), None, _p(g_h2b), _p(g_vecb), None))
     torch.cuda.synchronize()
-    assert torch.equal(out, out2)
+    assert torch.equal(g_h2, g_h2b) and torch.equal(g_vec, g_vecb)
+    lib.snet_fused_plan_destroy(fplan)
     lib.snet_conv_plan_destroy(plan)
     lib.snet_radial_mlp_plan_destroy(mlp)
 
@@ -491,3 +545,100 @@ def test_conv_bwd_edge_ragged_degrees_vs_autograd(cfg_name):
     gv_ref = torch.einsum('ei,eia->ea', sh64.grad, dsh.double())
     assert (g_vec.cpu().double() - gv_ref).abs().max() < tol(gv_ref)
     lib.snet_conv_plan_destroy(plan)
+
+
+# --------------------------------------------------------------------------- #
+# HIP kernels vs outputs of the reference's own pure-torch modules
+# (tests/golden/ref_torch_modules.npz, oracle/tools/make_golden_torch_modules.py)
+# --------------------------------------------------------------------------- #
+def _ref_modules():
+    from helpers import GOLDEN
+    return np.load(f'{GOLDEN}/ref_torch_modules.npz')
+
+
+@pytest.mark.parametrize('tag', ['rc5', 'rc6', 'rc4'])
+def test_edge_embedding_vs_reference_modules(tag):
+    """snet_edge_embed_fwd == BesselBasis * {PolynomialCutoff, XPLORCutoff} of the reference
+    (edge_embedding.py:101-103,125-132,150-160) on its own fp32 outputs, incl. r_on and r_cut"""
+    L, lib = _lib()
+    dev = 'cuda:0'
+    d = _ref_modules()
+    rc, r_on, p = (float(v) for v in d[f'{tag}_params'])
+    r = torch.tensor(d[f'{tag}_r'], dtype=torch.float32)
+    E, nb = r.numel(), 8
+    u = torch.nn.functional.normalize(torch.randn(E, 3, generator=torch.Generator().manual_seed(1)), dim=1)
+    vd = (u * r.unsqueeze(1)).to(dev)
+    r_act = vd.norm(dim=1).cpu().double()        # the length the kernel actually sees
+    cf = (C.c_float * nb)(*[float(v) for v in d[f'{tag}_coeffs_f32']])
+    for kind, ref in ((0, d[f'{tag}_poly_f64']), (1, d[f'{tag}_xplor_f64'])):
+        P = L.EdgeParams(rc, nb, kind, int(p), r_on, 1, 0)
+        emb, sh, dsh = torch.empty(E, nb, device=dev), torch.empty(E, 4, device=dev), torch.empty(E, 4, 3, device=dev)
+        L.check(lib.snet_edge_embed_fwd(C.byref(P), cf, _p(vd), E, _p(emb), _p(sh), _p(dsh), None))
+        torch.cuda.synchronize()
+        want = d[f'{tag}_bessel_f64'] * ref[:, None]
+        # |d(emb)/dr| <= ~10 / A: allow for the fp32 rounding of r itself
+        slack = 2e-6 + 12.0 * (r_act - torch.tensor(d[f'{tag}_r'])).abs().max().item()
+        assert np.abs(emb.cpu().double().numpy() - want).max() <= slack, (tag, kind)
+
+
+def test_edge_force_vs_reference_module():
+    """snet_edge_force == ForceStressOutputFromEdge.forward (force_output.py:171-230) on the reference's own
+    inputs / outputs: forces, per-atom virial (xx,yy,zz,xy,yz,zx at edge_index[1]), total virial"""
+    L, lib = _lib()
+    dev = 'cuda:0'
+    d = _ref_modules()
+    ei = torch.tensor(d['fs_edge_index'])
+    n = d['fs_force_f32'].shape[0]
+    order = torch.sort(ei[0], stable=True).indices       # the kernels want edges sorted by center (edge_index[0])
+    ei = ei[:, order]
+    g = torch.tensor(d['fs_gij_f32'])[order].contiguous().to(dev)
+    rij = torch.tensor(d['fs_rij_f32'])[order].contiguous().to(dev)
+    E = ei.shape[1]
+    row_ptr = torch.zeros(n + 1, dtype=torch.int64)
+    row_ptr[1:] = torch.cumsum(torch.bincount(ei[0], minlength=n), 0)
+    col_ptr = torch.zeros(n + 1, dtype=torch.int64)
+    col_ptr[1:] = torch.cumsum(torch.bincount(ei[1], minlength=n), 0)
+    eperm = torch.sort(ei[1], stable=True).indices
+    rp, cp, ep = (t.to(torch.int32).to(dev) for t in (row_ptr, col_ptr, eperm))
+    F = torch.empty(n, 3, device=dev)
+    va = torch.empty(n, 6, device=dev)
+    vt = torch.empty(6, dtype=torch.float64, device=dev)
+    L.check(lib.snet_edge_force(_p(g), _p(rij), _p(rp), _p(cp), _p(ep), n, E, _p(F), _p(va), _p(vt), None))
+    torch.cuda.synchronize()
+    assert np.abs(F.cpu().numpy() - d['fs_force_f64']).max() <= 1e-5 * np.abs(d['fs_force_f64']).max()
+    assert np.abs(va.cpu().numpy() - d['fs_atomic_virial_f64']).max() <= 1e-5 * np.abs(d['fs_atomic_virial_f64']).max()
+    stress = vt.cpu().numpy() / d['fs_volume'][0]
+    assert np.abs(stress - d['fs_stress_f64']).max() <= 1e-5 * np.abs(d['fs_stress_f64']).max()
+
+
+def test_rescale_reduce_vs_reference_modules():
+    """snet_rescale_reduce == Rescale / SpeciesWiseRescale / ModalWiseRescale.forward + AtomReduce
+    (scale.py:53-56,155-162,341-363; linear.py:127-141)"""
+    L, lib = _lib()
+    dev = 'cuda:0'
+    d = _ref_modules()
+    e = torch.tensor(d['rs_in']).to(dev)
+    types = torch.tensor(d['rs_types']).to(torch.int32).to(dev)
+    n = e.shape[0]
+
+    def run(scale, shift):
+        sc = torch.tensor(np.asarray(scale, np.float32)).reshape(-1).to(dev)
+        sh = torch.tensor(np.asarray(shift, np.float32)).reshape(-1).to(dev)
+        ea = torch.empty(n, device=dev)
+        tot = torch.empty(1, dtype=torch.float64, device=dev)
+        L.check(lib.snet_rescale_reduce(_p(e), _p(types), _p(sc), _p(sh), sc.numel(), n, _p(ea), _p(tot), None))
+        torch.cuda.synchronize()
+        return ea.cpu().numpy(), tot.item()
+    sh0, sc0 = d['rs_global_params']
+    ea, _ = run([sc0], [sh0])
+    assert np.abs(ea - d['rs_global'][:, 0]).max() <= 1e-6
+    ea, tot = run(d['rs_species_scale'], d['rs_species_shift'])
+    assert np.abs(ea - d['rs_species'][:, 0]).max() <= 1e-6
+    assert abs(tot - float(d['reduce_total'][0])) <= 2e-5
+    # modal-wise: the engine selects the fidelity channel's row at load time (model_spec.rescale_vectors)
+    sm, cm = d['rs_modal_shift'], d['rs_modal_scale']
+    for modal in range(sm.shape[0]):
+        for tag, shift, scale in (('mm', sm[modal], cm[modal]), ('ms', sm[modal], d['rs_species_scale']),
+                                  ('sm', d['rs_species_shift'], cm[modal])):
+            ea, _ = run(scale, shift)
+            assert np.abs(ea - d[f'rs_modal_{tag}_{modal}'][:, 0]).max() <= 1e-6, (tag, modal)

@@ -197,3 +197,66 @@ def test_oracle_rotation_equivariance_l3():
     # improper rotation (parity model): energy invariant as well
     c = m.forward(types, ei, -ev)
     assert abs(float(a['energy']) - float(c['energy'])) < 1e-9 * abs(float(a['energy']))
+
+
+# --------------------------------------------------------------------------- #
+# the reference's own pure-torch modules, executed from /root/reference in the build container
+# (oracle/tools/make_golden_torch_modules.py) -> tests/golden/ref_torch_modules.npz
+# --------------------------------------------------------------------------- #
+def _ref_modules():
+    return np.load(f'{GOLDEN}/ref_torch_modules.npz')
+
+
+@pytest.mark.parametrize('tag', ['rc5', 'rc6', 'rc4'])
+def test_oracle_radial_basis_and_cutoffs_vs_reference_modules(tag):
+    """BesselBasis / PolynomialCutoff / XPLORCutoff.forward (edge_embedding.py:101-103,125-132,150-160),
+    incl. the points around r_on and r_cut: fp64 restatement vs the reference classes run in fp64"""
+    from oracle.model import bessel_basis, poly_cutoff, xplor_cutoff
+    d = _ref_modules()
+    rc, r_on, p = d[f'{tag}_params']
+    r = torch.tensor(d[f'{tag}_r'])
+    b = bessel_basis(r, torch.tensor(d[f'{tag}_coeffs_f64']), rc)
+    assert np.abs(b.numpy() - d[f'{tag}_bessel_f64']).max() <= 1e-13 * np.abs(d[f'{tag}_bessel_f64']).max()
+    assert np.abs(poly_cutoff(r, rc, int(p)).numpy() - d[f'{tag}_poly_f64']).max() <= 1e-13
+    assert np.abs(xplor_cutoff(r, rc, r_on).numpy() - d[f'{tag}_xplor_f64']).max() <= 1e-13
+    # fp32 arithmetic of the same formulae stays within fp32 rounding of the reference's fp32 run
+    r32 = r.float()
+    assert np.abs(xplor_cutoff(r32, float(rc), float(r_on)).numpy() - d[f'{tag}_xplor_f32']).max() <= 2e-6
+    assert np.abs(poly_cutoff(r32, float(rc), int(p)).numpy() - d[f'{tag}_poly_f32']).max() <= 2e-5
+
+
+def test_oracle_force_virial_vs_reference_module():
+    """ForceStressOutputFromEdge.forward (force_output.py:171-230): force sign rule, virial component order
+    (xx, yy, zz, xy, yz, zx), atomic virial assigned to edge_index[1], stress = -sum / volume"""
+    from oracle.model import force_virial_from_edge
+    d = _ref_modules()
+    g, rij = torch.tensor(d['fs_gij_f64']), torch.tensor(d['fs_rij_f64'])
+    ei = torch.tensor(d['fs_edge_index'])
+    n = d['fs_force_f64'].shape[0]
+    out = force_virial_from_edge(g, rij, ei, n)
+    assert np.abs(out['forces'].numpy() - d['fs_force_f64']).max() <= 1e-12 * np.abs(d['fs_force_f64']).max()
+    assert np.abs(out['atomic_virial'].numpy() - d['fs_atomic_virial_f64']).max() <= 1e-12 * np.abs(d['fs_atomic_virial_f64']).max()
+    stress = out['virial'].numpy() / d['fs_volume'][0]
+    assert np.abs(stress - d['fs_stress_f64']).max() <= 1e-12 * np.abs(d['fs_stress_f64']).max()
+
+
+def test_oracle_rescale_vs_reference_modules():
+    """Rescale / SpeciesWiseRescale / ModalWiseRescale.forward (scale.py:53-56,155-162,341-363), AtomReduce
+    (linear.py:127-141), OnehotEmbedding (node_embedding.py:44-53)"""
+    from oracle.model import rescale_apply
+    d = _ref_modules()
+    e, types = torch.tensor(d['rs_in']), torch.tensor(d['rs_types'])
+    sh, sc = d['rs_global_params']
+    out = rescale_apply(e, types, torch.tensor([sc], dtype=torch.float32), torch.tensor([sh], dtype=torch.float32))
+    assert np.abs(out.numpy() - d['rs_global']).max() <= 1e-6
+    ss, cs = torch.tensor(d['rs_species_shift']), torch.tensor(d['rs_species_scale'])
+    out = rescale_apply(e, types, cs, ss)
+    assert np.abs(out.numpy() - d['rs_species']).max() <= 1e-6
+    assert abs(float(out.sum()) - float(d['reduce_total'][0])) <= 1e-4
+    sm, cm = torch.tensor(d['rs_modal_shift']), torch.tensor(d['rs_modal_scale'])
+    for modal in range(sm.shape[0]):
+        for tag, shift, scale in (('mm', sm, cm), ('ms', sm, cs), ('sm', ss, cm)):
+            out = rescale_apply(e, types, scale, shift, modal)
+            assert np.abs(out.numpy() - d[f'rs_modal_{tag}_{modal}']).max() <= 1e-6, (tag, modal)
+    oh = torch.nn.functional.one_hot(types, d['onehot'].shape[1]).float().numpy()
+    assert np.array_equal(oh, d['onehot'])

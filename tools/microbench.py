@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--model', default='sevennet_0')
     ap.add_argument('--mlp-mode', default='bf16x6')
+    ap.add_argument('--terms', type=int, default=3)
     ap.add_argument('--only', default='', help='substring filter on kernel names')
     ap.add_argument('--order', default='raster', choices=['raster', 'morton', 'random'], help='atom order of the test cell')
     a = ap.parse_args()
@@ -36,7 +37,7 @@ def main():
     from sevennet_amd.neighbor import diamond_cubic, neighbor_list
     from sevennet_amd.synthetic import random_state_dict
     cfg = model_config(a.model)
-    eng = HipForceEngine(cfg, random_state_dict(cfg, 0), mlp_mode=a.mlp_mode)
+    eng = HipForceEngine(cfg, random_state_dict(cfg, 0), mlp_mode=a.mlp_mode, fused_terms=a.terms)
     lib = eng.lib
     pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
     if a.order == 'random':
@@ -83,10 +84,14 @@ def main():
     km = kernel_model(ls, N, E)
     st = _stream()
     h2 = rnd(E, 64)
+    g_h2 = rnd(E, 64)
+    tile_ptr, n_tiles = g.tiles()
     ops = {
         'radial_mlp_hidden_fwd': lambda: lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb), E, _ptr(h2), st),
-        f'conv_fwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_fwd_fused(L.plan, L.mlp_plan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), _ptr(w), st),
-        f'conv_fwd_fused_nowout[{ls.conv.tag}]': lambda: lib.snet_conv_fwd_fused(L.plan, L.mlp_plan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), None, st),
+        f'conv_fwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_fwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
+        f'conv_bwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), N, n_tiles, L.scale, _ptr(g_m), _ptr(g_xe), _ptr(g_h2), _ptr(g_vec), st),
+        f'conv_bwd_fused_no_gxe[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), N, n_tiles, L.scale, _ptr(g_m), None, _ptr(g_h2), _ptr(g_vec), st),
+        'radial_mlp_hidden_bwd': lambda: lib.snet_radial_mlp_hidden_bwd(L.mlp_plan, _ptr(emb), _ptr(g_h2), E, _ptr(g_emb), st),
         f'radial_mlp_fwd[wn={wn}]': lambda: eng._mlp_fwd(L, emb, E),
         f'conv_fwd[{ls.conv.tag}]': lambda: lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), None, _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
         f'conv_bwd_edge[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_edge_vec(L.plan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(w), None, _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(g_m), _ptr(g_w), _ptr(g_xe), _ptr(g_vec), st),
