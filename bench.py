@@ -11,7 +11,10 @@ exist offline; throughput is weight-independent).  Workload at every N: the
 ~100k-atom cell BASELINE.json's metric is quoted on (97 336 atoms, Si x 23^3,
 sigma = 0.05 A, cutoff 5.0 A); with N > 1 the SAME cell is split into N spatial
 bricks (strong scaling) with an RCCL ghost-feature halo exchange per layer.
-Inputs (graph + weights) are resident in HBM before the timed region.
+Weights and the graph TOPOLOGY (CSR index arrays, pair map) are resident in HBM before the timed
+region; the per-step inputs of an MD step -- the edge vectors r_j - r_i [E,3] fp32, i.e. what positions
+turn into -- are copied host -> device INSIDE every timed step (SURVEY.md section 8d: "graph already built;
+H2D of positions/edges included"; `--no-h2d` times the resident-input step instead).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline     -- dominant kernel class, achieved vs gfx950 peak, from HIP events
@@ -34,6 +37,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak
 MFMA_F32_PEAK_TF = 157.3   # dense fp32-input MFMA peak
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (the split-precision products run there)
+# algorithmic work per atom-step of the named shapes (bytes, flops), fwd + reverse
+STEP_WORK = {'sevennet_0': (0.992e6, 44.5e6), 'sevennet_l3i5': (1.584e6, 119e6), 'sevennet_mf_ompa': (3.225e6, 305e6)}
 
 
 def parse():
@@ -51,11 +57,13 @@ def parse():
     ap.add_argument('--fused', default='auto', choices=['auto', 'off', 'fwd', 'bwd'],
                     help="radial-MLP last layer inside the tensor-product kernels (w / g_w never materialised): "
                          "'auto' = forward and reverse (default), 'off' = separate kernels")
-    ap.add_argument('--terms', type=int, default=3, choices=[1, 2, 3],
-                    help='bf16 terms per operand of the fused in-kernel products (3 = bf16x6, fp32-rounding class)')
+    ap.add_argument('--terms', type=int, default=2, choices=[1, 2, 3],
+                    help='bf16 terms per operand of the fused in-kernel products: 2 = bf16x3 (engine default, force error vs fp64 '
+                         '6e-7 eV/A), 3 = bf16x6 (fp32-rounding class), 1 = plain bf16 (outside the 1e-4 eV/A bar)')
     ap.add_argument('--no-overlap', action='store_true', help='radial MLPs on the main stream (no second stream)')
+    ap.add_argument('--no-h2d', action='store_true', help='keep the edge vectors resident (no per-step host -> device copy)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-reps', type=int, default=5, help='CPU-baseline sample: cells per axis (5 -> 1000 atoms)')
+    ap.add_argument('--cpu-reps', type=int, default=6, help='CPU-baseline sample: cells per axis (6 -> 1728 atoms, 11 -> 10 648)')
     return ap.parse_args()
 
 
@@ -82,7 +90,12 @@ def kernel_model(ls, n_nodes, n_edges):
     mlp_flops = 2.0 * n_edges * sum(h[i] * h[i + 1] for i in range(len(h) - 1))
     return {
         f'conv_fwd[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 4 * nsh + 8) + n_nodes * 4 * dmid),
-        f'conv_fwd_fused[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 4 * nsh + 8) + n_nodes * 4 * dmid),
+        # fused kernels: w = h2 @ W2 and g_h2 = g_w @ W2^T run inside (bf16 x terms products on the matrix cores);
+        # per edge they move the source row, Y (+ its Jacobian), src / w_row, h2[64] (+ g_xe, g_h2, g_vec on the way back)
+        f'conv_fwd_fused[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 4 * nsh + 8 + 256) + n_nodes * 4 * dmid,
+                                               flops=2.0 * n_edges * 64 * wn),
+        f'conv_bwd_fused[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (2 * 4 * dx + 4 * 4 * nsh + 8 + 512 + 24) + n_nodes * 4 * dmid,
+                                               flops=2.0 * 2.0 * n_edges * 64 * wn),
         f'conv_bwd_edge[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 2 * 4 * nsh + 8) + n_nodes * 4 * dmid),
         f'conv_bwd_node[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dmid + 4 * nsh + 12) + n_nodes * 4 * dx),
         f'radial_mlp_fwd[wn={wn}]': dict(bound='mfma', flops=mlp_flops),
@@ -90,37 +103,44 @@ def kernel_model(ls, n_nodes, n_edges):
     }
 
 
+def cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown CPU'
+
+
 def cpu_baseline(cfg, sd, reps):
-    """The oracle = this repo's CPU restatement of the reference's e3nn/PyTorch path, fp32,
-    on a bounded sample (about 10-20 s of CPU work)."""
+    """The oracle = this repo's CPU restatement of the reference's e3nn/PyTorch path, fp32, on a bounded
+    sample: >= 3 evaluations after one warm-up, about 30 s of CPU work at the default sample size
+    (6^3 cells = 1728 atoms; `--cpu-reps 11` times the 10 648-atom cell of BASELINE config 2, ~4 min)."""
     from oracle.model import OracleModel
     from sevennet_amd.neighbor import diamond_cubic, neighbor_list
     pos, cell = diamond_cubic(5.431, (reps,) * 3, 0.05, 2)
     ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
     types = species_of(cfg, len(pos))
     m = OracleModel(cfg, sd, dtype=torch.float32, modal='mpa' if cfg.get('use_modality') else None)
-    best = None
     default_threads = torch.get_num_threads()
-    # eager PyTorch on many small ops does not scale to every core: try the default and 32 threads
-    for threads in sorted({default_threads, min(32, default_threads)}):
-        torch.set_num_threads(threads)
-        t0 = time.perf_counter()
-        m.forward(types, ei, ev)  # warm-up
-        warm = time.perf_counter() - t0
-        n_max = int(max(1, min(8, 6.0 / max(warm, 1e-3))))
-        t0 = time.perf_counter()
-        for _ in range(n_max):
-            m.forward(types, ei, ev)
-        dt = time.perf_counter() - t0
-        rate = len(pos) * n_max / dt
-        if best is None or rate > best[0]:
-            best = (rate, threads, n_max, dt)
+    # eager PyTorch on many small ops does not scale to every core: 32 threads were the best of {default, 32}
+    # on the 128-core host of the GPU box (round 1); the count actually used is reported in `cores`
+    threads = min(32, default_threads)
+    torch.set_num_threads(threads)
+    m.forward(types, ei, ev)  # warm-up
+    n_eval = 3
+    t0 = time.perf_counter()
+    for _ in range(n_eval):
+        m.forward(types, ei, ev)
+    dt = time.perf_counter() - t0
     torch.set_num_threads(default_threads)
-    rate, threads, n, dt = best
-    return dict(value=rate, unit='atom-steps/s', cores=threads, kind='port',
-                sample=f'SevenNet-0 shape, {len(pos)}-atom Si cell ({ei.shape[1]} edges), {n} energy+force '
+    return dict(value=len(pos) * n_eval / dt, unit='atom-steps/s', cores=threads, kind='port', cpu=cpu_model_name(),
+                logical_cpus=os.cpu_count(),
+                sample=f'SevenNet-0 shape, {len(pos)}-atom Si cell ({ei.shape[1]} edges), {n_eval} energy+force '
                        f'evaluations in {dt:.1f} s after one warm-up, fp32 torch CPU oracle (oracle/model.py), '
-                       f'best of {{default, 32}} torch threads = {threads} on {os.cpu_count()} logical CPUs')
+                       f'{threads} torch threads on {cpu_model_name()} ({os.cpu_count()} logical CPUs)')
 
 
 def main():
@@ -183,7 +203,15 @@ def main():
         nat = NativeModel(cfg, sd, device=dev, modal=modal)
         nat.set_halo(halo)
 
+    # per-step input: the edge vectors (what an MD host derives from the new positions) come from pinned host
+    # memory every step, on the compute stream, inside the timed region
+    ev_host = None
+    if not a.no_h2d:
+        ev_host = graph.edge_vec.cpu().pin_memory()
+
     def step():
+        if ev_host is not None:
+            graph.edge_vec.copy_(ev_host, non_blocking=True)
         return nat.compute(graph) if nat is not None else eng.compute(graph, halo=halo)
 
     def fence():
@@ -195,7 +223,21 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    eng.events = []
+    # Per-kernel HIP events cost time on this platform (a timestamp packet per record: the step with ~120 records
+    # ran 15 % slower than without).  So: (1) one untimed pass with every class bracketed picks the dominant class,
+    # (2) the TIMED steps bracket only that class (6 records per step) -- its average launch duration is measured
+    # live inside the timed region, as the contract asks --, (3) a last untimed pass gives the full breakdown.
+    eng.events, eng.event_filter = [], None
+    eng.compute(graph, halo=halo)
+    fence()
+    probe = {}
+    for name, t in eng.kernel_times_ms().items():
+        probe[name] = float(np.sum(t))
+    models0 = {}
+    for ls in eng.spec.layers:
+        models0.update(kernel_model(ls, graph.n_local, graph.n_edges))
+    dominant0 = max((k for k in probe if k in models0), key=lambda k: probe[k])
+    eng.events, eng.event_filter = [], {dominant0}
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
@@ -206,11 +248,12 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    if nat is not None:  # per-kernel timers live in the Python host: one extra untimed pass of the same kernels
-        eng.events = []
-        for _ in range(a.steps):
-            eng.compute(graph, halo=halo)
-        fence()
+    timed_dom = eng.kernel_times_ms().get(dominant0, [])   # recorded by the Python host only
+    eng.events, eng.event_filter = [], None
+    for _ in range(min(a.steps, 3)):
+        eng.compute(graph, halo=halo)
+    fence()
+    n_break = min(a.steps, 3)
     times = eng.kernel_times_ms()
     eng.events = None
 
@@ -222,14 +265,21 @@ def main():
         models.update(kernel_model(ls, graph.n_local, graph.n_edges))
     # classes tagged '@side' ran on the second stream, overlapped with main-stream kernels: their event brackets
     # are not exclusive time, so the dominant class is chosen among the main-stream ones
-    dominant = max((k for k in totals if k in models), key=lambda k: totals[k])
-    avg_ms = totals[dominant] / counts[dominant]
+    dominant = dominant0
+    # average launch duration of the dominant class: from the timed steps when the Python host sequenced them,
+    # from the breakdown pass when the native sequencer did (its launches are not bracketed)
+    avg_ms = float(np.mean(timed_dom)) if len(timed_dom) else totals[dominant] / counts[dominant]
     km = models[dominant]
     if km['bound'] == 'hbm':
         ach = km['bytes'] / (avg_ms * 1e-3) / 1e9
         roof = dict(bound='hbm', kernel=dominant, achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=ach / HBM_PEAK_GBS, traffic=None, avg_ms=avg_ms,
                     algorithmic_bytes_per_launch=km['bytes'])
+        if 'flops' in km:  # fused kernels also carry the radial MLP's last layer on the matrix cores
+            n_prod = {3: 6, 2: 3, 1: 1}[a.terms]
+            roof['mfma'] = dict(algorithmic_flops_per_launch=km['flops'], bf16_products_per_flop=n_prod,
+                                achieved_tflops=km['flops'] * n_prod / (avg_ms * 1e-3) / 1e12, peak_tflops=MFMA_BF16_PEAK_TF,
+                                frac=km['flops'] * n_prod / (avg_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF)
     else:
         ach = km['flops'] / (avg_ms * 1e-3) / 1e12
         roof = dict(bound='mfma', kernel=dominant, achieved=ach, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
@@ -241,10 +291,11 @@ def main():
         pmc = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')))[-1]
         with open(pmc) as f:
             tr = json.load(f)
-        key = dominant.replace('conv_bwd_edge[', 'conv_bwd_edge_vec_').replace('conv_fwd_fused[', 'conv_ffwd_').replace('conv_fwd[', 'conv_fwd_') \
+        key = dominant.replace('conv_bwd_edge[', 'conv_bwd_edge_vec_').replace('conv_fwd_fused[', 'conv_fwdf_') \
+            .replace('conv_bwd_fused[', 'conv_bwdf_').replace('conv_fwd[', 'conv_fwd_') \
             .replace('conv_bwd_node[', 'conv_bwd_node_').rstrip(']')
         # a kernel class may be several kernels (one per x irrep block: <name>_k0, _k1, ...)
-        parts = [v for k, v in tr.items() if k == key or k.startswith(key + '_k')]
+        parts = [v for k, v in tr.items() if k == key or k.startswith(key + '_k') or k.startswith(key + '<')]
         if world == 1 and a.reps == 23 and parts:
             roof['traffic'] = sum(v['hbm_bytes_per_launch'] for v in parts)
             roof['traffic_frac_of_peak'] = roof['traffic'] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -259,7 +310,17 @@ def main():
     e_total = out['energy'].clone()
     if world > 1:  # ranks hold partial energies of their bricks
         dist.all_reduce(e_total)
-    roof['kernel_ms_per_step'] = {k: round(v / a.steps, 4) for k, v in sorted(totals.items(), key=lambda kv: -kv[1])}
+    roof['kernel_ms_per_step'] = {k: round(v / n_break, 4) for k, v in sorted(totals.items(), key=lambda kv: -kv[1])}
+    roof['avg_ms_source'] = 'HIP events inside the timed steps' if len(timed_dom) else 'HIP events of an untimed pass of the same kernels (native host)'
+    # whole step against SURVEY.md 8(d)'s algorithmic work: bytes at the HBM peak, flops at the fp32 matrix peak
+    if a.model in STEP_WORK:
+        sb, sf = (v * n_atoms for v in STEP_WORK[a.model])
+        t = dt / a.steps * world   # GPU-seconds per step
+        roof['step'] = dict(bytes=sb, flops=sf, frac_hbm=sb / t / (HBM_PEAK_GBS * 1e9), frac_mfma=sf / t / (MFMA_F32_PEAK_TF * 1e12),
+                            floor_ms=max(sb / (HBM_PEAK_GBS * 1e9), sf / (MFMA_F32_PEAK_TF * 1e12)) * 1e3,
+                            note='SURVEY.md 8(d): 0.992 MB and 44.5 MFLOP per atom-step for SevenNet-0 (fwd + reverse, no cache '
+                                 'credit, radial weights not materialised); fractions of 8 TB/s and of the 157.3 TFLOP/s fp32 '
+                                 'matrix peak over the measured step time')
 
     if rank == 0:
         res = {
@@ -275,6 +336,9 @@ def main():
                        'parallelism': 'single GPU' if world == 1 else f'spatial decomposition x{world}, RCCL halo',
                        'graph_build_s': round(t_graph, 3),
                        'host': a.host, 'host_enqueue_ms_per_step': round(t_enq / a.steps * 1e3, 3),
+                       'h2d_in_step': (None if ev_host is None else
+                                       f'edge_vec [E,3] fp32 = {ev_host.numel() * 4 / 1e6:.1f} MB from pinned host memory every step'),
+                       'fused': a.fused, 'terms': a.terms,
                        'energy': float(e_total.cpu())},
             'roofline': roof,
         }

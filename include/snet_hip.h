@@ -148,13 +148,16 @@ int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, c
  * the fly.  What crosses HBM per edge is h2[64] in and g_h2[64] out instead of w[wn] and g_w[wn].
  *   h2[R,64]   hidden activations a2 of the MLP (snet_radial_mlp_hidden_fwd), R = edges or undirected
  *              pairs; edge e reads row w_row[e] (NULL: row e)
- *   terms      bf16 terms per operand of the in-kernel products: 3 = bf16x6 (fp32-rounding class,
- *              default), 2 = bf16x3 (~2^-16 relative), 1 = plain bf16
- *   tile_ptr   int32[n_dst+1], exclusive scan of ceil(degree/16) (snet_edge_tiles): the reverse kernel
- *              gives each 16-edge tile of a node's CSR segment to one wavefront
+ *   terms      bf16 terms per operand of the in-kernel products: 2 = bf16x3 (a0b0 + a0b1 + a1b0, ~2^-16 relative per
+ *              product; the default of both hosts: whole-model force error vs fp64 6e-7 eV/A against 2e-7 for the
+ *              fp32-class paths), 3 = bf16x6 (fp32-rounding class), 1 = plain bf16 (~4e-4 eV/A: outside the 1e-4 bar)
+ *   tile_ptr   int32[n_dst+1], exclusive scan of ceil(degree/16), and tile_node int32[n_tiles] (tile -> node), both
+ *              from snet_edge_tiles: the reverse kernel gives each 16-edge tile of a node's CSR segment to one
+ *              wavefront (tile_node capacity: n_dst + n_edges / 16 entries always suffice)
  * reverse outputs: g_xe[E,dx] (nullable; sum per source with snet_segment_sum_rows), g_h2[E,64]
  * (overwritten; feed to snet_radial_mlp_hidden_bwd), g_vec[E,3] ACCUMULATED (as snet_conv_bwd_edge_vec).
  * snet_conv_fused_available() != 0 iff the shape has these kernels (channel multiplicities % 16 == 0). */
+#define SNET_FUSED_TERMS_DEFAULT 2
 typedef struct snet_fused_plan snet_fused_plan;
 int snet_radial_mlp_hidden_fwd(const snet_mlp_plan *plan, const float *emb, int64_t n_edges, float *h2, void *stream);
 int snet_radial_mlp_hidden_bwd(const snet_mlp_plan *plan, const float *emb, const float *g_h2, int64_t n_edges,
@@ -162,14 +165,15 @@ int snet_radial_mlp_hidden_bwd(const snet_mlp_plan *plan, const float *emb, cons
 int snet_conv_fused_available(const snet_conv_plan *plan);
 int snet_fused_plan_create(const snet_conv_plan *plan, const snet_mlp_plan *mlp, int32_t terms, snet_fused_plan **out);
 void snet_fused_plan_destroy(snet_fused_plan *plan);
-int snet_edge_tiles(const int32_t *row_ptr, int64_t n_dst, int32_t *tile_ptr, int64_t *n_tiles, void *stream);
+int snet_edge_tiles(const int32_t *row_ptr, int64_t n_dst, int32_t *tile_ptr, int32_t *tile_node, int64_t tile_capacity,
+                    int64_t *n_tiles, void *stream);
 int snet_conv_fwd_fused(const snet_fused_plan *plan, const float *x, const float *sh, const float *h2,
                         const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
                         float *out, void *stream);
 int snet_conv_bwd_fused(const snet_fused_plan *plan, const float *x, const float *sh, const float *dsh,
                         const float *h2, const int32_t *w_row, const int32_t *row_ptr, const int32_t *src,
-                        const int32_t *tile_ptr, int64_t n_dst, int64_t n_tiles, float scale, const float *g_out,
-                        float *g_xe, float *g_h2, float *g_vec, void *stream);
+                        const int32_t *tile_ptr, const int32_t *tile_node, int64_t n_tiles, float scale,
+                        const float *g_out, float *g_xe, float *g_h2, float *g_vec, void *stream);
 /* per-edge gradients given g_out[n_dst,dout]: g_w[E,wn] (overwritten), g_sh[E,nsh] (ACCUMULATED,
  * so one buffer collects all layers) and, if g_xe != NULL, this edge's contribution to the gradient
  * of its source row, g_xe[E,dx] (overwritten; sum it per source node with snet_segment_sum_rows --

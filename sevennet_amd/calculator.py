@@ -235,7 +235,8 @@ class SevenNetCalculator(Calculator):
             bad = sorted(set(numbers[types < 0].tolist()))
             raise ValueError(f'Model do not know atomic number: {bad[0]}, (knows: {list(self.type_map.keys())})')
         cell = np.asarray(cell, np.float64).reshape(3, 3)
-        ns = self.model.spec.num_species
+        # per-species row lists only where a per-species (FCTP) self-connection reads them
+        ns = self.model.spec.num_species if self.model.needs_species_rows else 0
         if gpu_neighbor_supported(cell, pbc, self.cutoff):  # bulk periodic cell: cell list on the GPU
             g = build_graph_gpu(types, positions, cell, self.cutoff, device=str(self.device), num_species=ns)
             n_edges = g.n_edges

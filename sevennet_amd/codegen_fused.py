@@ -28,7 +28,7 @@ from __future__ import annotations
 
 from typing import Dict, List
 
-from .codegen import _Cat, _f, _path_terms, _sum_expr
+from .codegen import OPTS, _Cat, _f, _path_terms, _sum_expr
 from .model_spec import ConvSpec
 
 
@@ -55,8 +55,37 @@ def schedule(spec: ConvSpec):
     return cats, pairs_of, cols
 
 
+def _emit_staging(A, lines: str):
+    """stage_load(s, b) / stage_store(b): the next sub-step's `lines` fragment lines (1 KB each) travel
+    global -> LDS either through registers (load early, ds_write late) or (GLDS) by gfx950's direct
+    global_load_lds (no staging VGPRs; lane i of a wave lands at base + 16 i)"""
+    A('  u32x4 st[GLDS ? 1 : NST];')
+    A('  auto stage_load = [&](int s, int b) {')
+    A('    if constexpr (GLDS) {')
+    A(f'      for (int l = wave; l < {lines}; l += NWV)')
+    A('        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(slabs + (size_t)s * (LPS * 64) + l * 64 + lane),')
+    A('                                         (__attribute__((address_space(3))) void *)(&slab[b][l * 64]), 16, 0, 0);')
+    A('    } else {')
+    A('#pragma unroll')
+    A(f'      for (int i = 0; i < NST; ++i) if (({lines} * 64) % NTH == 0 || tid + NTH * i < {lines} * 64) st[i] = slabs[(size_t)s * (LPS * 64) + tid + NTH * i];')
+    A('    }')
+    A('  };')
+    A('  auto stage_store = [&](int b) {')
+    A('    if constexpr (!GLDS) {')
+    A('#pragma unroll')
+    A(f'      for (int i = 0; i < NST; ++i) if (({lines} * 64) % NTH == 0 || tid + NTH * i < {lines} * 64) slab[b][tid + NTH * i] = st[i];')
+    A('    }')
+    A('  };')
+
+
 def gen_conv_fused(spec: ConvSpec) -> str:
     tag = spec.tag
+    # default configuration of the two kernels: (waves per workgroup, direct global->LDS staging, waves per SIMD the
+    # register allocation targets); SNET_CODEGEN_OPTS="fexp=<tag>" adds every combination for one shape, selected at
+    # run time by SNET_FV_BWD / SNET_FV_FWD="nwv,glds,occ" (kernel tuning only)
+    def_b = (int(OPTS.get('fnwv', 8)), int(OPTS.get('fglds', 0)), int(OPTS.get('focc', 2)))
+    def_f = (int(OPTS.get('fnwvf', 8)), int(OPTS.get('fgldsf', 0)), int(OPTS.get('foccf', 2)))
+    exp = OPTS.get('fexp') == tag
     DX, DOUT, NSH, WN = spec.irreps_x.dim, spec.irreps_out.dim, spec.irreps_sh.dim, spec.weight_numel
     cats, pairs_of, cols = schedule(spec)
     NS = len(cols)
@@ -68,6 +97,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('// GENERATED by sevennet_amd/codegen_fused.py -- do not edit.')
     A(f'// fused conv shape {tag}: x = {spec.irreps_x}, sh = {spec.irreps_sh}, out = {spec.irreps_out}')
     A(f'// {len(spec.paths)} paths, weight_numel = {WN}, {NS} sub-steps of two 16-column tiles')
+    A('#include <cstdio>')
+    A('#include <cstdlib>')
     A('#include "snet_common.h"')
     A('#include "snet_split.h"')
     A('namespace {')
@@ -119,14 +150,16 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A('  }')
         A('}')
         # ---- forward: lane = channel, the 4 edges of the lane's group in the vector components
-        A(f'__device__ __forceinline__ void fwdf_p{pi}(const float (&xr)[4][{d1}], const float (&ys)[4][NSH], const f32x4 w,')
+        A(f'__device__ __forceinline__ void fwdf_p{pi}(const float (&xr)[4][{d1}], const float *ysl, const f32x4 w,')
         A(f'    float (&acc)[{d3}]) {{')
         for r in range(4):
-            A(f'  {{  // edge {r} of the lane\'s group')
+            A(f'  {{  // edge {r} of the lane\'s group (its spherical harmonics: wave-private LDS rows)')
             for i in range(d3):
                 A(f'    float s{i} = 0.f;')
+            for b_ in sorted({b_ for (_, b_) in byab}):
+                A(f'    const float y{b_} = ysl[{r} * NSH + {p.sh_off + b_}];')
             for (a_, b_), cl in sorted(byab.items()):
-                A(f'    {{ const float xy = xr[{r}][{a_}] * ys[{r}][{p.sh_off + b_}];')
+                A(f'    {{ const float xy = xr[{r}][{a_}] * y{b_};')
                 for cc, v in cl:
                     A(f'      s{cc} = fmaf({_f(v)}, xy, s{cc});')
                 A('    }')
@@ -137,35 +170,37 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('')
 
     # ------------------------------------------------------------------ reverse kernel
-    A('template <int NT, int NWV>')
-    A(f'__global__ __launch_bounds__(64 * NWV, 2) void conv_bwdf_{tag}(const float *__restrict__ x, const float *__restrict__ sh,')
+    A('template <int NT, int NWV, bool GLDS, int OCC>')
+    A(f'__global__ __launch_bounds__(64 * NWV, OCC) void conv_bwdf_{tag}(const float *__restrict__ x, const float *__restrict__ sh,')
     A('    const float *__restrict__ dsh, const float *__restrict__ h2, const int32_t *__restrict__ w_row,')
     A('    const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ src, const int32_t *__restrict__ tile_ptr,')
-    A('    int n_nodes, int n_tiles, const u32x4 *__restrict__ slabs, float scale, const float *__restrict__ g_out,')
-    A('    float *__restrict__ g_xe, float *__restrict__ g_h2, float *__restrict__ g_vec) {')
-    A('  constexpr int LPS = 8 * NT, NTH = 64 * NWV, NST = LPS * 64 / NTH;  // 1-KB fragment lines per sub-step')
-    A('  static_assert(LPS * 64 % NTH == 0, "slab size must divide over the workgroup");')
+    A('    const int32_t *__restrict__ tile_node, int n_tiles, const u32x4 *__restrict__ slabs, float scale,')
+    A('    const float *__restrict__ g_out, float *__restrict__ g_xe, float *__restrict__ g_h2, float *__restrict__ g_vec, int diag) {')
+    A('  // diag: always 0 in production (bit 0 also serves as the opaque branch condition around the tensor-product bodies);')
+    A('  // kernel-tuning builds: 1 skip the tensor product, 2 skip the g_h2 products, 4 skip the w products, 8 skip the')
+    A('  // g_out loads, 16 skip the g_xe stores -- timing decomposition, results are then garbage')
+    A('  constexpr int LPS = 8 * NT, NTH = 64 * NWV, NST = (LPS * 64 + NTH - 1) / NTH;  // 1-KB fragment lines per sub-step')
     A('  __shared__ u32x4 slab[2][LPS * 64];')
     A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
     A('  const int j = lane & 15, g = lane >> 4;')
     A('  const int t_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
     A('  const bool live = t_raw < n_tiles;')
     A('  const int t = __builtin_amdgcn_readfirstlane(live ? t_raw : n_tiles - 1);  // idle waves shadow the last tile, stores masked')
-    A('  int lo = 0, hi = n_nodes;  // largest node with tile_ptr[node] <= t')
-    A('  while (hi - lo > 1) {')
-    A('    const int mid = (lo + hi) >> 1;')
-    A('    if (tile_ptr[mid] <= t) lo = mid; else hi = mid;')
-    A('  }')
-    A('  const int node = __builtin_amdgcn_readfirstlane(lo);')
+    A('  const int node = __builtin_amdgcn_readfirstlane(tile_node[t]);')
     A('  const int e0 = row_ptr[node] + 16 * (t - tile_ptr[node]);')
     A('  const int cnt = min(16, row_ptr[node + 1] - e0);')
     A('  const bool valid = live && j < cnt;')
     A('  const int e = e0 + min(j, cnt - 1);')
     A('  const int s_src = src[e];')
     A('  const int wr = w_row ? w_row[e] : e;')
-    A('  float ys[NSH];')
+    A('  // the edge\'s spherical harmonics wait in wave-private LDS ([component][edge]: conflict-free, the four channel')
+    A('  // groups of an edge read the same word) and are re-read per path: 9 .. 16 fewer live registers per lane')
+    A('  __shared__ float s_y[NWV][NSH * 16];')
+    A('  if (g == 0) {')
     A('#pragma unroll')
-    A('  for (int k = 0; k < NSH; ++k) ys[k] = sh[(size_t)e * NSH + k];')
+    A('    for (int k = 0; k < NSH; ++k) s_y[wave][k * 16 + j] = sh[(size_t)e * NSH + k];')
+    A('  }')
+    A('  const float *yl = &s_y[wave][j];')
     A('  SplitN<NT> hb[2];  // h2^T as B operand: column = edge, k slots (g, 0..7) <-> hidden unit 32 q + 8 g + slot')
     A('#pragma unroll')
     A('  for (int q = 0; q < 2; ++q) {')
@@ -180,35 +215,83 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  float gy[NSH];')
     A('#pragma unroll')
     A('  for (int k = 0; k < NSH; ++k) gy[k] = 0.f;')
-    A('  u32x4 st[NST];')
-    A('  auto stage_load = [&](int s) {')
-    A('#pragma unroll')
-    A('    for (int i = 0; i < NST; ++i) st[i] = slabs[(size_t)s * (LPS * 64) + tid + NTH * i];')
-    A('  };')
-    A('  auto stage_store = [&](int b) {')
-    A('#pragma unroll')
-    A('    for (int i = 0; i < NST; ++i) slab[b][tid + NTH * i] = st[i];')
-    A('  };')
-    A('  stage_load(0);')
+    _emit_staging(A, 'LPS')
+    # The node's g_out entries of one (x block, 16-channel tile) are shared by the 16 edge lanes of a group.  They
+    # are fetched ONCE per wave, one block ahead, by one or two 16-byte loads per lane (lane L: channels 4 (L & 3)
+    # .. +3 of entry 16 k + (L >> 2); vector-memory instructions, not bytes, are what this kernel runs out of),
+    # parked in a wave-private LDS buffer and read back as group-broadcast 16-byte reads.
+    glists = [[(pi, m3) for pi, p in cat.paths for m3 in range(2 * p.l3 + 1)] for cat in cats]
+    NGP = max((len(gl) + 15) // 16 * 16 for gl in glists)   # rows of the LDS buffer (padded to 16 entries per load)
+    NK = NGP // 16
+    A(f'  constexpr int NGP = {NGP}, NK = {NK};')
+    A('  __shared__ __attribute__((aligned(16))) float s_g[NWV][2][NGP * 16];')
+    A('  f32x4 gpre[NK];')
+    A('  const float *gnode = g_out + (size_t)((diag & 256) ? (node & 63) : node) * DOUT + 4 * (lane & 3);')
+    for ci, gl in enumerate(glists):   # per-lane offsets of the entries this lane fetches (-1: none)
+        for k in range((len(gl) + 15) // 16):
+            offs = [out_index(spec.paths[gl[q][0]], gl[q][1]) if q < len(gl) else -1 for q in range(16 * k, 16 * k + 16)]
+            A(f'  static const int32_t GOFF{ci}_{k}[16] = {{' + ', '.join(str(o) for o in offs) + '};')
+            A(f'  const int goff{ci}_{k} = GOFF{ci}_{k}[lane >> 2];')
+
+    def emit_g_loads(ind, ci, ct_expr):
+        gl = glists[ci]
+        for k in range((len(gl) + 15) // 16):
+            dg = '(diag & 8) ? f32x4{scale, scale, scale, scale} : ' if exp else ''
+            A(f'{ind}gpre[{k}] = {dg}(goff{ci}_{k} < 0) ? f32x4{{0.f, 0.f, 0.f, 0.f}} : '
+              f'*reinterpret_cast<const f32x4 *>(gnode + goff{ci}_{k} + 16 * ({ct_expr})) * scale;')
+
+    def emit_g_park(ind, ci, buf_expr):
+        gl = glists[ci]
+        for k in range((len(gl) + 15) // 16):
+            A(f'{ind}*reinterpret_cast<f32x4 *>(&s_g[wave][{buf_expr}][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]) = gpre[{k}];')
+
+    def g_row(ci, pi, m3):
+        return glists[ci].index((pi, m3))
+
+    emit_g_loads('  ', 0, '0')
+    emit_g_park('  ', 0, '0')
+    A('  stage_load(0, 0);')
     A('  stage_store(0);')
     A('  __syncthreads();')
-    A('  int sidx = 0, buf = 0;')
-    A('  const float *gnode = g_out + (size_t)node * DOUT + 4 * g;')
+    A('  int sidx = 0, buf = 0, gbuf = 0;')
     for ci, cat in enumerate(cats):
         d1 = 2 * cat.l1 + 1
         A(f'  // ---- x block {cat.i_x}: {cat.mul}x l={cat.l1}, {len(cat.paths)} paths')
-        A(f'  for (int ct = 0; ct < {cat.mul // 16}; ++ct) {{')
-        A(f'    const float *xs = x + (size_t)s_src * DX + {cat.x_off} + 16 * ct + 4 * g;')
-        A(f'    f32x4 xr[{d1}], gx[{d1}];')
+        nct = cat.mul // 16
+        # source rows: the next channel tile's slice is requested one block ahead (gather latency ~1-2 us)
+        A(f'  const float *xs{ci} = x + (size_t)s_src * DX + {cat.x_off} + 4 * g;')
+        A(f'  f32x4 xr{ci}[{d1}], xn{ci}[{d1}];')
         for m in range(d1):
-            A(f'    xr[{m}] = *reinterpret_cast<const f32x4 *>(xs + {m * cat.mul});')
+            A(f'  xr{ci}[{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {m * cat.mul});')
+        A(f'  for (int ct = 0; ct < {nct}; ++ct) {{')
+        A(f'    f32x4 (&xr)[{d1}] = xr{ci};')
+        A(f'    f32x4 gx[{d1}];')
+        for m in range(d1):
             A(f'    gx[{m}] = f32x4{{0.f, 0.f, 0.f, 0.f}};')
-        A('    const float *gb = gnode + 16 * ct;')
+        if nct > 1:
+            A(f'    if (ct + 1 < {nct}' + (' && !(diag & 64)' if exp else '') + ') {')
+            for m in range(d1):
+                A(f'      xn{ci}[{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + 16 * (ct + 1) + {m * cat.mul});')
+            A('    }')
+        A('    const float *gl_ = &s_g[wave][gbuf][4 * g];')
+        # next block's g_out entries: this x block's next channel tile, or the first tile of the next x block
+        if nct > 1:
+            A(f'    if (ct + 1 < {nct}) {{')
+            emit_g_loads('      ', ci, 'ct + 1')
+            A('    }' + (' else {' if ci + 1 < len(cats) else ''))
+            if ci + 1 < len(cats):
+                emit_g_loads('      ', ci + 1, '0')
+                A('    }')
+        elif ci + 1 < len(cats):
+            emit_g_loads('    ', ci + 1, '0')
         for (pa, pb) in pairs_of[ci]:
             A('    {')
-            A('      if (sidx + 1 < NS) stage_load(sidx + 1);')
+            A('      if (sidx + 1 < NS' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, buf ^ 1);')
+            # hipcc's machine scheduler, left alone, sinks the prefetch loads next to their use (zero overlap) and
+            # interleaves the phases until ~200 VGPRs spill: pin the prefetch at the top and fence the phases
+            A('      __builtin_amdgcn_sched_barrier(0);')
             A('      const u32x4 *sl = slab[buf];')
-            A('      f32x4 gw0, gw1 = f32x4{0.f, 0.f, 0.f, 0.f};')
+            A('      f32x4 gw0 = f32x4{0.f, 0.f, 0.f, 0.f}, gw1 = gw0;')
             for tp, pi in enumerate((pa, pb)):
                 if pi is None:
                     continue
@@ -216,6 +299,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 d3 = 2 * p.l3 + 1
                 A(f'      {{  // tile {tp}: path {pi}')
                 A('        f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
+                if exp:
+                    A('        if (diag & 4) wv = f32x4{yl[0], yl[16], yl[32], yl[48]}; else')
                 A('#pragma unroll')
                 A('        for (int q = 0; q < 2; ++q) {')
                 A('          bf16x8 a[NT];')
@@ -225,11 +310,20 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A('        }')
                 A(f'        f32x4 G[{d3}];')
                 for m3 in range(d3):
-                    A(f'        G[{m3}] = *reinterpret_cast<const f32x4 *>(gb + {out_index(p, m3)}) * scale;')
-                A(f'        bwdf_p{pi}(xr, ys, wv, G, gw{tp}, gy, gx);')
+                    A(f'        G[{m3}] = *reinterpret_cast<const f32x4 *>(gl_ + {g_row(ci, pi, m3)} * 16);')
+                A('        float ys[NSH];')
+                for b_ in range(2 * p.l2 + 1):
+                    A(f'        ys[{p.sh_off + b_}] = yl[{(p.sh_off + b_) * 16}];')
+                # The tensor-product body sits in its own (always taken) branch on an opaque kernel argument: as
+                # straight-line code hipcc's scheduler interleaves it with the surrounding matrix products and
+                # loads until ~200 VGPRs spill to scratch (measured: 692 spilled registers without the branch, 0 with)
+                A(f'        gw{tp} = f32x4{{0.f, 0.f, 0.f, 0.f}};')
+                A(f'        if (!(diag & 1)) bwdf_p{pi}(xr, ys, wv, G, gw{tp}, gy, gx);')
                 A('      }')
             A('      const float v[8] = {gw0[0], gw0[1], gw0[2], gw0[3], gw1[0], gw1[1], gw1[2], gw1[3]};')
             A('      const SplitN<NT> b = splitn8<NT>(v);')
+            if exp:
+                A('      if (diag & 2) ga[0] += f32x4{v[0], v[1], v[4], v[5]}; else')
             A('#pragma unroll')
             A('      for (int m = 0; m < 4; ++m) {')
             A('        bf16x8 a[NT];')
@@ -237,16 +331,31 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A('        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
             A('        ga[m] = mfma16_split<NT>(a, b, ga[m]);')
             A('      }')
-            A('      if (sidx + 1 < NS) stage_store(buf ^ 1);')
-            A('      __syncthreads();')
+            A('      if (sidx + 1 < NS' + (' && !(diag & 32)' if exp else '') + ') stage_store(buf ^ 1);')
+            A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
             A('      buf ^= 1;')
             A('      ++sidx;')
             A('    }')
-        A('    if (g_xe && valid) {')
+        A('    if (g_xe && valid' + (' && !(diag & 16)' if exp else '') + ') {')
         A(f'      float *o = g_xe + (size_t)e * DX + {cat.x_off} + 16 * ct + 4 * g;')
         for m in range(d1):
             A(f'      *reinterpret_cast<f32x4 *>(o + {m * cat.mul}) = gx[{m}];')
         A('    }')
+        # park the prefetched entries of the next block in the other buffer (last read one block ago)
+        if nct > 1:
+            A(f'    if (ct + 1 < {nct}) {{')
+            emit_g_park('      ', ci, 'gbuf ^ 1')
+            A('    }' + (' else {' if ci + 1 < len(cats) else ''))
+            if ci + 1 < len(cats):
+                emit_g_park('      ', ci + 1, 'gbuf ^ 1')
+                A('    }')
+        elif ci + 1 < len(cats):
+            emit_g_park('    ', ci + 1, 'gbuf ^ 1')
+        A('    gbuf ^= 1;')
+        A('    __builtin_amdgcn_wave_barrier();')
+        if nct > 1:
+            A('#pragma unroll')
+            A(f'    for (int m = 0; m < {d1}; ++m) xr{ci}[m] = xn{ci}[m];')
         A('  }')
     if dead_x:
         A('  if (g_xe && valid) {  // x blocks that feed no path get a zero gradient')
@@ -259,18 +368,22 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('#pragma unroll')
     A('    for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4 *>(g_h2 + (size_t)e * 64 + 16 * m + 4 * g) = ga[m];')
     A('  }')
-    A('  // d/d(edge_vec) = sum_i gy_i dY_i/dr (Y_0 is constant); the 4 channel groups of an edge are lanes j, j+16, j+32, j+48')
-    A('  float t0 = 0.f, t1 = 0.f, t2 = 0.f;')
-    A('  const float *jd = dsh + (size_t)e * (3 * NSH);')
+    A('  // d/d(edge_vec) = sum_i gy_i dY_i/dr (Y_0 is constant).  The 4 channel groups of an edge (lanes j, j+16, j+32,')
+    A('  // j+48) are summed with two permlane swaps per value; only the g == 0 lanes then touch dsh and g_vec.')
     A('#pragma unroll')
     A('  for (int i = 1; i < NSH; ++i) {')
-    A('    t0 = fmaf(gy[i], jd[3 * i], t0);')
-    A('    t1 = fmaf(gy[i], jd[3 * i + 1], t1);')
-    A('    t2 = fmaf(gy[i], jd[3 * i + 2], t2);')
+    A('    gy[i] = snet::swap_add16(gy[i], gy[i]);')
+    A('    gy[i] = snet::swap_add32(gy[i], gy[i]);')
     A('  }')
-    A('  t0 += __shfl_xor(t0, 16, 64); t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);')
-    A('  t0 += __shfl_xor(t0, 32, 64); t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);')
     A('  if (valid && g == 0) {')
+    A('    float t0 = 0.f, t1 = 0.f, t2 = 0.f;')
+    A('    const float *jd = dsh + (size_t)e * (3 * NSH);')
+    A('#pragma unroll')
+    A('    for (int i = 1; i < NSH; ++i) {')
+    A('      t0 = fmaf(gy[i], jd[3 * i], t0);')
+    A('      t1 = fmaf(gy[i], jd[3 * i + 1], t1);')
+    A('      t2 = fmaf(gy[i], jd[3 * i + 2], t2);')
+    A('    }')
     A('    float *o = g_vec + (size_t)e * 3;')
     A('    o[0] += t0; o[1] += t1; o[2] += t2;')
     A('  }')
@@ -278,14 +391,32 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('')
 
     # ------------------------------------------------------------------ forward kernel
-    A('template <int NT, int NWV>')
-    A(f'__global__ __launch_bounds__(64 * NWV, 2) void conv_fwdf_{tag}(const float *__restrict__ x, const float *__restrict__ sh,')
+    # One wavefront = one destination node, up to two 16-edge tiles per pass.  The weight stream is consumed in
+    # BLOCKS of up to FG sub-steps (all paths of one (x block, 16-channel tile) when there are <= 2 FG of them):
+    # one workgroup barrier per block; inside a block the wave walks its tiles, and for each tile stages the 16
+    # source rows' slice ONCE in wave-private LDS with d1 16-byte loads per lane (instead of 4 d1 4-byte gathers
+    # per path pair), then runs every path of the block on it.  Output rows leave through LDS too: 16-byte
+    # stores of 4 channels per lane instead of one 64-byte row segment per instruction.
+    FG = int(OPTS.get('ffg', 3))
+    fgroups = []   # per cat: list of groups, each a list of (sub-step index within the (cat, ct) block, (pa, pb))
+    for ci, cat in enumerate(cats):
+        prs = list(enumerate(pairs_of[ci]))
+        fgroups.append([prs[i:i + FG] for i in range(0, len(prs), FG)])
+    LPB = max(len(grp) for gl in fgroups for grp in gl)          # sub-steps per slab block
+    NOE = max(sum(2 * spec.paths[pi].l3 + 1 for _, pr in grp for pi in pr if pi is not None) for gl in fgroups for grp in gl)
+    NOEP = (NOE + 15) // 16 * 16
+    MAXD1 = max(2 * cat.l1 + 1 for cat in cats)
+    A('template <int NT, int NWV, bool GLDS, int OCC>')
+    A(f'__global__ __launch_bounds__(64 * NWV, OCC) void conv_fwdf_{tag}(const float *__restrict__ x, const float *__restrict__ sh,')
     A('    const float *__restrict__ h2, const int32_t *__restrict__ w_row, const int32_t *__restrict__ row_ptr,')
-    A('    const int32_t *__restrict__ src, int n_nodes, const u32x4 *__restrict__ slabs, float scale, float *__restrict__ out) {')
-    A('  constexpr int LPS = 8 * NT, LPF = 4 * NT, NTH = 64 * NWV, NST = LPF * 64 / NTH;  // only the w part of each sub-step is staged')
-    A('  static_assert(LPF * 64 % NTH == 0, "slab size must divide over the workgroup");')
-    A('  __shared__ u32x4 slab[2][LPF * 64];')
+    A('    const int32_t *__restrict__ src, int n_nodes, const u32x4 *__restrict__ slabs, float scale, float *__restrict__ out, int diag) {')
+    A(f'  constexpr int LPS = 8 * NT, LPF = 4 * NT, LPB = {LPB}, NTH = 64 * NWV;  // lines per sub-step (all / w part), sub-steps per block')
+    A('  constexpr int NSTB = (LPB * LPF * 64 + NTH - 1) / NTH;')
+    A('  __shared__ u32x4 slab[2][LPB * LPF * 64];')
     A('  __shared__ int s_pass[NWV];')
+    A('  __shared__ __attribute__((aligned(16))) float s_ys[NWV][32 * NSH];  // spherical harmonics of the pass\'s edges')
+    A(f'  __shared__ __attribute__((aligned(16))) float s_x[NWV][{MAXD1} * 256];  // source-row slice of one tile: [m][r][g][channel]')
+    A(f'  __shared__ __attribute__((aligned(16))) float s_o[NWV][{NOEP} * 16];      // output rows of one block: [entry][channel]')
     A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
     A('  const int c = lane & 15, g = lane >> 4;')
     A('  const int n_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
@@ -298,111 +429,162 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  int n_pass = 1;  // every wave of the block walks the weight stream the same number of times')
     A('#pragma unroll')
     A('  for (int i = 0; i < NWV; ++i) n_pass = max(n_pass, s_pass[i]);')
-    A('  u32x4 st[NST];')
-    A('  auto stage_load = [&](int s) {')
+    # block staging: sub-steps s0 .. s0 + n - 1, only their w parts (LPF lines each)
+    A('  u32x4 st[GLDS ? 1 : NSTB];')
+    A('  auto stage_load = [&](int s0, int n, int b) {  // the w parts of sub-steps s0 .. s0 + n - 1 -> slab[b]')
+    A('    if constexpr (GLDS) {')
+    A('      for (int l = wave; l < n * LPF; l += NWV)')
+    A('        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(slabs + (size_t)(s0 + l / LPF) * (LPS * 64) + (l % LPF) * 64 + lane),')
+    A('                                         (__attribute__((address_space(3))) void *)(&slab[b][l * 64]), 16, 0, 0);')
+    A('    } else {')
     A('#pragma unroll')
-    A('    for (int i = 0; i < NST; ++i) st[i] = slabs[(size_t)s * (LPS * 64) + tid + NTH * i];')
+    A('      for (int i = 0; i < NSTB; ++i) {')
+    A('        const int f = tid + NTH * i, l = f >> 6;')
+    A('        if (l < n * LPF) st[i] = slabs[(size_t)(s0 + l / LPF) * (LPS * 64) + (l % LPF) * 64 + (f & 63)];')
+    A('      }')
+    A('    }')
     A('  };')
-    A('  auto stage_store = [&](int b) {')
+    A('  auto stage_store = [&](int n, int b) {')
+    A('    if constexpr (!GLDS) {')
     A('#pragma unroll')
-    A('    for (int i = 0; i < NST; ++i) slab[b][tid + NTH * i] = st[i];')
+    A('      for (int i = 0; i < NSTB; ++i) if (((tid + NTH * i) >> 6) < n * LPF) slab[b][tid + NTH * i] = st[i];')
+    A('    }')
     A('  };')
-    A('  float *onode = out + (size_t)node * DOUT + c;')
+    A('  float *onode = out + (size_t)node * DOUT + 4 * (lane & 3);')
+    A('  const bool has_e = e_end > e_beg;')
+    A('  const int e_last = max(e_beg, e_end - 1);  // clamp target for padded rows (their weight is zeroed)')
+    # output offsets per (cat, group): entry = 16 k + (lane >> 2)
+    olists = {}
+    for ci, gl in enumerate(fgroups):
+        for gi, grp in enumerate(gl):
+            ol = [(pi, m3) for _, pr in grp for pi in pr if pi is not None for m3 in range(2 * spec.paths[pi].l3 + 1)]
+            olists[(ci, gi)] = ol
+            for k in range((len(ol) + 15) // 16):
+                offs = [out_index(spec.paths[ol[q][0]], ol[q][1]) if q < len(ol) else -1 for q in range(16 * k, 16 * k + 16)]
+                A(f'  static const int32_t OOFF{ci}_{gi}_{k}[16] = {{' + ', '.join(str(o) for o in offs) + '};')
+                A(f'  const int ooff{ci}_{gi}_{k} = OOFF{ci}_{gi}_{k}[lane >> 2];')
+    # flat block schedule: first sub-step index and size of every block, in stream order
     A('  for (int pass = 0; pass < n_pass; ++pass) {')
     A('    const int eb = e_beg + 32 * pass;')
-    A('    const int n_e = max(0, min(32, e_end - eb));  // edges of this pass: tile 0 = [0,16), tile 1 = [16,32)')
+    A('    const int n_e = live ? max(0, min(32, e_end - eb)) : 0;  // edges of this pass: tile 0 = [0,16), tile 1 = [16,32)')
     A('    const bool two = n_e > 16;')
-    A('    const int e_last = max(e_beg, e_end - 1);  // clamp target for padded rows (their weight is zeroed)')
-    A('    // per tile: A fragments of h2 (row = edge lane & 15), and the 4 edges (4 g + r) this lane accumulates')
+    A('    // per tile: A fragments of h2 (row = edge lane & 15) and the source row this lane stages (edge lane >> 2)')
     A('    SplitN<NT> ha[2][2];')
-    A('    int sr[2][4];')
-    A('    float ys[2][4][NSH];')
-    A('    bool ok[2][4];')
+    A('    int srs[2];')
     A('#pragma unroll')
     A('    for (int tl = 0; tl < 2; ++tl) {')
     A('      const int ea = min(eb + 16 * tl + c, e_last);')
-    A('      const int wra = (e_end > e_beg) ? (w_row ? w_row[ea] : ea) : 0;')
+    A('      const int wra = has_e ? (w_row ? w_row[ea] : ea) : 0;')
     A('#pragma unroll')
     A('      for (int q = 0; q < 2; ++q) {')
     A('        f32x4 lo4 = f32x4{0.f, 0.f, 0.f, 0.f}, hi4 = lo4;')
-    A('        if (e_end > e_beg) {')
+    A('        if (has_e) {')
     A('          lo4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wra * 64 + 32 * q + 8 * g);')
     A('          hi4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wra * 64 + 32 * q + 8 * g + 4);')
     A('        }')
     A('        const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};')
     A('        ha[tl][q] = splitn8<NT>(v);')
     A('      }')
-    A('#pragma unroll')
-    A('      for (int r = 0; r < 4; ++r) {')
-    A('        const int el = 16 * tl + 4 * g + r;')
-    A('        ok[tl][r] = live && el < n_e;')
-    A('        const int er = min(eb + el, e_last);')
-    A('        sr[tl][r] = (e_end > e_beg) ? src[er] : 0;')
-    A('#pragma unroll')
-    A('        for (int k = 0; k < NSH; ++k) ys[tl][r][k] = (e_end > e_beg) ? sh[(size_t)er * NSH + k] : 0.f;')
-    A('      }')
+    A('      srs[tl] = has_e ? src[min(eb + 16 * tl + (lane >> 2), e_last)] : 0;')
     A('    }')
-    A('    stage_load(0);')
-    A('    stage_store(0);')
-    A('    __syncthreads();')
+    A('    for (int i = lane; i < 32 * NSH; i += 64) {')
+    A('      const int el = i / NSH;')
+    A('      s_ys[wave][i] = has_e ? sh[(size_t)min(eb + el, e_last) * NSH + (i - el * NSH)] : 0.f;')
+    A('    }')
+    first_n = len(fgroups[0][0])
+    A(f'    stage_load(0, {first_n}, 0);')
+    A(f'    stage_store({first_n}, 0);')
+    A('    __syncthreads();  // also orders the wave\'s s_ys stores before its reads')
     A('    int sidx = 0, buf = 0;')
     for ci, cat in enumerate(cats):
         d1 = 2 * cat.l1 + 1
+        nct = cat.mul // 16
+        npairs = len(pairs_of[ci])
         A(f'    // ---- x block {cat.i_x}: {cat.mul}x l={cat.l1}, {len(cat.paths)} paths')
-        A(f'    for (int ct = 0; ct < {cat.mul // 16}; ++ct) {{')
-        A(f'      float xr[2][4][{d1}];')
-        A('#pragma unroll')
-        A('      for (int tl = 0; tl < 2; ++tl)')
-        A('#pragma unroll')
-        A('        for (int r = 0; r < 4; ++r) {')
-        A(f'          const float *xs = x + (size_t)sr[tl][r] * DX + {cat.x_off} + 16 * ct + c;')
-        for m in range(d1):
-            A(f'          xr[tl][r][{m}] = (tl == 0 || two) ? xs[{m * cat.mul}] : 0.f;')
-        A('        }')
-        A('      float *ob = onode + 16 * ct;')
-        for (pa, pb) in pairs_of[ci]:
+        A(f'    for (int ct = 0; ct < {nct}; ++ct) {{')
+        # staged slice: lane L holds channels 4 (L & 3) .. + 3 of edge L >> 2
+        A(f'      const float *xb = x + {cat.x_off} + 16 * ct + 4 * (lane & 3);')
+        for gi, grp in enumerate(fgroups[ci]):
+            n_here = len(grp)
+            # what the next block is (for the slab prefetch): next group of this ct, next ct, or the next x block
+            if gi + 1 < len(fgroups[ci]):
+                nxt = f'{len(fgroups[ci][gi + 1])}'
+            else:
+                n_first = len(fgroups[ci][0])
+                n_next_cat = len(fgroups[ci + 1][0]) if ci + 1 < len(cats) else 0
+                nxt = f'(ct + 1 < {nct} ? {n_first} : {n_next_cat})'
+            ol = olists[(ci, gi)]
             A('      {')
-            A('        if (sidx + 1 < NS) stage_load(sidx + 1);')
+            A(f'        const int n_next = (sidx + {n_here} < NS) ? {nxt} : 0;')
+            A(f'        if (n_next) stage_load(sidx + {n_here}, n_next, buf ^ 1);')
+            A('        __builtin_amdgcn_sched_barrier(0);  // the scheduler would sink the prefetch next to its use')
             A('        const u32x4 *sl = slab[buf];')
-            for tp, pi in enumerate((pa, pb)):
-                if pi is None:
-                    continue
-                p = spec.paths[pi]
-                d3 = 2 * p.l3 + 1
-                A(f'        {{  // tile {tp}: path {pi}')
-                A(f'          float acc[{d3}];')
-                A('#pragma unroll')
-                A(f'          for (int i = 0; i < {d3}; ++i) acc[i] = 0.f;')
-                A('          bf16x8 bfr[2][NT];')
-                A('#pragma unroll')
-                A('          for (int q = 0; q < 2; ++q)')
-                A('#pragma unroll')
-                A(f'            for (int tm = 0; tm < NT; ++tm) bfr[q][tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
-                A('#pragma unroll')
-                A('          for (int tl = 0; tl < 2; ++tl) {')
-                A('            if (tl == 0 || two) {')
-                A('              f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
-                A('#pragma unroll')
-                A('              for (int q = 0; q < 2; ++q) wv = mfma16_split<NT>(ha[tl][q], bfr[q], wv);')
-                A('#pragma unroll')
-                A('              for (int r = 0; r < 4; ++r) wv[r] = ok[tl][r] ? wv[r] : 0.f;')
-                A(f'              fwdf_p{pi}(xr[tl], ys[tl], wv, acc);')
-                A('            }')
-                A('          }')
-                A('#pragma unroll')
-                A(f'          for (int i = 0; i < {d3}; ++i) {{')
-                A('            acc[i] += __shfl_xor(acc[i], 16, 64);')
-                A('            acc[i] += __shfl_xor(acc[i], 32, 64);')
-                A('          }')
-                A('          if (live && g == 0) {')
-                for m3 in range(d3):
-                    A(f'            ob[{out_index(p, m3)}] = (pass ? ob[{out_index(p, m3)}] : 0.f) + acc[{m3}] * scale;')
-                A('          }')
+            for _, pr in grp:
+                for pi in pr:
+                    if pi is not None:
+                        A(f'        float acc{pi}[{2 * spec.paths[pi].l3 + 1}];')
+                        A('#pragma unroll')
+                        A(f'        for (int i = 0; i < {2 * spec.paths[pi].l3 + 1}; ++i) acc{pi}[i] = 0.f;')
+            A('#pragma unroll')
+            A('        for (int tl = 0; tl < 2; ++tl) {')
+            A('          if (tl == 0 || two) {')
+            A('            {  // stage the 16 source rows\' slice: [m][r][g][channel], conflict-free for the reads below')
+            A('              const float *xs = xb + (size_t)srs[tl] * DX;')
+            A(f'              f32x4 xv[{d1}];')
+            for m in range(d1):
+                A(f'              xv[{m}] = *reinterpret_cast<const f32x4 *>(xs + {m * cat.mul});')
+            A('              __builtin_amdgcn_wave_barrier();  // every read of the previous tile\'s slice has been issued')
+            A('              float *xw = &s_x[wave][(((lane >> 2) & 3) * 4 + (lane >> 4)) * 16 + 4 * (lane & 3)];')
+            for m in range(d1):
+                A(f'              *reinterpret_cast<f32x4 *>(xw + {m * 256}) = xv[{m}];')
+            A('              __builtin_amdgcn_wave_barrier();')
+            A('            }')
+            A(f'            float xr[4][{d1}];')
+            A('#pragma unroll')
+            A('            for (int r = 0; r < 4; ++r)')
+            A('#pragma unroll')
+            A(f'              for (int m = 0; m < {d1}; ++m) xr[r][m] = s_x[wave][m * 256 + r * 64 + lane];')
+            A('            const float *ysl = &s_ys[wave][(16 * tl + 4 * g) * NSH];')
+            for ls, pr in grp:
+                for tp, pi in enumerate(pr):
+                    if pi is None:
+                        continue
+                    A(f'            {{  // sub-step {ls} of the block, tile {tp}: path {pi}')
+                    A('              f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
+                    A('#pragma unroll')
+                    A('              for (int q = 0; q < 2; ++q) {')
+                    A('                bf16x8 bfr[NT];')
+                    A('#pragma unroll')
+                    A(f'                for (int tm = 0; tm < NT; ++tm) bfr[tm] = as_bf16x8(sl[(({ls - grp[0][0]} * 4 + {tp} * 2 + q) * NT + tm) * 64 + lane]);')
+                    A('                wv = mfma16_split<NT>(ha[tl][q], bfr, wv);')
+                    A('              }')
+                    A('#pragma unroll')
+                    A('              for (int r = 0; r < 4; ++r) wv[r] = (16 * tl + 4 * g + r < n_e) ? wv[r] : 0.f;')
+                    A(f'              if (!(diag & 1)) fwdf_p{pi}(xr, ysl, wv, acc{pi});  // opaque branch: see the reverse kernel')
+                    A('            }')
+            A('          }')
+            A('        }')
+            # reduce over the 4 edge groups, park in LDS, write out with 16-byte stores
+            for q, (pi, m3) in enumerate(ol):
+                A(f'        acc{pi}[{m3}] = snet::swap_add16(acc{pi}[{m3}], acc{pi}[{m3}]);')
+                A(f'        acc{pi}[{m3}] = snet::swap_add32(acc{pi}[{m3}], acc{pi}[{m3}]);')
+            A('        __builtin_amdgcn_wave_barrier();')
+            A('        if (g == 0) {')
+            for q, (pi, m3) in enumerate(ol):
+                A(f'          s_o[wave][{q} * 16 + c] = acc{pi}[{m3}] * scale;')
+            A('        }')
+            A('        __builtin_amdgcn_wave_barrier();')
+            for k in range((len(ol) + 15) // 16):
+                A(f'        if (live && ooff{ci}_{gi}_{k} >= 0) {{')
+                A(f'          float *o = onode + ooff{ci}_{gi}_{k} + 16 * ct;')
+                A(f'          f32x4 v = *reinterpret_cast<const f32x4 *>(&s_o[wave][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]);')
+                A('          if (pass) v += *reinterpret_cast<const f32x4 *>(o);')
+                A('          *reinterpret_cast<f32x4 *>(o) = v;')
                 A('        }')
-            A('        if (sidx + 1 < NS) stage_store(buf ^ 1);')
+            A('        if (n_next) stage_store(n_next, buf ^ 1);')
             A('        __syncthreads();')
             A('        buf ^= 1;')
-            A('        ++sidx;')
+            A(f'        sidx += {n_here};')
             A('      }')
         A('    }')
     A('  }')
@@ -410,33 +592,92 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('')
 
     # ------------------------------------------------------------------ launchers
-    A('template <int NT, int NWV>')
+    def variants(default, fwd=False):
+        combos = [default]
+        if exp:
+            cand = ((4, 0, 2), (8, 0, 2), (8, 1, 2), (4, 0, 3), (12, 0, 3), (12, 1, 3)) if fwd else \
+                ((4, 0, 2), (8, 0, 2), (8, 1, 2), (4, 0, 3), (4, 1, 3), (12, 0, 3), (12, 1, 3), (8, 1, 4))
+            combos += [v for v in cand if v != default]
+        return combos
+
+    A('template <int NT, int NWV, bool GLDS, int OCC>')
     A('void launch_bwd_t(const float *x, const float *sh, const float *dsh, const float *h2, const int32_t *w_row,')
-    A('                  const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, int64_t n_dst, int64_t n_tiles,')
+    A('                  const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, const int32_t *tile_node, int64_t n_tiles,')
     A('                  const void *slabs, float scale, const float *g_out, float *g_xe, float *g_h2, float *g_vec, hipStream_t st) {')
     A('  const unsigned grid = (unsigned)((n_tiles + NWV - 1) / NWV);')
-    A(f'  conv_bwdf_{tag}<NT, NWV><<<dim3(grid), dim3(64 * NWV), 0, st>>>(x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, (int)n_dst,')
-    A('      (int)n_tiles, static_cast<const u32x4 *>(slabs), scale, g_out, g_xe, g_h2, g_vec);')
+    A('  int diag = 0;')
+    if exp:
+        A('  if (const char *e = getenv("SNET_FV_DIAG")) diag = atoi(e);')
+    A(f'  conv_bwdf_{tag}<NT, NWV, GLDS, OCC><<<dim3(grid), dim3(64 * NWV), 0, st>>>(x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node,')
+    A('      (int)n_tiles, static_cast<const u32x4 *>(slabs), scale, g_out, g_xe, g_h2, g_vec, diag);')
     A('}')
     A('void launch_bwd(int nt, const float *x, const float *sh, const float *dsh, const float *h2, const int32_t *w_row,')
-    A('                const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, int64_t n_dst, int64_t n_tiles,')
+    A('                const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, const int32_t *tile_node, int64_t n_tiles,')
     A('                const void *slabs, float scale, const float *g_out, float *g_xe, float *g_h2, float *g_vec, hipStream_t st) {')
-    A('  if (nt == 3) launch_bwd_t<3, 4>(x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, n_dst, n_tiles, slabs, scale, g_out, g_xe, g_h2, g_vec, st);')
-    A('  else if (nt == 2) launch_bwd_t<2, 4>(x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, n_dst, n_tiles, slabs, scale, g_out, g_xe, g_h2, g_vec, st);')
-    A('  else launch_bwd_t<1, 4>(x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, n_dst, n_tiles, slabs, scale, g_out, g_xe, g_h2, g_vec, st);')
+    args_b = 'x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node, n_tiles, slabs, scale, g_out, g_xe, g_h2, g_vec, st'
+    if exp:
+        A('  int vw = %d, vg = %d, vo = %d;' % def_b)
+        A('  if (const char *e = getenv("SNET_FV_BWD")) sscanf(e, "%d,%d,%d", &vw, &vg, &vo);')
+        for (w, gl, oc) in variants(def_b):
+            for nt_ in (3, 2):
+                A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<{nt_}, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
+    def bwd_lds(nt, nwv):
+        return 2 * 8 * nt * 1024 + nwv * (2 * NGP * 64 + NSH * 64)
+
+    def bwd_cfg(nt):
+        # measured on MI355X (SevenNet-0 middle layer): three 4-wave workgroups per CU (LDS <= 53 KB each, <= 168
+        # VGPRs) beat two; when the slab does not leave room for three, two 4-wave workgroups at 256 VGPRs
+        if 'fnwv' in OPTS:
+            return def_b
+        if bwd_lds(nt, 4) <= 53 * 1024:
+            return (4, 0, 3)
+        if bwd_lds(nt, 4) <= 80 * 1024:
+            return (4, 0, 2)
+        return (2, 0, 2)
+    for nt_, kw in ((3, 'if'), (2, 'else if'), (1, 'else')):
+        w, gl, oc = bwd_cfg(nt_)
+        cond = f' (nt == {nt_})' if kw != 'else' else ''
+        A(f'  {kw}{cond} launch_bwd_t<{nt_}, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
     A('}')
-    A('template <int NT, int NWV>')
+    A('template <int NT, int NWV, bool GLDS, int OCC>')
     A('void launch_fwd_t(const float *x, const float *sh, const float *h2, const int32_t *w_row, const int32_t *row_ptr,')
     A('                  const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, hipStream_t st) {')
     A('  const unsigned grid = (unsigned)((n_dst + NWV - 1) / NWV);')
-    A(f'  conv_fwdf_{tag}<NT, NWV><<<dim3(grid), dim3(64 * NWV), 0, st>>>(x, sh, h2, w_row, row_ptr, src, (int)n_dst,')
-    A('      static_cast<const u32x4 *>(slabs), scale, out);')
+    A('  int diag = 0;')
+    if exp:
+        A('  if (const char *e = getenv("SNET_FV_DIAG")) diag = atoi(e);')
+    A(f'  conv_fwdf_{tag}<NT, NWV, GLDS, OCC><<<dim3(grid), dim3(64 * NWV), 0, st>>>(x, sh, h2, w_row, row_ptr, src, (int)n_dst,')
+    A('      static_cast<const u32x4 *>(slabs), scale, out, diag);')
     A('}')
     A('void launch_fwd(int nt, const float *x, const float *sh, const float *h2, const int32_t *w_row, const int32_t *row_ptr,')
     A('                const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, hipStream_t st) {')
-    A('  if (nt == 3) launch_fwd_t<3, 4>(x, sh, h2, w_row, row_ptr, src, n_dst, slabs, scale, out, st);')
-    A('  else if (nt == 2) launch_fwd_t<2, 4>(x, sh, h2, w_row, row_ptr, src, n_dst, slabs, scale, out, st);')
-    A('  else launch_fwd_t<1, 4>(x, sh, h2, w_row, row_ptr, src, n_dst, slabs, scale, out, st);')
+    args_f = 'x, sh, h2, w_row, row_ptr, src, n_dst, slabs, scale, out, st'
+    if exp:
+        A('  int vw = %d, vg = %d, vo = %d;' % def_f)
+        A('  if (const char *e = getenv("SNET_FV_FWD")) sscanf(e, "%d,%d,%d", &vw, &vg, &vo);')
+        for (w, gl, oc) in variants(def_f, True):
+            for nt_ in (3, 2):
+                if nt_ == 3 and w > 8:
+                    continue   # would not fit the 160-KB LDS
+                A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_fwd_t<{nt_}, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
+    def fwd_lds(nt, nwv):
+        return 2 * LPB * 4 * nt * 1024 + nwv * (32 * NSH * 4 + MAXD1 * 1024 + NOEP * 64) + 4 * nwv
+
+    def fwd_cfg(nt):
+        # measured: occupancy decides -- one 12-wave workgroup per CU at <= 168 VGPRs (3 waves per SIMD, direct
+        # global->LDS staging) where the LDS and the register count of this nt allow it, 8 or 4 waves otherwise
+        if 'fnwvf' in OPTS:
+            return def_f
+        if nt <= 2 and fwd_lds(nt, 12) <= 160 * 1024:
+            return (12, 1, 3)
+        for w in (8, 4, 2, 1):
+            if fwd_lds(nt, w) <= 160 * 1024:
+                return (w, 1, 2)
+        raise NotImplementedError(f'conv shape {spec.key}: the fused forward kernel does not fit the LDS')
+    for nt_, kw in ((3, 'if'), (2, 'else if'), (1, 'else')):
+        w, gl, oc = fwd_cfg(nt_)
+        cond = f' (nt == {nt_})' if kw != 'else' else ''
+        A(f'  {kw}{cond} launch_fwd_t<{nt_}, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
     A('}')
     A(f'const snet::FusedKernels kernels = {{"{tag}", DX, DOUT, NSH, WN, NS, SUB_COLS, launch_bwd, launch_fwd}};')
     A('const snet::FusedRegistrar registrar(&kernels);')

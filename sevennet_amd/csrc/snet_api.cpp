@@ -138,13 +138,14 @@ int snet_conv_fwd_fused(const snet_fused_plan *fp, const float *x, const float *
 }
 int snet_conv_bwd_fused(const snet_fused_plan *fp, const float *x, const float *sh, const float *dsh, const float *h2,
                         const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr,
-                        int64_t n_dst, int64_t n_tiles, float scale, const float *g_out, float *g_xe, float *g_h2,
-                        float *g_vec, void *stream) {
+                        const int32_t *tile_node, int64_t n_tiles, float scale, const float *g_out, float *g_xe,
+                        float *g_h2, float *g_vec, void *stream) {
   SNET_REQUIRE(fp != nullptr, "snet_conv_bwd_fused: null plan");
-  SNET_REQUIRE(n_dst < (1ll << 31) && n_tiles < (1ll << 31), "snet_conv_bwd_fused: too many nodes / tiles");
-  if (n_dst <= 0 || n_tiles <= 0) return 0;
-  fp->k->bwd(fp->terms, x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, n_dst, n_tiles, fp->slabs, scale, g_out, g_xe,
-             g_h2, g_vec, static_cast<hipStream_t>(stream));
+  SNET_REQUIRE(n_tiles < (1ll << 31), "snet_conv_bwd_fused: too many tiles");
+  if (n_tiles <= 0) return 0;
+  SNET_REQUIRE(tile_ptr != nullptr && tile_node != nullptr, "snet_conv_bwd_fused: null tile list");
+  fp->k->bwd(fp->terms, x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node, n_tiles, fp->slabs, scale, g_out,
+             g_xe, g_h2, g_vec, static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_conv_bwd_fused");
   return 0;
 }

@@ -64,9 +64,9 @@ struct FusedKernels {
   const int32_t *sub_cols;
   // reverse pass of one tile list (snet_edge_tiles): g_xe[E,dx] (nullable), g_h2[E,64], g_vec[E,3] +=
   void (*bwd)(int nt, const float *x, const float *sh, const float *dsh, const float *h2, const int32_t *w_row,
-              const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, int64_t n_dst, int64_t n_tiles,
-              const void *slabs, float scale, const float *g_out, float *g_xe, float *g_h2, float *g_vec,
-              hipStream_t st);
+              const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, const int32_t *tile_node,
+              int64_t n_tiles, const void *slabs, float scale, const float *g_out, float *g_xe, float *g_h2,
+              float *g_vec, hipStream_t st);
   // forward: out[n_dst, dout]
   void (*fwd)(int nt, const float *x, const float *sh, const float *h2, const int32_t *w_row, const int32_t *row_ptr,
               const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, hipStream_t st);

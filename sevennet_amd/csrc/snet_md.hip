@@ -235,8 +235,13 @@ struct TileScratch {
   DevBuf<int32_t> cnt;
   DevBuf<char> tmp;
 };
-int edge_tiles_impl(TileScratch &S, const int32_t *row_ptr, int64_t n_dst, int32_t *tile_ptr, int64_t *n_tiles,
-                    hipStream_t st) {
+__global__ void tile_node_kernel(const int32_t *__restrict__ tile_ptr, int64_t n, int32_t *__restrict__ tile_node) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = tile_ptr[i]; k < tile_ptr[i + 1]; ++k) tile_node[k] = (int32_t)i;
+}
+int edge_tiles_impl(TileScratch &S, const int32_t *row_ptr, int64_t n_dst, int32_t *tile_ptr, int32_t *tile_node,
+                    int64_t tile_capacity, int64_t *n_tiles, hipStream_t st) {
   *n_tiles = 0;
   if (n_dst <= 0) return 0;
   SNET_REQUIRE(n_dst < (1LL << 31) - 1, "snet_edge_tiles: too many nodes");
@@ -255,14 +260,21 @@ int edge_tiles_impl(TileScratch &S, const int32_t *row_ptr, int64_t n_dst, int32
                    hipStreamSynchronize(st) == hipSuccess,
                "snet_edge_tiles: readback failed");
   *n_tiles = nt;
+  SNET_REQUIRE(nt <= tile_capacity, "snet_edge_tiles: tile_node capacity too small (n_dst + n_edges / 16 always suffices)");
+  if (nt > 0) {
+    tile_node_kernel<<<(unsigned)((n_dst + 255) / 256), 256, 0, st>>>(tile_ptr, n_dst, tile_node);
+    SNET_CHECK_LAUNCH("tile_node_kernel");
+  }
   return 0;
 }
 }  // namespace
 
-extern "C" int snet_edge_tiles(const int32_t *row_ptr, int64_t n_dst, int32_t *tile_ptr, int64_t *n_tiles, void *stream) {
-  SNET_REQUIRE(row_ptr && tile_ptr && n_tiles, "snet_edge_tiles: null argument");
+extern "C" int snet_edge_tiles(const int32_t *row_ptr, int64_t n_dst, int32_t *tile_ptr, int32_t *tile_node,
+                               int64_t tile_capacity, int64_t *n_tiles, void *stream) {
+  SNET_REQUIRE(row_ptr && tile_ptr && tile_node && n_tiles, "snet_edge_tiles: null argument");
   static thread_local TileScratch scratch;  // grow-only, one per host thread
-  return edge_tiles_impl(scratch, row_ptr, n_dst, tile_ptr, n_tiles, static_cast<hipStream_t>(stream));
+  return edge_tiles_impl(scratch, row_ptr, n_dst, tile_ptr, tile_node, tile_capacity, n_tiles,
+                         static_cast<hipStream_t>(stream));
 }
 
 struct snet_md_host {

@@ -291,7 +291,7 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
                                             m->act_radial, m->act_cst, 1, &L.mlp_plan)) good = false;
     if (good && snet_conv_plan_create(L.tag, &L.conv)) good = false;
     if (good && getenv("SNET_NO_FUSED") == nullptr && snet_conv_fused_available(L.conv) &&
-        snet_fused_plan_create(L.conv, L.mlp_plan, 3, &L.fused))
+        snet_fused_plan_create(L.conv, L.mlp_plan, SNET_FUSED_TERMS_DEFAULT, &L.fused))
       good = false;
     good = good && read_linear(r, L.sc) && read_linear(r, L.si1) && read_linear(r, L.si2);
     if (good) {
@@ -486,7 +486,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   size_t wn_max = 0;
   for (auto &L : m->layers) wn_max = wn_max > (size_t)L.wn ? wn_max : (size_t)L.wn;
   if (ov) { add((size_t)E * wn_max); add((size_t)E * wn_max); }  // g_w double buffer (its reader runs on the side stream)
-  if (any_fused) add((size_t)N + 64);  // tile_ptr
+  if (any_fused) { add((size_t)N + 64); add((size_t)N + (size_t)E / 16 + 64); }  // tile_ptr, tile_node
   add((size_t)NT * dmax * 2 + 256); add((size_t)N * (m->ro1.dim_out + 8) * 2); add(trans + 64 * 1024);
   need += 1 << 20;
   if (m->arena.cap < need) {
@@ -520,11 +520,12 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     saved[t].w = A.f(m->layers[t].fused ? (size_t)WR * 64 : (size_t)WR * m->layers[t].wn);
     saved[t].y = A.f((size_t)N * m->layers[t].gin);
   }
-  int32_t *tile_ptr = nullptr;
+  int32_t *tile_ptr = nullptr, *tile_node = nullptr;
   int64_t n_tiles = 0;
   if (any_fused && E > 0) {  // 16-edge tiles of the CSR segments: work list of the fused reverse kernels
     tile_ptr = reinterpret_cast<int32_t *>(A.f((size_t)N + 64));
-    if ((rc = snet_edge_tiles(row_ptr, N, tile_ptr, &n_tiles, st))) return rc;
+    tile_node = reinterpret_cast<int32_t *>(A.f((size_t)N + (size_t)E / 16 + 64));
+    if ((rc = snet_edge_tiles(row_ptr, N, tile_ptr, tile_node, N + E / 16 + 1, &n_tiles, st))) return rc;
   }
   float *gw_buf[2] = {nullptr, nullptr};
   bool gw_busy[2] = {false, false};
@@ -615,7 +616,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     if (L.fused) {  // g_w is contracted with W2^T inside the kernel: only g_h2[E,64] leaves it
       float *g_h2 = A.f((size_t)E * 64);
       if (E > 0 && (rc = snet_conv_bwd_fused(L.fused, saved[t].h, sh, dsh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src,
-                                             tile_ptr, N, n_tiles, L.conv_scale, g_m, g_xe, g_h2, g_vec, st)))
+                                             tile_ptr, tile_node, n_tiles, L.conv_scale, g_m, g_xe, g_h2, g_vec, st)))
         return rc;
       if (t > 0) {
         float *g_h = A.f((size_t)NT * L.dx);

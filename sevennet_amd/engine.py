@@ -61,20 +61,23 @@ class Graph:
     n_pairs: int = 0
     # 16-edge tiles of the CSR segments (snet_edge_tiles): work list of the fused reverse kernels
     tile_ptr: Optional[torch.Tensor] = None
+    tile_node: Optional[torch.Tensor] = None
     n_tiles: int = 0
 
     def tiles(self):
-        """(tile_ptr, n_tiles), built on first use"""
+        """(tile_ptr, tile_node, n_tiles), built on first use"""
         if self.tile_ptr is None:
             lib = _lib.load()
             dev = self.edge_vec.device
             with torch.cuda.device(dev):
                 tp = torch.empty(self.n_local + 1, dtype=torch.int32, device=dev)
+                cap = self.n_local + self.n_edges // 16 + 1
+                tn = torch.empty(cap, dtype=torch.int32, device=dev)
                 n = C.c_int64()
-                _lib.check(lib.snet_edge_tiles(_ptr(self.row_ptr), self.n_local, _ptr(tp), C.byref(n), _stream()),
-                           'snet_edge_tiles')
-            self.tile_ptr, self.n_tiles = tp, int(n.value)
-        return self.tile_ptr, self.n_tiles
+                _lib.check(lib.snet_edge_tiles(_ptr(self.row_ptr), self.n_local, _ptr(tp), _ptr(tn), cap, C.byref(n),
+                                               _stream()), 'snet_edge_tiles')
+            self.tile_ptr, self.tile_node, self.n_tiles = tp, tn, int(n.value)
+        return self.tile_ptr, self.tile_node, self.n_tiles
 
     def share_pairs(self):
         """Number the undirected pairs so the radial MLP runs once per pair (in place; returns self)."""
@@ -91,6 +94,20 @@ class Graph:
                                            _ptr(w_row), _ptr(pair_edge), C.byref(n), _stream()), 'snet_edge_pairs')
         self.w_row, self.pair_edge, self.n_pairs = w_row, pair_edge[:n.value].contiguous(), int(n.value)
         return self
+
+
+def species_row_lists(types_local: torch.Tensor, num_species: int) -> List[torch.Tensor]:
+    """per species: int32 ids of the local rows of that species, ascending -- views of ONE sorted tensor
+    (one stable sort + one bincount, one device sync; 119-species models would otherwise pay one
+    `nonzero` sync per species)"""
+    t = types_local.long()
+    order = torch.sort(t, stable=True).indices.to(torch.int32)
+    counts = torch.bincount(t, minlength=num_species).cpu().tolist()
+    rows, o = [], 0
+    for s in range(num_species):
+        rows.append(order[o:o + counts[s]])
+        o += counts[s]
+    return rows
 
 
 def build_graph(types, edge_index, edge_vec, n_local: Optional[int] = None, device='cuda',
@@ -122,7 +139,7 @@ def build_graph(types, edge_index, edge_vec, n_local: Optional[int] = None, devi
         eperm = torch.zeros(0, dtype=torch.int64, device=dev)
     rows = None
     if num_species:
-        rows = [torch.nonzero(types[:n_local] == s).reshape(-1).to(torch.int32) for s in range(num_species)]
+        rows = species_row_lists(types[:n_local], num_species)
     g = Graph(n_total, n_local, E, types, center.to(torch.int32).contiguous(), src.to(torch.int32).contiguous(),
               row_ptr.to(torch.int32), col_ptr.to(torch.int32), eperm.to(torch.int32).contiguous(),
               ev.contiguous(), order, rows)
@@ -197,13 +214,14 @@ class _Span:
         self.eng, self.name = eng, name
 
     def __enter__(self):
-        if self.eng.events is not None:
+        self.on = self.eng.events is not None and (self.eng.event_filter is None or self.name in self.eng.event_filter)
+        if self.on:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
             self.a.record()
 
     def __exit__(self, *exc):
-        if self.eng.events is not None:
+        if self.on:
             self.b.record()
             self.eng.events.append((self.name, self.a, self.b))
 
@@ -212,14 +230,17 @@ class HipForceEngine:
     OVERLAP_MAX_EDGES = 1_000_000
 
     def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6',
-                 linear_mode: str = 'bf16x6', fused='auto', fused_terms: int = 3, modal=None, overlap: bool = True):
+                 linear_mode: str = 'bf16x6', fused='auto', fused_terms: int = 2, modal=None, overlap: bool = True):
         """mlp_mode / linear_mode: 'bf16x6' (split-precision MFMA, fp32-class accuracy, default) or
         'fp32' (exact fp32 MFMA) for the fused radial MLP / the node-level equivariant linears.
         fused: 'auto' (default) / True / False / 'fwd' / 'bwd' -- run the radial MLP's last layer INSIDE the
         tensor-product kernels (snet_conv_fwd_fused / snet_conv_bwd_fused): neither w[E,wn] nor g_w[E,wn] is
         materialised; what is kept per layer is h2[pairs,64].  Needs mlp_mode 'bf16x6' and a shape whose channel
         multiplicities are multiples of 16 ('auto': used where available; True: required).
-        fused_terms: bf16 terms per operand of the in-kernel products (3 = bf16x6, 2 = bf16x3, 1 = bf16).
+        fused_terms: bf16 terms per operand of the in-kernel products w = h2 @ W2 and g_h2 = g_w @ W2^T:
+        2 (default) = bf16x3 (a0b0 + a0b1 + a1b0, ~2^-16 relative per product: measured max force error vs the
+        fp64 oracle 6e-7 eV/A where the fp32-class paths give 2e-7, tools/gpu/terms_accuracy.py), 3 = bf16x6
+        (fp32-rounding class, twice the matrix-core work), 1 = plain bf16 (3e-4 .. 5e-4 eV/A: outside the 1e-4 bar).
         overlap: run the radial MLPs on a second HIP stream -- forward: all layers' weights are produced
         from the edge embedding while the node-level work of earlier layers runs; reverse: the MLP reverse of
         layer t (which only feeds the final radial gradient) runs beside the rest of the reverse pass.
@@ -242,6 +263,7 @@ class HipForceEngine:
         self.overlap = bool(overlap)
         self._side = None  # second stream, created on first use
         self.events = None  # set to [] to collect (name, start, end) HIP events per kernel class
+        self.event_filter = None  # optional set of class names: only those spans are recorded
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError('HipForceEngine needs a ROCm GPU (no CPU fallback exists)')
@@ -256,6 +278,11 @@ class HipForceEngine:
                 raise KeyError(f'state_dict is missing {k}')
             v = state_dict[k]
             v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if k.startswith('rescale_atomic_energy.'):  # shape taken from the tensor itself (ModelSpec.rescale_vectors)
+                sd[k] = v.astype(np.float64)
+                continue
+            if v.size != int(np.prod(shp)):
+                raise ValueError(f'{k}: checkpoint tensor has {v.size} entries, the model config implies {shp}')
             sd[k] = v.astype(np.float64).reshape(shp)
 
         self.edge_params = _lib.EdgeParams(sp.cutoff, sp.n_basis, sp.cutoff_kind, sp.cutoff_p, sp.cutoff_on,
@@ -466,7 +493,7 @@ class HipForceEngine:
             side = None
             w_ready = {}
             any_fused = any(L.fused_fwd or L.fused_bwd for L in self.layers)
-            tile_ptr, n_tiles = g.tiles() if any(L.fused_bwd for L in self.layers) and E > 0 else (None, 0)
+            tile_ptr, tile_node, n_tiles = g.tiles() if any(L.fused_bwd for L in self.layers) and E > 0 else (None, None, 0)
             if self.overlap and E <= self.OVERLAP_MAX_EDGES and not any_fused and all(L.fused_mlp for L in self.layers):
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=self.dev)
@@ -588,7 +615,7 @@ class HipForceEngine:
                     with _Span(self, f'conv_bwd_fused[{ls.conv.tag}]'):
                         if E > 0:
                             _lib.check(lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(w_row),
-                                                               _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), N, n_tiles, L.scale,
+                                                               _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale,
                                                                _ptr(g_m), _ptr(g_xe), _ptr(g_h2), _ptr(g_vec), st),
                                        'snet_conv_bwd_fused')
                 else:

@@ -96,7 +96,8 @@ def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray],
     for k, shp in sp.param_shapes().items():
         if k not in sd:
             raise KeyError(f'state_dict is missing {k}')
-        sd[k] = sd[k].reshape(shp)
+        if not k.startswith('rescale_atomic_energy.'):  # rescale shapes come from the tensors (rescale_vectors)
+            sd[k] = sd[k].reshape(shp)
     scale_v, shift_v = sp.rescale_vectors(sd, mi)
     n_scale = len(scale_v)
     embed = linear_weight_matrices(sp.embed, sd[sp.embed.name])[0]

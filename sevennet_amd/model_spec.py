@@ -331,16 +331,22 @@ class ModelSpec:
         return idx
 
     def rescale_vectors(self, sd, modal_idx: int):
-        """(scale, shift) as flat float arrays for the chosen fidelity channel: [1] global or [n_species]"""
-        sc = np.asarray(sd['rescale_atomic_energy.scale'], np.float64)
-        sh = np.asarray(sd['rescale_atomic_energy.shift'], np.float64)
-        if self.n_modal:
-            sc = sc.reshape(self.param_shapes()['rescale_atomic_energy.scale'])
-            sh = sh.reshape(self.param_shapes()['rescale_atomic_energy.shift'])
-            sc = sc[modal_idx] if sc.ndim == 2 else sc
-            sh = sh[modal_idx] if sh.ndim == 2 else sh
-        n = max(sc.size, sh.size)
-        return np.broadcast_to(sc.reshape(-1), (n,)).copy(), np.broadcast_to(sh.reshape(-1), (n,)).copy()
+        """(scale, shift) as flat float arrays for the chosen fidelity channel: [1] global or [n_species].
+        Shapes come from the checkpoint TENSORS (a species-wise checkpoint may still carry scalars in its
+        config): [1] (Rescale), [n_species] (SpeciesWiseRescale), or -- multi-modal models -- [n_modal, n_species]."""
+        ns = self.num_species
+        out = []
+        for name in ('scale', 'shift'):
+            v = np.asarray(sd[f'rescale_atomic_energy.{name}'], np.float64)
+            if self.n_modal and v.size == self.n_modal * ns and v.size != ns:
+                v = v.reshape(self.n_modal, ns)[modal_idx]
+            v = v.reshape(-1)
+            if v.size not in (1, ns):
+                raise ValueError(f'rescale_atomic_energy.{name} has {v.size} entries: expected 1, n_species = {ns}'
+                                 + (f' or n_modal x n_species = {self.n_modal} x {ns}' if self.n_modal else ''))
+            out.append(v)
+        n = max(out[0].size, out[1].size)
+        return np.broadcast_to(out[0], (n,)).copy(), np.broadcast_to(out[1], (n,)).copy()
 
     def num_weights(self) -> int:
         return sum(int(np.prod(v)) for k, v in self.param_shapes().items()
@@ -395,6 +401,19 @@ def build_model_spec(config: dict) -> ModelSpec:
     if not isinstance(denom, (list, tuple)):
         denom = [denom] * L
     cf = cfg['cutoff_function']
+    if cf.get('cutoff_function_name') not in ('poly_cut', 'XPLOR'):
+        raise NotImplementedError(f"cutoff function {cf.get('cutoff_function_name')!r}: the HIP engine implements "
+                                  "'poly_cut' and 'XPLOR' (sevenn/nn/edge_embedding.py:106-160)")
+    if cfg['radial_basis'].get('radial_basis_name', 'bessel') != 'bessel':
+        raise NotImplementedError(f"radial basis {cfg['radial_basis'].get('radial_basis_name')!r}: the HIP engine "
+                                  "implements 'bessel' (sevenn/nn/edge_embedding.py:81-103)")
+    for key in ('act_radial',):
+        if cfg[key] not in ACT_ID:
+            raise ValueError(f"{key}={cfg[key]!r}: supported activations are {sorted(ACT_ID)}")
+    for key in ('act_scalar', 'act_gate'):
+        bad = [v for v in cfg[key].values() if v not in ACT_ID]
+        if bad:
+            raise ValueError(f"{key} uses {bad[0]!r}: supported activations are {sorted(ACT_ID)}")
     ckind = {'poly_cut': 0, 'XPLOR': 1}[cf['cutoff_function_name']]
     n_basis = int(cfg['radial_basis'].get('bessel_basis_num', 8))
     hidden = list(cfg['weight_nn_hidden_neurons'])

@@ -74,7 +74,8 @@ def build_graph_gpu(types, pos, cell, cutoff: float, device='cuda:0', num_specie
             eperm = torch.zeros(0, dtype=torch.int32, device=dev)
         rows = None
         if num_species:
-            rows = [torch.nonzero(ty == s).reshape(-1).to(torch.int32) for s in range(num_species)]
+            from .engine import species_row_lists
+            rows = species_row_lists(ty, num_species)
         g = Graph(n, n, E, ty, center, src, row_ptr, col_ptr.to(torch.int32), eperm, ev, None, rows)
         g.shifts = shifts
         return g.share_pairs() if share_pairs else g

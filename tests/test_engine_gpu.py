@@ -49,11 +49,17 @@ def _compare(eng, out, ref, n, rel=3e-5, check_inter=True):
     _close(out['virial'], ref['virial'], rel, 1e-7, 'virial')
     _close(out['atomic_virial'], ref['atomic_virial'], rel, 1e-8, 'atomic_virial')
     if check_inter and 'inter' in out:
+        # module-by-module features: 1e-5 of each tensor's scale for the fp32-class kernels; layers whose radial
+        # weights are formed inside the tensor-product kernel from bf16x3 products (engine default, ~2^-16 per
+        # product, tools/gpu/terms_accuracy.py: forces 6e-7 eV/A) get 4e-5 from their convolution on
+        loose = [t for t, L in enumerate(eng.layers) if getattr(L, 'fused_fwd', False) and eng.fused_terms < 3]
+        first = loose[0] if loose else len(eng.layers)
         for t, L in enumerate(eng.layers):
             ls = L.spec
             for key, irr in ((f'{t}_si1', ls.si1.irreps_out), (f'{t}_conv', ls.conv.irreps_out),
                              (f'{t}_gate_in', ls.gate.irreps_in), (f'{t}_x', ls.gate.irreps_out)):
-                _close(irmul_to_mulir(out['inter'][key], irr), ref['inter'][key], 1e-5, 1e-9, key)
+                downstream = t > first or (t == first and not key.endswith('_si1'))
+                _close(irmul_to_mulir(out['inter'][key], irr), ref['inter'][key], 4e-5 if downstream else 1e-5, 1e-9, key)
 
 
 @pytest.mark.parametrize('name', ['hfo2_12', 'hfo_rs64', 'hfo2_96'])

@@ -167,3 +167,25 @@ def test_old_checkpoint_w3j_sign_fix(tmp_path):
     bad[key] = bad[key] * 0.5
     with pytest.raises(ValueError, match='neither'):
         fix_old_convolution_signs(cfg, bad)
+
+
+def test_species_wise_rescale_checkpoint_with_scalar_config():
+    """shift / scale shapes come from the checkpoint tensors: a species-wise-rescale checkpoint whose config
+    still holds scalars loads; sizes that match neither 1 nor n_species are refused; unsupported
+    radial basis / activation / cutoff names raise explicit errors"""
+    from sevennet_amd.model_spec import build_model_spec
+    from sevennet_amd.shapes import unit_test_config
+    cfg = unit_test_config(shift=-1.0, scale=2.0)
+    sp = build_model_spec(cfg)
+    ns = sp.num_species
+    sd = {'rescale_atomic_energy.scale': np.arange(1, ns + 1, dtype=np.float32), 'rescale_atomic_energy.shift': np.array([0.5], np.float32)}
+    sc, sh = sp.rescale_vectors(sd, -1)
+    assert sc.tolist() == list(range(1, ns + 1)) and sh.tolist() == [0.5] * ns
+    with pytest.raises(ValueError, match='entries'):
+        sp.rescale_vectors({'rescale_atomic_energy.scale': np.ones(ns + 1), 'rescale_atomic_energy.shift': np.ones(1)}, -1)
+    with pytest.raises(NotImplementedError, match='radial basis'):
+        build_model_spec(unit_test_config(radial_basis={'radial_basis_name': 'gaussian'}))
+    with pytest.raises(ValueError, match='act_radial'):
+        build_model_spec(unit_test_config(act_radial='relu'))
+    with pytest.raises(NotImplementedError, match='cutoff function'):
+        build_model_spec(unit_test_config(cutoff_function={'cutoff_function_name': 'cosine'}))

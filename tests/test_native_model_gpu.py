@@ -17,7 +17,7 @@ F_TOL = 1e-4  # eV/A, BASELINE.json north_star tolerance
 def _both(cfg, sd, types, ei, ev):
     from sevennet_amd.engine import HipForceEngine, build_graph
     from sevennet_amd.native_model import NativeModel
-    eng = HipForceEngine(cfg, sd, device='cuda:0', fused=False)
+    eng = HipForceEngine(cfg, sd, device='cuda:0')
     nat = NativeModel(cfg, sd, device='cuda:0')
     g = build_graph(types, ei, ev, device='cuda:0', num_species=eng.spec.num_species)
     a = eng.compute(g, want_atomic_virial=True)
@@ -123,7 +123,7 @@ def test_native_model_bricks_equal_single_graph_on_one_gpu():
     cfg = mini_sevennet_0_config()
     sd = random_state_dict(cfg, seed=9)
     types, pos, cell, ei, ev = synthetic_system((4, 4, 4), sigma=0.06, seed=4, cutoff=5.0, n_species=2)
-    ref = HipForceEngine(cfg, sd, device='cuda:0', fused=False).compute(build_graph(types, ei, ev, device='cuda:0'))
+    ref = HipForceEngine(cfg, sd, device='cuda:0').compute(build_graph(types, ei, ev, device='cuda:0'))
     torch.cuda.synchronize()
     bricks = [build_brick_graph(pos, cell, types, 5.0, world, r, neighbors=(ei, ev)) for r in range(world)]
     grp = InProcessHaloGroup(bricks, 'cuda:0')

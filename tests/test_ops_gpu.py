@@ -320,15 +320,18 @@ def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms):
     out = torch.full((N, dout), float('nan'), device=dev)
     L.check(lib.snet_conv_fwd_fused(fplan, _p(x), _p(sh), _p(h2), _p(wr), _p(rp), _p(sr), N, scale, _p(out), None))
     tile_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    cap = N + E // 16 + 1
+    tile_node = torch.full((cap,), -1, dtype=torch.int32, device=dev)
     n_tiles = C.c_int64()
-    L.check(lib.snet_edge_tiles(_p(rp), N, _p(tile_ptr), C.byref(n_tiles), None))
+    L.check(lib.snet_edge_tiles(_p(rp), N, _p(tile_ptr), _p(tile_node), cap, C.byref(n_tiles), None))
     deg = (c['row_ptr'][1:] - c['row_ptr'][:-1]).long()
     assert n_tiles.value == int(((deg + 15) // 16).sum())
     assert torch.equal(tile_ptr.cpu()[1:].long(), torch.cumsum((deg + 15) // 16, 0))
+    assert torch.equal(tile_node.cpu()[:n_tiles.value].long(), torch.repeat_interleave(torch.arange(N), (deg + 15) // 16))
     g_xe = torch.full((E, dx), float('nan'), device=dev)
     g_h2 = torch.full((E, 64), float('nan'), device=dev)
     g_vec = torch.ones(E, 3, device=dev)
-    L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), N,
+    L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), _p(tile_node),
                                     n_tiles.value, scale, _p(g_out), _p(g_xe), _p(g_h2), _p(g_vec), None))
     g_emb = torch.ones(E, nb, device=dev)
     L.check(lib.snet_radial_mlp_hidden_bwd(mlp, _p(emb_e), _p(g_h2), E, _p(g_emb), None))
@@ -338,7 +341,7 @@ def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms):
     assert (h2.cpu().double() - a2).abs().max() < 5e-6 * a2.abs().max()
     for t in (out, g_xe, g_h2, g_vec, g_emb):
         assert not torch.isnan(t).any()
-    tol = {3: 2e-5, 2: 3e-4, 1: 4e-2}[terms]
+    tol = {3: 2e-5, 2: 1e-4, 1: 4e-2}[terms]
     # g_h2 against the fp64 contraction of the separate kernel's g_w with W2^T
     g_h2_ref = g_w.double().cpu() @ c['W2'].double().T
     for name, a, b in (('out', out, out_ref), ('g_xe', g_xe, g_xe_ref), ('g_vec', g_vec, g_vec_ref),
@@ -349,7 +352,7 @@ def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms):
     # g_xe is optional (first layer: inputs depend on species only)
     g_h2b = torch.empty_like(g_h2)
     g_vecb = torch.ones(E, 3, device=dev)
-    L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), N,
+    L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), _p(tile_node),
                                     n_tiles.value, scale, _p(g_out), None, _p(g_h2b), _p(g_vecb), None))
     torch.cuda.synchronize()
     assert torch.equal(g_h2, g_h2b) and torch.equal(g_vec, g_vecb)

@@ -1,0 +1,18 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/g11_all.log
+tail -8 gpurun_out/g11_all.log
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3
+timeout 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/g11_bench_fused.json 2> gpurun_out/g11_bench_fused.err
+timeout 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --fused off > gpurun_out/g11_bench_off.json 2> gpurun_out/g11_bench_off.err
+timeout 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --terms 3 > gpurun_out/g11_bench_t3.json 2> gpurun_out/g11_bench_t3.err
+timeout 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --host native > gpurun_out/g11_bench_native.json 2> gpurun_out/g11_bench_native.err
+python - <<'PY'
+import json
+for f in ('fused', 'off', 't3', 'native'):
+    try:
+        d = json.loads(open(f'gpurun_out/g11_bench_{f}.json').read().strip().splitlines()[-1])
+        print(f, round(d['ms_per_step'], 2), d['roofline']['kernel_ms_per_step'])
+    except Exception as e:
+        print(f, 'FAILED', e, open(f'gpurun_out/g11_bench_{f}.err').read()[-600:])
+PY

@@ -28,6 +28,8 @@ def main():
     ap.add_argument('--model', default='sevennet_0')
     ap.add_argument('--mlp-mode', default='bf16x6')
     ap.add_argument('--terms', type=int, default=3)
+    ap.add_argument('--fv', default='', help='kernel-tuning builds (SNET_CODEGEN_OPTS=fexp=<tag>): semicolon-separated '
+                    '"nwv,glds,occ[,diag]" variants of the fused kernels to time, e.g. "4,0,2;4,1,2;4,1,1;4,1,2,1"')
     ap.add_argument('--only', default='', help='substring filter on kernel names')
     ap.add_argument('--order', default='raster', choices=['raster', 'morton', 'random'], help='atom order of the test cell')
     a = ap.parse_args()
@@ -85,12 +87,12 @@ def main():
     st = _stream()
     h2 = rnd(E, 64)
     g_h2 = rnd(E, 64)
-    tile_ptr, n_tiles = g.tiles()
+    tile_ptr, tile_node, n_tiles = g.tiles()
     ops = {
         'radial_mlp_hidden_fwd': lambda: lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb), E, _ptr(h2), st),
         f'conv_fwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_fwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
-        f'conv_bwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), N, n_tiles, L.scale, _ptr(g_m), _ptr(g_xe), _ptr(g_h2), _ptr(g_vec), st),
-        f'conv_bwd_fused_no_gxe[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), N, n_tiles, L.scale, _ptr(g_m), None, _ptr(g_h2), _ptr(g_vec), st),
+        f'conv_bwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), _ptr(g_xe), _ptr(g_h2), _ptr(g_vec), st),
+        f'conv_bwd_fused_no_gxe[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), None, _ptr(g_h2), _ptr(g_vec), st),
         'radial_mlp_hidden_bwd': lambda: lib.snet_radial_mlp_hidden_bwd(L.mlp_plan, _ptr(emb), _ptr(g_h2), E, _ptr(g_emb), st),
         f'radial_mlp_fwd[wn={wn}]': lambda: eng._mlp_fwd(L, emb, E),
         f'conv_fwd[{ls.conv.tag}]': lambda: lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), None, _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
@@ -107,9 +109,20 @@ def main():
         'si2_bwd': lambda: eng._linear_T(L.si2, rnd(N, ls.si2.dim_out), N, g),
     }
     print(f'lib={_lib.LIB_PATH} N={N} E={E} layer={a.layer} dx={dx} dmid={dmid} wn={wn}')
+    todo = []
     for name, fn in ops.items():
         if a.only and a.only not in name:
             continue
+        if a.fv and 'fused[' in name:
+            for v in a.fv.split(';'):
+                todo.append((f'{name} fv={v}', fn, v))
+        else:
+            todo.append((name, fn, None))
+    for name, fn, fv in todo:
+        if fv is not None:
+            parts = fv.split(',')
+            os.environ['SNET_FV_BWD'] = os.environ['SNET_FV_FWD'] = ','.join(parts[:3])
+            os.environ['SNET_FV_DIAG'] = parts[3] if len(parts) > 3 else '0'
         fn()
         torch.cuda.synchronize()
         ts = []
@@ -122,8 +135,8 @@ def main():
             ts.append(s0.elapsed_time(s1))
         ms = float(np.median(ts))
         extra = ''
-        if name in km:
-            k = km[name]
+        if name.split(' fv=')[0] in km:
+            k = km[name.split(' fv=')[0]]
             extra = (f"{k['bytes'] / ms / 1e6:8.1f} GB/s (algorithmic)" if k['bound'] == 'hbm'
                      else f"{k['flops'] / ms / 1e9:8.2f} TFLOP/s")
         print(f'{name:34s} {ms:8.3f} ms  {extra}')
