@@ -61,6 +61,9 @@ def parse():
                     help='bf16 terms per operand of the fused in-kernel products: 2 = bf16x3 (engine default, force error vs fp64 '
                          '6e-7 eV/A), 3 = bf16x6 (fp32-rounding class), 1 = plain bf16 (outside the 1e-4 eV/A bar)')
     ap.add_argument('--no-overlap', action='store_true', help='radial MLPs on the main stream (no second stream)')
+    ap.add_argument('--halo', default='auto', choices=['auto', 'native', 'torch'],
+                    help="N > 1: ghost exchange by libsnet_hip.so's own RCCL send/recv groups ('native', default with the "
+                         "nccl backend) or by torch.distributed.all_to_all_single ('torch'; the only choice over gloo)")
     ap.add_argument('--no-h2d', action='store_true', help='keep the edge vectors resident (no per-step host -> device copy)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-reps', type=int, default=6, help='CPU-baseline sample: cells per axis (6 -> 1728 atoms, 11 -> 10 648)')
@@ -189,7 +192,13 @@ def main():
         bg = build_brick_graph(pos, cell, species_of(cfg, n_atoms), cfg['cutoff'], world, rank)
         graph = build_graph(bg.types, bg.edge_index, bg.edge_vec, n_local=bg.n_local, device=dev,
                             num_species=eng.spec.num_species)
-        halo = HaloExchange(bg.send_lists, bg.recv_counts, dev)
+        use_native = a.halo == 'native' or (a.halo == 'auto' and backend == 'nccl')
+        if use_native:
+            from sevennet_amd.parallel import NativeHalo, RcclComm
+            rccl_comm = RcclComm(world, rank)
+            halo = NativeHalo(rccl_comm, bg.send_lists, bg.recv_counts)
+        else:
+            halo = HaloExchange(bg.send_lists, bg.recv_counts, dev)
         ne = torch.tensor([graph.n_edges], device=dev, dtype=torch.int64)
         dist.all_reduce(ne)
         n_edges_total = int(ne.item())
@@ -339,6 +348,11 @@ def main():
                        'h2d_in_step': (None if ev_host is None else
                                        f'edge_vec [E,3] fp32 = {ev_host.numel() * 4 / 1e6:.1f} MB from pinned host memory every step'),
                        'fused': a.fused, 'terms': a.terms,
+                       'halo': (None if world == 1 else ('libsnet_hip RCCL send/recv groups' if type(halo).__name__ == 'NativeHalo'
+                                                          else f'torch.distributed all_to_all_single ({backend})')),
+                       'ghost_rows_rank0': (None if world == 1 else int(graph.n_total - graph.n_local)),
+                       'halo_ms_per_step_rank0': (None if world == 1 else round(sum(v for k, v in totals.items() if k.startswith('halo')) / n_break, 4)),
+                       'kernel_ms_per_step_rank0': round(sum(v for k, v in totals.items() if not k.startswith('halo')) / n_break, 3),
                        'energy': float(e_total.cpu())},
             'roofline': roof,
         }

@@ -312,6 +312,35 @@ int snet_model_meta(const snet_model *model, const char *key, char *value, int32
 typedef int (*snet_halo_fn)(void *user, float *x, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
 int snet_model_set_halo(snet_model *model, snet_halo_fn forward, snet_halo_fn reverse, void *user,
                         int32_t fold_forces);
+/* ---- a12, native: the ghost exchange itself, on RCCL (xGMI point-to-point), no host staging --------------
+ * What a C++ host (LAMMPS pair style, any MD driver) installs instead of writing its own hooks; replaces the
+ * reference's PairE3GNNParallel::{pack,unpack}_{forward,reverse}_comm_gnn (pair_e3gnn_parallel.cpp:747-911) and the
+ * float overloads of CommBrick::forward_comm / reverse_comm (comm_brick.cpp:1057-1123): six sequential blocking
+ * MPI swaps (with ghost-of-ghost forwarding and optional host staging, :806-809) become ONE ncclGroup of
+ * send / recv pairs per call -- every peer concurrently, each over its own xGMI link, on the caller's stream.
+ *   snet_rccl_unique_id / snet_rccl_comm_create   one communicator per process group: rank 0 makes the 128-byte id,
+ *       the host broadcasts it (MPI_Bcast, torch.distributed ...), every rank creates its communicator
+ *   snet_halo_create   the exchange plan of one decomposition: send_counts[world] rows go to each peer, taken from
+ *       local rows send_idx (HOST int32, concatenated in peer order); recv_counts[world] ghost rows arrive from
+ *       each peer and land contiguously, in peer order, behind the local rows
+ *   snet_halo_forward / snet_halo_reverse   have the snet_halo_fn signature (user = the snet_halo*): forward fills
+ *       ghost rows, reverse adds ghost rows into their owners (received rows are summed per target row in fixed
+ *       peer order: deterministic).  snet_model_set_rccl_halo installs both on a model.
+ * RCCL is bound with dlopen at first use: libsnet_hip.so has no link-time dependency on it.                        */
+typedef struct snet_halo snet_halo;
+int snet_rccl_unique_id(void *id128);
+int snet_rccl_comm_create(const void *id128, int32_t world, int32_t rank, void **comm);
+void snet_rccl_comm_destroy(void *comm);
+int snet_rccl_allreduce_sum_f64(void *comm, double *dev_values, int64_t n, void *stream);
+int snet_halo_create(void *comm, int32_t world, int32_t rank, const int32_t *send_counts, const int32_t *send_idx_host,
+                     const int32_t *recv_counts, snet_halo **out);
+void snet_halo_destroy(snet_halo *halo);
+int64_t snet_halo_ghost_rows(const snet_halo *halo);
+int64_t snet_halo_send_rows(const snet_halo *halo);
+int snet_halo_forward(void *halo, float *x, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
+int snet_halo_reverse(void *halo, float *gx, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
+int snet_model_set_rccl_halo(snet_model *model, snet_halo *halo, int32_t fold_forces);
+
 /* One energy/force evaluation.  Device inputs: types[n_total] species index, row_ptr[n_local+1] /
  * src[E] edges sorted by center (CSR), col_ptr[n_total+1] / eperm[E] the same edges grouped by source,
  * edge_vec[E,3] = r_src - r_center.  types_host[n_local] (HOST, may be NULL for models without a

@@ -111,6 +111,17 @@ SIGNATURES = {
     'snet_model_set_halo': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     'snet_model_eval': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p,
                                   c_i32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, c_stream]),
+    'snet_rccl_unique_id': (C.c_int, [C.c_void_p]),
+    'snet_rccl_comm_create': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    'snet_rccl_comm_destroy': (None, [C.c_void_p]),
+    'snet_rccl_allreduce_sum_f64': (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_stream]),
+    'snet_halo_create': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    'snet_halo_destroy': (None, [C.c_void_p]),
+    'snet_halo_ghost_rows': (C.c_int64, [C.c_void_p]),
+    'snet_halo_send_rows': (C.c_int64, [C.c_void_p]),
+    'snet_halo_forward': (C.c_int, [C.c_void_p, c_f32p, C.c_int64, C.c_int64, C.c_int32, c_stream]),
+    'snet_halo_reverse': (C.c_int, [C.c_void_p, c_f32p, C.c_int64, C.c_int64, C.c_int32, c_stream]),
+    'snet_model_set_rccl_halo': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'snet_edge_pairs': (C.c_int, [c_i32p, c_i32p, c_f32p, C.c_int64, C.c_int64, c_i32p, c_i32p, C.POINTER(C.c_int64),
                                   c_stream]),
     'snet_md_create': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

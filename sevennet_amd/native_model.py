@@ -73,6 +73,11 @@ class NativeModel:
             self._cb = None
             _lib.check(self.lib.snet_model_set_halo(self.handle, None, None, None, 1), 'snet_model_set_halo')
             return
+        from .parallel import NativeHalo
+        if isinstance(halo, NativeHalo):  # the library's own RCCL exchange: no Python callback in the evaluation
+            self._cb = halo
+            _lib.check(self.lib.snet_model_set_rccl_halo(self.handle, halo.handle, int(fold_forces)), 'snet_model_set_rccl_halo')
+            return
 
         def wrap(fn):
             def cb(_user, ptr, n_total, n_local, dim, _stream):

@@ -232,6 +232,95 @@ class HaloExchange:
         self.reverse_finish(self.reverse_start(gx, n_local), gx)
 
 
+class RcclComm:
+    """One RCCL communicator created by libsnet_hip.so itself (snet_rccl_comm_create), so that the native
+    halo below -- and any C++ host -- talks to RCCL without PyTorch in between.  The 128-byte unique id is made
+    on rank 0 and handed to `bcast` (a callable bytes -> bytes that returns rank 0's value on every rank; by
+    default torch.distributed.broadcast_object_list on the default process group)."""
+
+    def __init__(self, world: int, rank: int, bcast=None):
+        from . import _lib
+        self.lib = _lib.load()
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            _lib.check(self.lib.snet_rccl_unique_id(C.cast(ident, C.c_void_p)), 'snet_rccl_unique_id')
+        raw = bytes(ident.raw)
+        if world > 1:
+            if bcast is None:
+                import torch.distributed as dist
+                box = [raw]
+                dist.broadcast_object_list(box, src=0)
+                raw = box[0]
+            else:
+                raw = bcast(raw)
+        buf = (C.c_char * 128).from_buffer_copy(raw)
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.snet_rccl_comm_create(C.cast(buf, C.c_void_p), world, rank, C.byref(self.handle)),
+                   'snet_rccl_comm_create')
+        self.world, self.rank = world, rank
+
+    def all_reduce_f64(self, t: torch.Tensor):
+        """in-place sum of a float64 device tensor over all ranks (total energy, virial)"""
+        from . import _lib
+        assert t.dtype == torch.float64 and t.is_contiguous()
+        _lib.check(self.lib.snet_rccl_allreduce_sum_f64(self.handle, C.c_void_p(t.data_ptr()), t.numel(),
+                                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   'snet_rccl_allreduce_sum_f64')
+        return t
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.snet_rccl_comm_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class NativeHalo:
+    """The ghost exchange implemented INSIDE libsnet_hip.so (csrc/snet_halo.cpp: one ncclGroup of send / recv
+    pairs per call on the compute stream, pack / reverse-accumulate kernels of the library) -- what replaces
+    CommBrick::forward_comm / reverse_comm + the pack / unpack hooks of pair_e3gnn_parallel.cpp:747-911 for
+    C++ hosts.  Same plan arguments and the same forward / reverse interface as HaloExchange, so both hosts
+    (HipForceEngine, NativeModel) accept it; NativeModel installs it with snet_model_set_rccl_halo, i.e. the
+    evaluation then runs without a single Python callback."""
+
+    def __init__(self, comm: RcclComm, send_lists: Sequence[np.ndarray], recv_counts: Sequence[int]):
+        from . import _lib
+        self.lib, self.comm = _lib.load(), comm
+        world = comm.world
+        assert len(send_lists) == world and len(recv_counts) == world
+        sc = np.asarray([len(s) for s in send_lists], np.int32)
+        rc = np.asarray(list(recv_counts), np.int32)
+        idx = np.ascontiguousarray(np.concatenate([np.asarray(s, np.int64) for s in send_lists]) if world else
+                                   np.zeros(0, np.int64), dtype=np.int32)
+        self.n_ghost = int(rc.sum())
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.snet_halo_create(comm.handle, world, comm.rank, C.c_void_p(sc.ctypes.data),
+                                             C.c_void_p(idx.ctypes.data) if idx.size else None,
+                                             C.c_void_p(rc.ctypes.data), C.byref(self.handle)), 'snet_halo_create')
+
+    def forward(self, x: torch.Tensor, n_local: int):
+        from . import _lib
+        assert x.is_contiguous() and x.dtype == torch.float32
+        _lib.check(self.lib.snet_halo_forward(self.handle, C.c_void_p(x.data_ptr()), x.shape[0], n_local, x.shape[1],
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'snet_halo_forward')
+
+    def reverse(self, gx: torch.Tensor, n_local: int):
+        from . import _lib
+        assert gx.is_contiguous() and gx.dtype == torch.float32
+        _lib.check(self.lib.snet_halo_reverse(self.handle, C.c_void_p(gx.data_ptr()), gx.shape[0], n_local, gx.shape[1],
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'snet_halo_reverse')
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.snet_halo_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 # --------------------------------------------------------------------------- #
 # all bricks inside ONE process (one GPU): same exchange semantics through shared memory.
 # Used to validate the N-brick == 1-brick property on a single MI355X.

@@ -515,3 +515,43 @@ def test_fused_engine_equals_separate_kernels(model):
     for mode in ('fwd', 'bwd'):
         rc = HipForceEngine(cfg, sd, device='cuda:0', fused=mode).compute(g)
         assert (rc['forces'] - rb['forces']).abs().max().item() < 2e-5 * fs
+
+
+def test_native_rccl_halo_self_exchange():
+    """csrc/snet_halo.cpp on a world-1 RCCL communicator (one GPU): the rank sends rows to itself.  forward fills
+    the ghost rows with the owners' rows; reverse adds ghost rows into their owners, duplicates summed in fixed
+    order -- the semantics of pair_e3gnn_parallel.cpp:747-911 (pack / unpack hooks), checked against index ops.
+    The N-rank plan itself is the one HaloExchange uses (tests/test_parallel_cpu.py, world 2 / 4 over gloo)."""
+    from sevennet_amd.parallel import NativeHalo, RcclComm
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(5)
+    n_local, dim = 50, 96
+    send = torch.randint(0, n_local, (37,), generator=g).numpy()     # with repeats: several ghosts of one owner row
+    comm = RcclComm(1, 0)
+    halo = NativeHalo(comm, [send], [len(send)])
+    assert halo.n_ghost == len(send)
+    x = torch.randn(n_local + len(send), dim, generator=g).to(dev)
+    x0 = x.clone()
+    halo.forward(x, n_local)
+    torch.cuda.synchronize()
+    assert torch.equal(x[:n_local], x0[:n_local])
+    assert torch.equal(x[n_local:], x0[torch.as_tensor(send, device=dev).long()])
+    gx = torch.randn(n_local + len(send), dim, generator=g).to(dev)
+    ref = gx.clone().double()
+    ref[:n_local].index_add_(0, torch.as_tensor(send, device=dev).long(), ref[n_local:].clone())
+    halo.reverse(gx, n_local)
+    torch.cuda.synchronize()
+    assert (gx[:n_local].double() - ref[:n_local]).abs().max() < 1e-5
+    assert torch.equal(gx[n_local:].double(), ref[n_local:])            # ghost rows themselves are left alone
+    # a second call out of the same buffers, other width
+    y = torch.randn(n_local + len(send), 3, generator=g).to(dev)
+    y0 = y.clone()
+    halo.forward(y, n_local)
+    torch.cuda.synchronize()
+    assert torch.equal(y[n_local:], y0[torch.as_tensor(send, device=dev).long()])
+    e = torch.tensor([1.5, -2.0], dtype=torch.float64, device=dev)
+    comm.all_reduce_f64(e)
+    torch.cuda.synchronize()
+    assert e.tolist() == [1.5, -2.0]
+    with pytest.raises(RuntimeError, match='ghost row count'):
+        halo.forward(torch.zeros(n_local + 1, 4, device=dev), n_local)
