@@ -322,7 +322,9 @@ int snet_model_set_halo(snet_model *model, snet_halo_fn forward, snet_halo_fn re
  *       the host broadcasts it (MPI_Bcast, torch.distributed ...), every rank creates its communicator
  *   snet_halo_create   the exchange plan of one decomposition: send_counts[world] rows go to each peer, taken from
  *       local rows send_idx (HOST int32, concatenated in peer order); recv_counts[world] ghost rows arrive from
- *       each peer and land contiguously, in peer order, behind the local rows
+ *       each peer and land contiguously, in peer order, behind the local rows -- or, with recv_perm (HOST
+ *       int32[n_ghost], nullable), the k-th row of that peer-ordered stream is the host's ghost row recv_perm[k]
+ *       (hosts that number their ghost nodes in their own order, e.g. a LAMMPS pair style)
  *   snet_halo_forward / snet_halo_reverse   have the snet_halo_fn signature (user = the snet_halo*): forward fills
  *       ghost rows, reverse adds ghost rows into their owners (received rows are summed per target row in fixed
  *       peer order: deterministic).  snet_model_set_rccl_halo installs both on a model.
@@ -333,7 +335,7 @@ int snet_rccl_comm_create(const void *id128, int32_t world, int32_t rank, void *
 void snet_rccl_comm_destroy(void *comm);
 int snet_rccl_allreduce_sum_f64(void *comm, double *dev_values, int64_t n, void *stream);
 int snet_halo_create(void *comm, int32_t world, int32_t rank, const int32_t *send_counts, const int32_t *send_idx_host,
-                     const int32_t *recv_counts, snet_halo **out);
+                     const int32_t *recv_counts, const int32_t *recv_perm_host, snet_halo **out);
 void snet_halo_destroy(snet_halo *halo);
 int64_t snet_halo_ghost_rows(const snet_halo *halo);
 int64_t snet_halo_send_rows(const snet_halo *halo);
@@ -385,6 +387,10 @@ int snet_edge_pairs(const int32_t *row_ptr, const int32_t *src, const float *edg
  * as ev_tally-free pair styles do.  Blocking: returns after the results are on the host.        */
 typedef struct snet_md_host snet_md_host;
 int snet_md_create(snet_model *model, snet_md_host **host);
+/* node -> atom index exactly as snet_md_compute will number the graph nodes for these arrays (capacity nall);
+ * lets a pair style lay out its ghost exchange (snet_halo_create) when the neighbor list was rebuilt */
+int snet_md_nodes(int32_t inum, const int32_t *ilist, int32_t nall, const void *tag, int32_t tag_bytes,
+                  int32_t ghost_mode, int32_t *node_to_atom_out, int64_t *n_nodes_out);
 void snet_md_destroy(snet_md_host *host);
 int snet_md_compute(snet_md_host *host, int32_t inum, const int32_t *ilist, const int32_t *numneigh,
                     const int32_t *const *firstneigh, int32_t nall, const double *x, const int32_t *type,

@@ -14,9 +14,12 @@
 #include "neighbor.h"
 
 #include <hip/hip_runtime.h>
+#include <mpi.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <numeric>
 #include <string>
 
 #include "snet_hip.h"
@@ -46,8 +49,10 @@ PairE3GNNHip::PairE3GNNHip(LAMMPS *lmp) : Pair(lmp) {
 }
 
 PairE3GNNHip::~PairE3GNNHip() {
+  if (halo) snet_halo_destroy(halo);
   if (host) snet_md_destroy(host);
   if (model) snet_model_destroy(model);
+  if (rccl_comm) snet_rccl_comm_destroy(rccl_comm);
   if (stream) (void)hipStreamDestroy(static_cast<hipStream_t>(stream));
   if (allocated) {
     memory->destroy(setflag);
@@ -85,11 +90,9 @@ void PairE3GNNHip::coeff(int narg, char **arg) {
   if (snet_model_meta(model, "model_type", buf, sizeof(buf)) || strcmp(buf, "E3_equivariant_model") != 0)
     error->all(FLERR, "given model type is not E3_equivariant_model");
   float rc = 0.f;
-  int32_t n_species = 0, n_layers = 0, comm_dims[64];
-  snet_model_info(model, &rc, &n_species, &n_layers, comm_dims, 64);
+  int32_t n_species = 0, n_layers = 0;
+  snet_model_info(model, &rc, &n_species, &n_layers, nullptr, 0);
   cutoff = rc;
-  max_comm_dim = 3;
-  for (int t = 1; t < n_layers && t < 64; t++) max_comm_dim = comm_dims[t] > max_comm_dim ? comm_dims[t] : max_comm_dim;
 
   if (snet_model_meta(model, "chemical_symbols_to_index", buf, sizeof(buf))) error->all(FLERR, snet_last_error());
   std::vector<std::string> symbols;
@@ -114,23 +117,97 @@ void PairE3GNNHip::coeff(int narg, char **arg) {
       }
 
   if (ghost_mode == 1) {
-    comm_forward = max_comm_dim;  // one feature row per atom and exchange
-    comm_reverse = max_comm_dim;
-    if (snet_model_set_halo(model, &PairE3GNNHip::halo_forward, &PairE3GNNHip::halo_reverse, this, 0))
-      error->all(FLERR, snet_last_error());
+    comm_forward = 2;  // (owner rank, owner's graph row), sent when the neighbor list was rebuilt
+    // one RCCL communicator over the LAMMPS world: rank 0 makes the id, MPI carries its 128 bytes
+    char id[128];
+    if (comm->me == 0 && snet_rccl_unique_id(id)) error->one(FLERR, std::string("e3gnn/parallel: ") + snet_last_error());
+    MPI_Bcast(id, 128, MPI_BYTE, 0, world);
+    if (snet_rccl_comm_create(id, comm->nprocs, comm->me, &rccl_comm))
+      error->one(FLERR, std::string("e3gnn/parallel: ") + snet_last_error());
   }
 }
 
 void PairE3GNNHip::init_style() {
+  // the serial style aliases ghosts to the local atom with the same tag: an atom owned by another rank has no
+  // such partner and its edges would silently vanish (reference: pair_e3gnn.cpp is serial-only as well)
+  if (ghost_mode == 0 && comm->nprocs > 1)
+    error->all(FLERR, "Pair style e3gnn runs on one MPI rank only; use e3gnn/parallel for domain decomposition");
   if (ghost_mode == 1 && force->newton_pair == 0) error->all(FLERR, "Pair style e3gnn/parallel requires newton pair on");
+  if (ghost_mode == 1 && atom->tag_consecutive() == 0)
+    error->all(FLERR, "Pair style e3gnn/parallel requires consecutive atom IDs");
   neighbor->add_request(this, NeighConst::REQ_FULL);  // many-body: full list (pair_e3gnn.cpp:423)
 }
 
 double PairE3GNNHip::init_one(int /*i*/, int /*j*/) { return cutoff; }
 
+/* ---- ghost exchange plan (e3gnn/parallel), rebuilt with the neighbor list ----------------------------------
+   1. snet_md_nodes: the graph nodes the engine will use -- owned atoms in ilist order, then one node per ghost
+      identity owned elsewhere.
+   2. every owned atom publishes (my rank, its graph row); one stock forward_comm (2 doubles per atom) carries
+      that to all its ghost images, through however many swaps the brick decomposition needs.
+   3. ghost nodes sorted by owner rank give the receive layout; the rows each owner has to send are exchanged
+      with one MPI_Alltoall + MPI_Alltoallv of int32 indices.
+   4. snet_halo_create + snet_model_set_rccl_halo: from here on every layer's exchange is one RCCL group inside
+      snet_model_eval, device to device.  (Reference: 6 blocking swaps per exchange through comm_brick.cpp with
+      optional host staging, pair_e3gnn_parallel.cpp:747-911.)                                                  */
+void PairE3GNNHip::build_halo_plan() {
+  const int nlocal = atom->nlocal, nall = atom->nlocal + atom->nghost;
+  const int inum = list->inum, me = comm->me, np = comm->nprocs;
+  node_to_atom.resize(nall);
+  int64_t n_nodes = 0;
+  if (snet_md_nodes(inum, list->ilist, nall, atom->tag, (int)sizeof(tagint), 1, node_to_atom.data(), &n_nodes))
+    error->one(FLERR, std::string("e3gnn/parallel: ") + snet_last_error());
+  n_ghost_nodes = (int)(n_nodes - inum);
+
+  owner_info.assign((size_t)nall * 2, -1.0);
+  for (int ii = 0; ii < inum; ii++) {
+    const int i = list->ilist[ii];
+    if (i < nlocal) {
+      owner_info[2 * (size_t)i] = me;
+      owner_info[2 * (size_t)i + 1] = ii;
+    }
+  }
+  comm->forward_comm(this);
+
+  // receive side: ghost nodes grouped by owner rank (stable), k-th row of that stream = ghost row perm[k]
+  std::vector<int> owner(n_ghost_nodes), orow(n_ghost_nodes), order(n_ghost_nodes);
+  for (int k = 0; k < n_ghost_nodes; k++) {
+    const int a = node_to_atom[inum + k];
+    owner[k] = (int)owner_info[2 * (size_t)a];
+    orow[k] = (int)owner_info[2 * (size_t)a + 1];
+    if (owner[k] < 0 || owner[k] >= np || owner[k] == me || orow[k] < 0)
+      error->one(FLERR, "e3gnn/parallel: a ghost atom has no owner among the other ranks (is the ghost cutoff >= the model cutoff?)");
+  }
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return owner[a] < owner[b]; });
+  std::vector<int32_t> recv_counts(np, 0), send_counts(np, 0), recv_perm(n_ghost_nodes), want(n_ghost_nodes);
+  for (int k = 0; k < n_ghost_nodes; k++) {
+    recv_counts[owner[order[k]]]++;
+    recv_perm[k] = order[k];
+    want[k] = orow[order[k]];  // the owner's graph row, in the order the owner has to send them
+  }
+  MPI_Alltoall(recv_counts.data(), 1, MPI_INT, send_counts.data(), 1, MPI_INT, world);
+  std::vector<int> rdisp(np + 1, 0), sdisp(np + 1, 0);
+  for (int p = 0; p < np; p++) {
+    rdisp[p + 1] = rdisp[p] + recv_counts[p];
+    sdisp[p + 1] = sdisp[p] + send_counts[p];
+  }
+  std::vector<int32_t> send_idx(std::max(sdisp[np], 1));
+  MPI_Alltoallv(want.data(), recv_counts.data(), rdisp.data(), MPI_INT, send_idx.data(), send_counts.data(), sdisp.data(),
+                MPI_INT, world);
+
+  if (halo) snet_halo_destroy(halo);
+  halo = nullptr;
+  if (snet_halo_create(rccl_comm, np, me, send_counts.data(), send_idx.data(), recv_counts.data(), recv_perm.data(), &halo))
+    error->one(FLERR, std::string("e3gnn/parallel: ") + snet_last_error());
+  // fold_forces 0: ghost forces stay in f[ghost], LAMMPS folds them with its own reverse_comm (newton on)
+  if (snet_model_set_rccl_halo(model, halo, 0)) error->one(FLERR, std::string("e3gnn/parallel: ") + snet_last_error());
+}
+
 void PairE3GNNHip::compute(int eflag, int vflag) {
   ev_init(eflag, vflag);
   if (ghost_mode == 1 && vflag_atom) error->all(FLERR, "atomic stress is not supported\n");
+  if (ghost_mode == 1 && (neighbor->ago == 0 || halo == nullptr)) build_halo_plan();
 
   const int nall = atom->nlocal + atom->nghost;
   node_to_atom.resize(nall);
@@ -141,60 +218,19 @@ void PairE3GNNHip::compute(int eflag, int vflag) {
                                  vflag_either, vflag_atom, &atom->f[0][0], &e, v, eflag_atom ? eatom : nullptr,
                                  vflag_atom ? &vatom[0][0] : nullptr, node_to_atom.data(), &n_nodes, &n_edges, stream);
   if (rc) error->one(FLERR, std::string("e3gnn: ") + snet_last_error());
+  if (ghost_mode == 1 && n_nodes - list->inum != n_ghost_nodes)
+    error->one(FLERR, "e3gnn/parallel: the ghost set changed without a neighbor-list rebuild");
   if (eflag_global) eng_vdwl += e;
   if (vflag_global)
     for (int k = 0; k < 6; k++) virial[k] += v[k];
 }
 
-/* ---- ghost-node feature exchange through LAMMPS' comm ---------------------------------------
-   The engine hands a DEVICE matrix x[n_nodes, dim].  Rows are staged to the host by atom index,
-   exchanged with comm->forward_comm(this) / reverse_comm(this), and staged back.  Several ghost
-   atoms can be images of one identity (one graph node): forward copies any of them (all equal);
-   reverse places the node's gradient on node_to_atom[node] only, so it is summed once.        */
-int PairE3GNNHip::halo_forward(void *self, float *x_dev, int64_t n_total, int64_t n_local, int32_t dim, void *st) {
-  auto *p = static_cast<PairE3GNNHip *>(self);
-  const int nall = p->atom->nlocal + p->atom->nghost;
-  p->row_dim = dim;
-  p->rows.assign((size_t)nall * dim, 0.f);
-  p->stage.resize((size_t)n_total * dim);
-  if (hipMemcpyAsync(p->stage.data(), x_dev, (size_t)n_local * dim * 4, hipMemcpyDeviceToHost, (hipStream_t)st) != hipSuccess ||
-      hipStreamSynchronize((hipStream_t)st) != hipSuccess)
-    return 1;
-  for (int64_t g = 0; g < n_local; g++)
-    memcpy(&p->rows[(size_t)p->node_to_atom[g] * dim], &p->stage[(size_t)g * dim], (size_t)dim * 4);
-  p->comm->forward_comm(p);
-  for (int64_t g = n_local; g < n_total; g++)
-    memcpy(&p->stage[(size_t)g * dim], &p->rows[(size_t)p->node_to_atom[g] * dim], (size_t)dim * 4);
-  if (hipMemcpyAsync(x_dev + n_local * dim, p->stage.data() + n_local * dim, (size_t)(n_total - n_local) * dim * 4,
-                     hipMemcpyHostToDevice, (hipStream_t)st) != hipSuccess)
-    return 1;
-  return hipStreamSynchronize((hipStream_t)st) != hipSuccess;  // `stage` is reused by the next exchange
-}
-
-int PairE3GNNHip::halo_reverse(void *self, float *x_dev, int64_t n_total, int64_t n_local, int32_t dim, void *st) {
-  auto *p = static_cast<PairE3GNNHip *>(self);
-  const int nall = p->atom->nlocal + p->atom->nghost;
-  p->row_dim = dim;
-  p->rows.assign((size_t)nall * dim, 0.f);
-  p->stage.resize((size_t)n_total * dim);
-  if (hipMemcpyAsync(p->stage.data(), x_dev, (size_t)n_total * dim * 4, hipMemcpyDeviceToHost, (hipStream_t)st) != hipSuccess ||
-      hipStreamSynchronize((hipStream_t)st) != hipSuccess)
-    return 1;
-  for (int64_t g = 0; g < n_total; g++)
-    memcpy(&p->rows[(size_t)p->node_to_atom[g] * dim], &p->stage[(size_t)g * dim], (size_t)dim * 4);
-  p->comm->reverse_comm(p);  // ghost rows are added into their owners (unpack_reverse_comm)
-  for (int64_t g = 0; g < n_local; g++)
-    memcpy(&p->stage[(size_t)g * dim], &p->rows[(size_t)p->node_to_atom[g] * dim], (size_t)dim * 4);
-  if (hipMemcpyAsync(x_dev, p->stage.data(), (size_t)n_local * dim * 4, hipMemcpyHostToDevice, (hipStream_t)st) != hipSuccess)
-    return 1;
-  return hipStreamSynchronize((hipStream_t)st) != hipSuccess;
-}
-
+/* the only traffic through LAMMPS' comm: two doubles per atom when the neighbor list was rebuilt */
 int PairE3GNNHip::pack_forward_comm(int n, int *list_, double *buf, int /*pbc_flag*/, int * /*pbc*/) {
   int m = 0;
   for (int i = 0; i < n; i++) {
-    const float *r = &rows[(size_t)list_[i] * row_dim];
-    for (int k = 0; k < row_dim; k++) buf[m++] = r[k];
+    buf[m++] = owner_info[2 * (size_t)list_[i]];
+    buf[m++] = owner_info[2 * (size_t)list_[i] + 1];
   }
   return m;
 }
@@ -202,24 +238,7 @@ int PairE3GNNHip::pack_forward_comm(int n, int *list_, double *buf, int /*pbc_fl
 void PairE3GNNHip::unpack_forward_comm(int n, int first, double *buf) {
   int m = 0;
   for (int i = first; i < first + n; i++) {
-    float *r = &rows[(size_t)i * row_dim];
-    for (int k = 0; k < row_dim; k++) r[k] = (float)buf[m++];
-  }
-}
-
-int PairE3GNNHip::pack_reverse_comm(int n, int first, double *buf) {
-  int m = 0;
-  for (int i = first; i < first + n; i++) {
-    const float *r = &rows[(size_t)i * row_dim];
-    for (int k = 0; k < row_dim; k++) buf[m++] = r[k];
-  }
-  return m;
-}
-
-void PairE3GNNHip::unpack_reverse_comm(int n, int *list_, double *buf) {
-  int m = 0;
-  for (int i = 0; i < n; i++) {
-    float *r = &rows[(size_t)list_[i] * row_dim];
-    for (int k = 0; k < row_dim; k++) r[k] += (float)buf[m++];
+    owner_info[2 * (size_t)i] = buf[m++];
+    owner_info[2 * (size_t)i + 1] = buf[m++];
   }
 }

@@ -2,21 +2,23 @@
    LAMMPS pair styles backed by libsnet_hip.so (MI355X force engine).
 
    pair_style e3gnn            (one process holds the periodic cell; ghosts aliased by tag)
-   pair_style e3gnn/parallel   (spatial decomposition; ghost atoms are graph nodes, their
-                                features travel through LAMMPS' own forward/reverse comm)
+   pair_style e3gnn/parallel   (spatial decomposition; ghost atoms are graph nodes, their features
+                                travel GPU to GPU over RCCL inside the engine)
 
    Same style names and pair_coeff grammar as the reference's TorchScript-backed styles
    (sevenn/pair_e3gnn/pair_e3gnn.h:15, pair_e3gnn_parallel.h:15):
        pair_coeff * * <model.snet> <element of type 1> <element of type 2> ...
    The model file is written by `python -m sevennet_amd.deploy` (replaces `sevenn get_model`).
-   Unlike the reference, e3gnn/parallel needs NO patched comm_brick.cpp: it uses the stock
-   Pair::pack_forward_comm / pack_reverse_comm hooks, and one model file instead of one
-   TorchScript segment per layer.
+   Unlike the reference, e3gnn/parallel needs NO patched comm_brick.cpp, no LibTorch and no CUDA-aware
+   MPI: the per-layer ghost exchange is the engine's own RCCL send/recv group (snet_halo_*,
+   csrc/snet_halo.cpp) -- device to device over xGMI.  LAMMPS' comm is used once per neighbor-list
+   rebuild, with two doubles per atom, to learn which rank owns each ghost and under which row.
 
-   NOT COMPILED in the development image (no LAMMPS tree / MPI there).  Everything below the
-   LAMMPS API surface -- graph build from the neighbor list, evaluation, force/virial
-   accumulation, ghost-node exchange hooks -- is snet_md_compute(), which IS tested
-   (tests/test_md_host_gpu.py drives it with the same arrays this file passes).
+   NOT COMPILED AGAINST LAMMPS in the development image (no LAMMPS tree / MPI there); tests/test_lammps_glue_cpu.py
+   only checks that both files parse and type-check against a small mock of the LAMMPS API subset they
+   use (tests/lammps_mock/).  Everything below that API -- graph build from the neighbor list,
+   evaluation, force / virial accumulation (snet_md_compute) and the ghost exchange (snet_halo_*) -- IS
+   tested on the GPU (tests/test_md_host_gpu.py, tests/test_engine_gpu.py).
 ------------------------------------------------------------------------- */
 #ifdef PAIR_CLASS
 // clang-format off
@@ -34,6 +36,7 @@ PairStyle(e3gnn/parallel, PairE3GNNHipParallel)
 
 struct snet_model;
 struct snet_md_host;
+struct snet_halo;
 
 namespace LAMMPS_NS {
 
@@ -47,29 +50,25 @@ class PairE3GNNHip : public Pair {
   void init_style() override;
   double init_one(int, int) override;
 
-  // ghost-node feature exchange (e3gnn/parallel only): stock LAMMPS comm hooks
+  // e3gnn/parallel, once per neighbor-list rebuild: (owner rank, owner's graph row) of every atom -> its ghosts
   int pack_forward_comm(int, int *, double *, int, int *) override;
   void unpack_forward_comm(int, int, double *) override;
-  int pack_reverse_comm(int, int, double *) override;
-  void unpack_reverse_comm(int, int *, double *) override;
 
  protected:
   int ghost_mode = 0;  // 0: e3gnn, 1: e3gnn/parallel
   double cutoff = 0.0;
   snet_model *model = nullptr;
   snet_md_host *host = nullptr;
-  void *stream = nullptr;  // hipStream_t
+  snet_halo *halo = nullptr;
+  void *rccl_comm = nullptr;  // created by libsnet_hip.so (snet_rccl_comm_create) from an id broadcast over MPI
+  void *stream = nullptr;     // hipStream_t
 
-  // host staging of one feature exchange, addressed by LAMMPS atom index
-  std::vector<float> rows;           // [nall, row_dim]
-  std::vector<float> stage;          // pinned-size staging of device rows [n_nodes, row_dim]
-  std::vector<int> node_to_atom;     // graph node -> atom index (filled by snet_md_compute)
-  int row_dim = 0;
-  int max_comm_dim = 0;
+  std::vector<int> node_to_atom;     // graph node -> atom index
+  std::vector<double> owner_info;    // [nall][2]: owning rank, graph row on that rank
+  int n_ghost_nodes = 0;
 
   void allocate();
-  static int halo_forward(void *self, float *x_dev, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
-  static int halo_reverse(void *self, float *x_dev, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
+  void build_halo_plan();
 };
 
 class PairE3GNNHipParallel : public PairE3GNNHip {

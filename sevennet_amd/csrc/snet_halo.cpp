@@ -117,7 +117,9 @@ struct snet_halo {
   std::vector<int64_t> send_cnt, recv_cnt, send_off, recv_off;  // rows per peer and their prefix sums
   int64_t n_send = 0, n_ghost = 0, n_seg = 0;
   Dev<int32_t> send_idx, red_rows, red_perm, red_ptr;
-  Dev<float> send_buf, recv_buf, seg_buf;  // grown to the widest row seen
+  Dev<int32_t> ghost_perm, ghost_inv;      // optional: k-th received row (peer order) <-> ghost row (host's node order)
+  bool permuted = false;
+  Dev<float> send_buf, recv_buf, seg_buf, ghost_buf;  // grown to the widest row seen
 };
 
 extern "C" {
@@ -161,7 +163,7 @@ int snet_rccl_allreduce_sum_f64(void *comm, double *dev_values, int64_t n, void 
 }
 
 int snet_halo_create(void *comm, int32_t world, int32_t rank, const int32_t *send_counts, const int32_t *send_idx_host,
-                     const int32_t *recv_counts, snet_halo **out) {
+                     const int32_t *recv_counts, const int32_t *recv_perm_host, snet_halo **out) {
   SNET_REQUIRE(comm != nullptr && out != nullptr && send_counts && recv_counts && world >= 1 && rank >= 0 && rank < world,
                "snet_halo_create: bad argument");
   auto *h = new snet_halo;
@@ -199,6 +201,21 @@ int snet_halo_create(void *comm, int32_t world, int32_t rank, const int32_t *sen
     h->n_seg = (int64_t)rows.size();
     ok = ok && h->red_rows.upload(rows) && h->red_perm.upload(perm) && h->red_ptr.upload(ptr);
   }
+  if (ok && recv_perm_host != nullptr && h->n_ghost > 0) {
+    // the host numbers its ghost rows in its own order: the k-th row of the peer-ordered stream is ghost row perm[k]
+    std::vector<int32_t> perm(recv_perm_host, recv_perm_host + h->n_ghost), inv(h->n_ghost, -1);
+    for (int64_t k = 0; k < h->n_ghost && ok; ++k) {
+      ok = perm[k] >= 0 && perm[k] < h->n_ghost && inv[perm[k]] < 0;
+      if (ok) inv[perm[k]] = (int32_t)k;
+    }
+    if (!ok) {
+      delete h;
+      snet::set_error("snet_halo_create: recv_perm is not a permutation of the ghost rows");
+      return 2;
+    }
+    ok = h->ghost_perm.upload(perm) && h->ghost_inv.upload(inv);
+    h->permuted = true;
+  }
   if (!ok) {
     delete h;
     snet::set_error("snet_halo_create: device allocation / upload failed");
@@ -225,17 +242,24 @@ int snet_halo_forward(void *user, float *x, int64_t n_total, int64_t n_local, in
     SNET_REQUIRE(h->send_buf.ensure((size_t)h->n_send * dim), "snet_halo_forward: allocation failed");
     if (int rc = snet_gather_rows(x, h->send_idx.p, h->send_buf.p, h->n_send, dim, stream)) return rc;
   }
+  float *land = x + n_local * dim;  // where the peer-ordered stream lands
+  if (h->permuted) {
+    SNET_REQUIRE(h->ghost_buf.ensure((size_t)h->n_ghost * dim), "snet_halo_forward: allocation failed");
+    land = h->ghost_buf.p;
+  }
   int rc = r->GroupStart();
   if (rc) return fail("ncclGroupStart", rc);
   for (int p = 0; p < h->world && !rc; ++p) {
     if (h->send_cnt[p])
       rc = r->Send(h->send_buf.p + h->send_off[p] * dim, (size_t)h->send_cnt[p] * dim, kFloat, p, h->comm, st);
     if (!rc && h->recv_cnt[p])
-      rc = r->Recv(x + (n_local + h->recv_off[p]) * dim, (size_t)h->recv_cnt[p] * dim, kFloat, p, h->comm, st);
+      rc = r->Recv(land + h->recv_off[p] * dim, (size_t)h->recv_cnt[p] * dim, kFloat, p, h->comm, st);
   }
   const int rc2 = r->GroupEnd();
   if (rc) return fail("ncclSend/ncclRecv", rc);
   if (rc2) return fail("ncclGroupEnd", rc2);
+  if (h->permuted)  // ghost row g <- stream row inv[g]
+    return snet_gather_rows(h->ghost_buf.p, h->ghost_inv.p, x + n_local * dim, h->n_ghost, dim, stream);
   return 0;
 }
 
@@ -250,11 +274,17 @@ int snet_halo_reverse(void *user, float *gx, int64_t n_total, int64_t n_local, i
   if (h->n_send > 0)
     SNET_REQUIRE(h->recv_buf.ensure((size_t)h->n_send * dim) && h->seg_buf.ensure((size_t)h->n_seg * dim),
                  "snet_halo_reverse: allocation failed");
+  const float *home = gx + n_local * dim;  // ghost rows in peer order
+  if (h->permuted) {
+    SNET_REQUIRE(h->ghost_buf.ensure((size_t)h->n_ghost * dim), "snet_halo_reverse: allocation failed");
+    if (int e = snet_gather_rows(gx + n_local * dim, h->ghost_perm.p, h->ghost_buf.p, h->n_ghost, dim, stream)) return e;
+    home = h->ghost_buf.p;
+  }
   int rc = r->GroupStart();
   if (rc) return fail("ncclGroupStart", rc);
   for (int p = 0; p < h->world && !rc; ++p) {
     if (h->recv_cnt[p])  // my ghost rows owned by p go home
-      rc = r->Send(gx + (n_local + h->recv_off[p]) * dim, (size_t)h->recv_cnt[p] * dim, kFloat, p, h->comm, st);
+      rc = r->Send(home + h->recv_off[p] * dim, (size_t)h->recv_cnt[p] * dim, kFloat, p, h->comm, st);
     if (!rc && h->send_cnt[p])  // p returns the gradients of the rows I sent it
       rc = r->Recv(h->recv_buf.p + h->send_off[p] * dim, (size_t)h->send_cnt[p] * dim, kFloat, p, h->comm, st);
   }

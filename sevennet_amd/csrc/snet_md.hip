@@ -313,6 +313,37 @@ extern "C" void snet_md_destroy(snet_md_host *h) {
   delete h;
 }
 
+
+// The graph nodes snet_md_compute will use for these arrays, without running anything: node -> atom index
+// (inum locals in ilist order, then -- ghost_mode 1 -- one node per ghost identity not owned here, in
+// first-seen atom order).  A pair style calls this when the neighbor list was rebuilt to lay out its ghost
+// exchange (snet_halo_create) before the next evaluations; snet_md_compute numbers the nodes identically.
+extern "C" int snet_md_nodes(int32_t inum, const int32_t *ilist, int32_t nall, const void *tag, int32_t tag_bytes,
+                             int32_t ghost_mode, int32_t *node_to_atom_out, int64_t *n_nodes_out) {
+  SNET_REQUIRE(inum > 0 && nall >= inum && ilist && tag && node_to_atom_out && n_nodes_out, "snet_md_nodes: bad argument");
+  SNET_REQUIRE(tag_bytes == 4 || tag_bytes == 8, "snet_md_nodes: tag_bytes must be 4 or 8");
+  SNET_REQUIRE(ghost_mode == 0 || ghost_mode == 1, "snet_md_nodes: ghost_mode must be 0 or 1");
+  auto tag_of = [&](int a) -> int64_t {
+    return tag_bytes == 4 ? (int64_t) static_cast<const int32_t *>(tag)[a] : static_cast<const int64_t *>(tag)[a];
+  };
+  std::unordered_map<int64_t, int32_t> seen;
+  seen.reserve((size_t)nall * 2);
+  int64_t n = 0;
+  for (int ii = 0; ii < inum; ++ii) {
+    SNET_REQUIRE(ilist[ii] >= 0 && ilist[ii] < nall, "snet_md_nodes: ilist entry out of range");
+    seen[tag_of(ilist[ii])] = ii;
+    node_to_atom_out[n++] = ilist[ii];
+  }
+  if (ghost_mode == 1)
+    for (int j = 0; j < nall; ++j)
+      if (seen.find(tag_of(j)) == seen.end()) {
+        seen[tag_of(j)] = (int32_t)n;
+        node_to_atom_out[n++] = j;
+      }
+  *n_nodes_out = n;
+  return 0;
+}
+
 extern "C" int snet_md_compute(snet_md_host *h, int32_t inum, const int32_t *ilist, const int32_t *numneigh,
                                const int32_t *const *firstneigh, int32_t nall, const double *x, const int32_t *type,
                                const void *tag, int32_t tag_bytes, const int32_t *type_map, int32_t ntypes,

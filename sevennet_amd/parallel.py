@@ -285,7 +285,7 @@ class NativeHalo:
     (HipForceEngine, NativeModel) accept it; NativeModel installs it with snet_model_set_rccl_halo, i.e. the
     evaluation then runs without a single Python callback."""
 
-    def __init__(self, comm: RcclComm, send_lists: Sequence[np.ndarray], recv_counts: Sequence[int]):
+    def __init__(self, comm: RcclComm, send_lists: Sequence[np.ndarray], recv_counts: Sequence[int], recv_perm=None):
         from . import _lib
         self.lib, self.comm = _lib.load(), comm
         world = comm.world
@@ -295,10 +295,14 @@ class NativeHalo:
         idx = np.ascontiguousarray(np.concatenate([np.asarray(s, np.int64) for s in send_lists]) if world else
                                    np.zeros(0, np.int64), dtype=np.int32)
         self.n_ghost = int(rc.sum())
+        # recv_perm (optional): the k-th received row (peer order) is ghost row recv_perm[k] of the host's numbering
+        perm = None if recv_perm is None else np.ascontiguousarray(recv_perm, dtype=np.int32)
         self.handle = C.c_void_p()
         _lib.check(self.lib.snet_halo_create(comm.handle, world, comm.rank, C.c_void_p(sc.ctypes.data),
                                              C.c_void_p(idx.ctypes.data) if idx.size else None,
-                                             C.c_void_p(rc.ctypes.data), C.byref(self.handle)), 'snet_halo_create')
+                                             C.c_void_p(rc.ctypes.data),
+                                             None if perm is None else C.c_void_p(perm.ctypes.data),
+                                             C.byref(self.handle)), 'snet_halo_create')
 
     def forward(self, x: torch.Tensor, n_local: int):
         from . import _lib

@@ -115,3 +115,27 @@ def test_gemm_split_pack_is_an_exact_three_term_bf16_sum():
                     want = float(B[k, n]) if (k < K and n < N) else 0.0
                     assert abs(total[t, q, lane, i] - want) <= 2.0 ** -22 * abs(want)
     assert lib.snet_gemm_split_pack(None, K, N, C.c_void_p(buf.ctypes.data)) != 0
+
+
+def test_md_nodes_numbering_host_only():
+    """snet_md_nodes (pure host code): owned atoms in ilist order, then one node per ghost identity owned
+    elsewhere in first-seen atom order -- the numbering snet_md_compute uses (tag_to_graph_idx of
+    pair_e3gnn_parallel.cpp:262-287), which a pair style needs before an evaluation to lay out its halo"""
+    import ctypes as C
+    import numpy as np
+    from sevennet_amd import _lib
+    lib = _lib.load()
+    tag = np.array([5, 6, 7, 8, 9, 5, 9, 11, 6, 11, 12], np.int32)   # 4 owned (ilist), images of owned 5 / 6, ghosts 9, 11, 12
+    ilist = np.array([2, 0, 3, 1], np.int32)
+    out = np.full(len(tag), -1, np.int32)
+    n = C.c_int64()
+    P = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    _lib.check(lib.snet_md_nodes(4, P(ilist), len(tag), P(tag), 4, 1, P(out), C.byref(n)))
+    assert n.value == 7 and out[:7].tolist() == [2, 0, 3, 1, 4, 7, 10]   # ghosts: tag 9 (atom 4), 11 (atom 7), 12 (atom 10)
+    _lib.check(lib.snet_md_nodes(4, P(ilist), len(tag), P(tag), 4, 0, P(out), C.byref(n)))
+    assert n.value == 4
+    tag8 = tag.astype(np.int64)
+    _lib.check(lib.snet_md_nodes(4, P(ilist), len(tag), P(tag8), 8, 1, P(out), C.byref(n)))
+    assert n.value == 7 and out[4:7].tolist() == [4, 7, 10]
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.snet_md_nodes(0, P(ilist), len(tag), P(tag), 4, 1, P(out), C.byref(n)))

@@ -555,3 +555,20 @@ def test_native_rccl_halo_self_exchange():
     assert e.tolist() == [1.5, -2.0]
     with pytest.raises(RuntimeError, match='ghost row count'):
         halo.forward(torch.zeros(n_local + 1, 4, device=dev), n_local)
+    # hosts that number their ghost rows themselves: k-th stream row -> ghost row perm[k]
+    perm = torch.randperm(len(send), generator=g).numpy()
+    hp = NativeHalo(comm, [send], [len(send)], recv_perm=perm)
+    x = x0.clone()
+    hp.forward(x, n_local)
+    torch.cuda.synchronize()
+    want = torch.empty_like(x0[n_local:])
+    want[torch.as_tensor(perm, device=dev).long()] = x0[torch.as_tensor(send, device=dev).long()]
+    assert torch.equal(x[n_local:], want)
+    gx = torch.randn(n_local + len(send), dim, generator=g).to(dev)
+    ref = gx.clone().double()
+    ref[:n_local].index_add_(0, torch.as_tensor(send, device=dev).long(), ref[n_local:][torch.as_tensor(perm, device=dev).long()])
+    hp.reverse(gx, n_local)
+    torch.cuda.synchronize()
+    assert (gx[:n_local].double() - ref[:n_local]).abs().max() < 1e-5
+    with pytest.raises(RuntimeError, match='permutation'):
+        NativeHalo(comm, [send], [len(send)], recv_perm=np.zeros(len(send), np.int32))

@@ -1,0 +1,55 @@
+"""CPU: the LAMMPS glue (lammps/pair_e3gnn_hip.{h,cpp}) parses and type-checks against a MOCK of the LAMMPS
+API subset it uses (tests/lammps_mock/ -- not LAMMPS; no LAMMPS tree or MPI exists in the development image),
+and the patch script does to a LAMMPS-shaped tree what the reference's patch_lammps.sh:74-134 does to a real
+one (backup, copy sources, append to cmake/CMakeLists.txt, refuse a second run)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which('g++') is None or not os.path.exists('/opt/rocm/include/hip/hip_runtime.h'),
+                    reason='needs g++ and the HIP headers')
+def test_pair_style_sources_type_check_against_mock_lammps():
+    r = subprocess.run(['g++', '-std=c++17', '-fsyntax-only', '-Wall', '-D__HIP_PLATFORM_AMD__',
+                        '-I', os.path.join(ROOT, 'tests', 'lammps_mock'), '-I', os.path.join(ROOT, 'include'),
+                        '-I', '/opt/rocm/include', os.path.join(ROOT, 'lammps', 'pair_e3gnn_hip.cpp')],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    own = [ln for ln in r.stderr.splitlines() if 'pair_e3gnn_hip' in ln and ('warning' in ln or 'error' in ln)]
+    assert own == [], own
+    # the style registration block the LAMMPS build scans for
+    h = open(os.path.join(ROOT, 'lammps', 'pair_e3gnn_hip.h')).read()
+    assert 'PairStyle(e3gnn, PairE3GNNHip)' in h and 'PairStyle(e3gnn/parallel, PairE3GNNHipParallel)' in h
+    c = open(os.path.join(ROOT, 'lammps', 'pair_e3gnn_hip.cpp')).read()
+    # every C-ABI entry point the glue calls is declared in include/snet_hip.h
+    import re
+    api = open(os.path.join(ROOT, 'include', 'snet_hip.h')).read()
+    for fn in sorted(set(re.findall(r'\b(snet_[a-z0-9_]+)\(', c))):
+        assert re.search(r'\b' + fn + r'\(', api), fn
+
+
+def test_patch_script_on_a_lammps_shaped_tree(tmp_path):
+    lmp = tmp_path / 'lammps'
+    (lmp / 'cmake').mkdir(parents=True)
+    (lmp / 'src').mkdir()
+    (lmp / 'cmake' / 'CMakeLists.txt').write_text('project(lammps)\nset(CMAKE_CXX_STANDARD 11)\nadd_library(lammps)\n')
+    libdir = tmp_path / 'lib'
+    libdir.mkdir()
+    (libdir / 'libsnet_hip.so').write_bytes(b'')
+    script = os.path.join(ROOT, 'lammps', 'patch_lammps_hip.sh')
+    r = subprocess.run(['bash', script, str(lmp), str(libdir)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for f in ('pair_e3gnn_hip.h', 'pair_e3gnn_hip.cpp', 'snet_hip.h'):
+        assert (lmp / 'src' / f).exists(), f
+    cm = (lmp / 'cmake' / 'CMakeLists.txt').read_text()
+    assert 'set(CMAKE_CXX_STANDARD 17)' in cm and 'libsnet_hip.so' in cm and 'find_package(hip REQUIRED)' in cm
+    assert 'Torch' not in cm and 'comm_brick' not in cm          # neither LibTorch nor a comm patch
+    assert (lmp / '_backups' / 'CMakeLists.txt').read_text().count('CMAKE_CXX_STANDARD 11') == 1
+    again = subprocess.run(['bash', script, str(lmp), str(libdir)], capture_output=True, text=True)
+    assert again.returncode != 0 and 'already patched' in again.stdout
+    bad = subprocess.run(['bash', script, str(tmp_path / 'nope')], capture_output=True, text=True)
+    assert bad.returncode != 0

@@ -233,6 +233,15 @@ def test_md_host_ghost_nodes_two_ranks_equal_single_process():
     for r, ((x, tag, nlocal, rows), out) in enumerate(zip(doms, results)):
         assert out['n_nodes'] == nlocal + len(expect_nodes[r]) and len(expect_nodes[r]) > 0
         assert [int(tag[a]) - 1 for a in out['node_to_atom'][nlocal:]] == expect_nodes[r]
+        # snet_md_nodes (what a pair style calls to lay out its RCCL halo) numbers the nodes identically
+        n2a = np.full(len(x), -1, np.int32)
+        nn = C.c_int64()
+        il = np.arange(nlocal, dtype=np.int32)
+        tg = np.ascontiguousarray(tag, np.int32)
+        from sevennet_amd import _lib
+        _lib.check(hosts[r].lib.snet_md_nodes(nlocal, C.c_void_p(il.ctypes.data), len(x), C.c_void_p(tg.ctypes.data), 4, 1,
+                                              C.c_void_p(n2a.ctypes.data), C.byref(nn)), 'snet_md_nodes')
+        assert nn.value == out['n_nodes'] and np.array_equal(n2a[:nn.value], out['node_to_atom'])
         np.add.at(F, tag - 1, out['f'])              # LAMMPS reverse_comm: ghost forces go to their owners
         np.add.at(Ea, tag[:nlocal] - 1, out['eatom'][:nlocal])
         e_tot += out['energy']; vir += out['virial']
