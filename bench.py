@@ -47,7 +47,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--reps', type=int, default=23, help='diamond cells per axis (23 -> 97 336 atoms)')
+    ap.add_argument('--reps', type=int, default=0, help='diamond cells per axis; default per model: sevennet_0 23 (97 336 atoms), '
+                    'sevennet_l3i5 19 (54 872, BASELINE config 4), sevennet_mf_ompa 15 (27 000)')
     ap.add_argument('--model', default='sevennet_0', choices=['sevennet_0', 'sevennet_l3i5', 'sevennet_mf_ompa'])
     ap.add_argument('--mlp-mode', default='bf16x6', choices=['bf16x6', 'fp32'],
                     help='radial-MLP MFMA mode: bf16 x6 split products (fp32-class accuracy) or exact fp32 MFMA')
@@ -178,7 +179,20 @@ def main():
     modal = 'mpa' if cfg.get('use_modality') else None
     eng = HipForceEngine(cfg, sd, device=dev, mlp_mode=a.mlp_mode, fused=(False if a.fused == 'off' else a.fused), fused_terms=a.terms, modal=modal, overlap=not a.no_overlap)
 
-    pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
+    # workloads of SURVEY.md section 8(d): config 3 (SevenNet-0: sigma 0.05 A, seed 2), config 4 (l3i5: "amorphous",
+    # sigma 0.35 A with a 1.8 A minimum-distance reject, seed 3), config 5's per-GPU share (MF-ompa: 4-species
+    # decoration, sigma 0.1 A, seed 4, cutoff 6 A)
+    a.reps = a.reps or {'sevennet_0': 23, 'sevennet_l3i5': 19, 'sevennet_mf_ompa': 15}[a.model]
+    if a.model == 'sevennet_l3i5':
+        from sevennet_amd.neighbor import amorphous_cell
+        pos, cell = amorphous_cell(5.431, (a.reps,) * 3, 0.35, 3, 1.8)
+        wl_note = 'sigma=0.35 A with a 1.8 A minimum-distance reject ("amorphous", BASELINE config 4)'
+    elif a.model == 'sevennet_mf_ompa':
+        pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.1, 4)
+        wl_note = 'sigma=0.1 A, 4-species decoration Z in {3, 8, 14, 22} (per-GPU share of BASELINE config 5)'
+    else:
+        pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
+        wl_note = 'sigma=0.05 A'
     n_atoms = len(pos)
     t0 = time.perf_counter()
     halo = None
@@ -339,7 +353,7 @@ def main():
             'warmup': a.warmup, 'ms_per_step': step_ms, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'{a.model} shape (5 interaction layers), {n_atoms}-atom periodic diamond-Si '
-                                   f'cell (a=5.431 A x {a.reps}^3, sigma=0.05 A), cutoff {cfg["cutoff"]} A, '
+                                   f'cell (a=5.431 A x {a.reps}^3, {wl_note}), cutoff {cfg["cutoff"]} A, '
                                    f'{n_edges_total} directed edges, seeded synthetic weights',
                        'atoms': n_atoms, 'edges': n_edges_total,
                        'parallelism': 'single GPU' if world == 1 else f'spatial decomposition x{world}, RCCL halo',

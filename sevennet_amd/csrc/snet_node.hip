@@ -255,8 +255,9 @@ extern "C" int snet_act_bwd(const float *z, const float *g_a, float *g_z, int64_
 }
 namespace {
 __global__ void add_row_bias_kernel(float *__restrict__ y, const float *__restrict__ bias, int64_t n, int dim) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n * dim) y[k] += bias[k % dim];
+  const int64_t total = n * dim;  // grid_for() caps the grid: stride over the rest
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x)
+    y[k] += bias[k % dim];
 }
 }  // namespace
 extern "C" int snet_add_row_bias(float *y, const float *bias, int64_t n_rows, int32_t dim, void *stream) {

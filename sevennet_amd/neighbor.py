@@ -97,3 +97,24 @@ def diamond_cubic(a: float, reps, sigma: float = 0.0, seed: int = 0):
         rng = np.random.default_rng(seed)
         pos = pos + rng.normal(0.0, sigma, pos.shape)
     return pos, cell
+
+
+def amorphous_cell(a: float, reps, sigma: float, seed: int, min_dist: float = 1.8, max_rounds: int = 400):
+    """diamond sites with a melt-like Gaussian disorder `sigma` (0.35 A) and a
+    minimum-distance reject -- every atom closer than `min_dist` to another one gets a fresh displacement from
+    its lattice site until no such pair is left (periodic KD-tree search)."""
+    from scipy.spatial import cKDTree
+    site, cell = diamond_cubic(a, reps, 0.0, 0)
+    box = np.diag(cell).copy()
+    rng = np.random.default_rng(seed)
+    pos = site + rng.normal(0.0, sigma, site.shape)
+    for k in range(max_rounds):
+        w = np.mod(pos, box)
+        pairs = cKDTree(w, boxsize=box).query_pairs(min_dist, output_type='ndarray')
+        if len(pairs) == 0:
+            return pos, cell
+        bad = np.unique(pairs[:, 1] if k < 60 else pairs)   # one partner of every close pair; both once the rest is stubborn
+        # the last few stubborn atoms (all neighbors displaced towards them) are re-drawn from a narrower Gaussian
+        s_k = sigma * (0.8 ** max(0, (k - 60) // 20))
+        pos[bad] = site[bad] + rng.normal(0.0, s_k, (len(bad), 3))
+    raise RuntimeError('amorphous_cell: could not satisfy the minimum distance')

@@ -572,3 +572,52 @@ def test_native_rccl_halo_self_exchange():
     assert (gx[:n_local].double() - ref[:n_local]).abs().max() < 1e-5
     with pytest.raises(RuntimeError, match='permutation'):
         NativeHalo(comm, [send], [len(send)], recv_perm=np.zeros(len(send), np.int32))
+
+
+@pytest.mark.parametrize('model,n_tile', [('sevennet_l3i5', 19), ('sevennet_mf_ompa', 15)])
+def test_lmax3_shapes_full_size_equal_tiled_small_cell(model, n_tile):
+    """BASELINE config 4 / 5 sizes through the size-independent tiling property: SevenNet-l3i5 shape at
+    19^3 x 8 = 54 872 atoms and the SevenNet-MF-ompa shape (119 species, two fidelity channels, cutoff 6) at
+    15^3 x 8 = 27 000 atoms.  The big cell is an exact n^3 tiling of a rattled, 4-species-decorated 8-atom cell, so
+    every replica must carry the forces / atomic energies of the 2^3 tiling, which the fp64 oracle evaluates;
+    the fused tensor-product kernels (engine default) run every layer of both shapes."""
+    from bench import model_config
+    from oracle.model import OracleModel
+    from sevennet_amd.engine import HipForceEngine
+    from sevennet_amd.neighbor import neighbor_list
+    from sevennet_amd.neighbor_gpu import build_graph_gpu
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = model_config(model)
+    sd = random_state_dict(cfg, seed=0)
+    multi = bool(cfg.get('use_modality'))
+    modal = 'mpa' if multi else None
+    a = 5.431
+    basis = np.array([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0],
+                      [.25, .25, .25], [.25, .75, .75], [.75, .25, .75], [.75, .75, .25]]) * a
+    unit = basis + np.random.default_rng(11).normal(0.0, 0.08, basis.shape)
+    z_unit = np.array([3, 8, 14, 22, 8, 3, 22, 14]) if multi else np.zeros(8, np.int64)
+
+    def tile(n):
+        g = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing='ij'), -1).reshape(-1, 3) * a
+        return (g[:, None, :] + unit[None, :, :]).reshape(-1, 3), np.eye(3) * n * a, np.tile(z_unit, n ** 3)
+
+    pos_s, cell_s, ty_s = tile(2)
+    ei, ev, _ = neighbor_list(pos_s, cell_s, [True] * 3, cfg['cutoff'])
+    ref = OracleModel(cfg, sd, dtype=torch.float64, modal=modal).forward(ty_s, ei, ev)
+    f_unit, e_unit = ref['forces'].numpy()[:8], ref['atomic_energy'].numpy()[:8]
+    pos, cell, ty = tile(n_tile)
+    n_big = len(pos)
+    eng = HipForceEngine(cfg, sd, device='cuda:0', modal=modal)
+    assert all(L.fused_fwd and L.fused_bwd for L in eng.layers)
+    g = build_graph_gpu(ty, pos, cell, cfg['cutoff'], device='cuda:0',
+                        num_species=eng.spec.num_species if eng.needs_species_rows else 0)
+    assert g.n_edges * 64 == ei.shape[1] * n_big
+    out = eng.compute(g)
+    torch.cuda.synchronize()
+    F = out['forces'].cpu().numpy().reshape(-1, 8, 3)
+    Ea = out['atomic_energy'].cpu().numpy().reshape(-1, 8)
+    scale = max(1.0, np.abs(f_unit).max())
+    assert np.abs(F - f_unit[None]).max() < f_tol(scale), (np.abs(F - f_unit[None]).max(), scale)
+    assert np.abs(Ea - e_unit[None]).max() < 2e-5 * max(1.0, np.abs(e_unit).max())
+    assert abs(float(out['energy'].cpu()) / n_big - float(ref['energy']) / 64) < 2e-6
+    assert np.abs(out['forces'].cpu().numpy().astype(np.float64).sum(0)).max() < 2e-3 * scale

@@ -418,6 +418,36 @@ def test_segment_sum_rows():
     assert (out.cpu().double() - ref).abs().max() < 1e-5
 
 
+def test_elementwise_node_kernels_beyond_the_grid_cap():
+    """the elementwise node kernels run on a capped grid (8192 x 256 threads): every one of them has to
+    stride over inputs larger than that (the multi-modal bias add did not: MF-ompa above ~2500 atoms)"""
+    L, lib = _lib()
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(8)
+    n, dim = 2744, 832  # > 2^21 elements
+    y0 = torch.randn(n, dim, generator=g).to(dev)
+    bias = torch.randn(dim, generator=g).to(dev)
+    y = y0.clone()
+    L.check(lib.snet_add_row_bias(_p(y), _p(bias), n, dim, None))
+    assert torch.equal(y, y0 + bias[None])
+    x = torch.randn(n, dim, generator=g).to(dev)
+    y = y0.clone()
+    L.check(lib.snet_add_inplace(_p(y), _p(x), n * dim, None))
+    assert torch.equal(y, y0 + x)
+    table = torch.randn(7, dim, generator=g).to(dev)
+    types = torch.randint(0, 7, (n,), generator=g).to(torch.int32).to(dev)
+    out = torch.empty(n, dim, device=dev)
+    L.check(lib.snet_embed_rows(_p(table), _p(types), _p(out), n, dim, None))
+    assert torch.equal(out, table[types.long()])
+    idx = torch.randperm(n, generator=g).to(torch.int32).to(dev)
+    L.check(lib.snet_gather_rows(_p(y0), _p(idx), _p(out), n, dim, None))
+    assert torch.equal(out, y0[idx.long()])
+    a = torch.zeros(n, dim, device=dev)
+    L.check(lib.snet_act_fwd(_p(y0), _p(a), n * dim, 0, 1.5, None))
+    torch.cuda.synchronize()
+    assert bool((a[-1] != 0).any()) and bool(torch.isfinite(a).all())
+
+
 def _mid_index(spec):
     """index of each path's block inside irreps_mid (sorted, one block per path)"""
     offs = {}
