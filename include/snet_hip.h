@@ -154,8 +154,12 @@ int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, c
  *   tile_ptr   int32[n_dst+1], exclusive scan of ceil(degree/16), and tile_node int32[n_tiles] (tile -> node), both
  *              from snet_edge_tiles: the reverse kernel gives each 16-edge tile of a node's CSR segment to one
  *              wavefront (tile_node capacity: n_dst + n_edges / 16 entries always suffice)
- * reverse outputs: g_xe[E,dx] (nullable; sum per source with snet_segment_sum_rows), g_h2[E,64]
- * (overwritten; feed to snet_radial_mlp_hidden_bwd), g_vec[E,3] ACCUMULATED (as snet_conv_bwd_edge_vec).
+ * reverse outputs: g_xe[E,dx] (nullable; sum per source with snet_segment_sum_rows), g_vec[E,3] ACCUMULATED (as
+ * snet_conv_bwd_edge_vec), and exactly ONE of
+ *   g_h2[E,64]  overwritten; feed to snet_radial_mlp_hidden_bwd, or
+ *   g_emb[E,nb] ACCUMULATED: the kernel also reverses the MLP's two hidden layers per 16-edge tile (it reads
+ *               emb[E,nb], the radial basis values per DIRECTED edge), so g_h2 never reaches memory either.
+ *               Needs snet_fused_plan_has_mlp_tail(plan) != 0 (n_basis <= 16 and a multiple of 4).
  * snet_conv_fused_available() != 0 iff the shape has these kernels (channel multiplicities % 16 == 0). */
 #define SNET_FUSED_TERMS_DEFAULT 2
 typedef struct snet_fused_plan snet_fused_plan;
@@ -173,7 +177,9 @@ int snet_conv_fwd_fused(const snet_fused_plan *plan, const float *x, const float
 int snet_conv_bwd_fused(const snet_fused_plan *plan, const float *x, const float *sh, const float *dsh,
                         const float *h2, const int32_t *w_row, const int32_t *row_ptr, const int32_t *src,
                         const int32_t *tile_ptr, const int32_t *tile_node, int64_t n_tiles, float scale,
-                        const float *g_out, float *g_xe, float *g_h2, float *g_vec, void *stream);
+                        const float *g_out, float *g_xe, float *g_h2, const float *emb, float *g_emb, float *g_vec,
+                        void *stream);
+int snet_fused_plan_has_mlp_tail(const snet_fused_plan *plan);
 /* per-edge gradients given g_out[n_dst,dout]: g_w[E,wn] (overwritten), g_sh[E,nsh] (ACCUMULATED,
  * so one buffer collects all layers) and, if g_xe != NULL, this edge's contribution to the gradient
  * of its source row, g_xe[E,dx] (overwritten; sum it per source node with snet_segment_sum_rows --

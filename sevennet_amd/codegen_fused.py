@@ -175,7 +175,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    const float *__restrict__ dsh, const float *__restrict__ h2, const int32_t *__restrict__ w_row,')
     A('    const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ src, const int32_t *__restrict__ tile_ptr,')
     A('    const int32_t *__restrict__ tile_node, int n_tiles, const u32x4 *__restrict__ slabs, float scale,')
-    A('    const float *__restrict__ g_out, float *__restrict__ g_xe, float *__restrict__ g_h2, float *__restrict__ g_vec, int diag) {')
+    A('    const float *__restrict__ g_out, float *__restrict__ g_xe, float *__restrict__ g_h2, float *__restrict__ g_vec,')
+    A('    const snet::FusedTail tail, int diag) {')
     A('  // diag: always 0 in production (bit 0 also serves as the opaque branch condition around the tensor-product bodies);')
     A('  // kernel-tuning builds: 1 skip the tensor product, 2 skip the g_h2 products, 4 skip the w products, 8 skip the')
     A('  // g_out loads, 16 skip the g_xe stores -- timing decomposition, results are then garbage')
@@ -366,9 +367,116 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A(f'    for (int q = 4 * g; q < {mul_d * (2 * l_d + 1)}; q += 16)')
             A(f'      *reinterpret_cast<f32x4 *>(g_xe + (size_t)e * DX + {offs_x[i]} + q) = f32x4{{0.f, 0.f, 0.f, 0.f}};')
         A('  }')
-    A('  if (valid) {')
+    A('  if (tail.g_emb == nullptr) {')
+    A('    if (valid) {')
     A('#pragma unroll')
-    A('    for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4 *>(g_h2 + (size_t)e * 64 + 16 * m + 4 * g) = ga[m];')
+    A('      for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4 *>(g_h2 + (size_t)e * 64 + 16 * m + 4 * g) = ga[m];')
+    A('    }')
+    A('  } else {')
+    A('    // The radial MLP\'s two hidden layers, reversed on this tile\'s 16 edges: g_h2 stays in the accumulators it was')
+    A('    // summed in.  Every product keeps the transposed layout [hidden unit 16 m + 4 g + r][edge j]; as a B operand')
+    A('    // the k slot (g, t) of k-step s then names unit 16 (2 s + (t >> 2)) + 4 g + (t & 3) -- this lane\'s own registers')
+    A('    // [2 s + (t >> 2)][t & 3] -- and the host packed the weight fragments (NT terms each) in that k order.  The')
+    A('    // fragments pass through the (now idle) slab buffers in two phases, staged by the whole workgroup: per-wave')
+    A('    // global fragment loads would add ~20 % to the kernel\'s vector-memory instruction count.')
+    A('    constexpr int TA = 12 * NT, TB = 10 * NT;  // 1-KB lines: z1 (4) + z2 (8) fragments | g_a1 (8) + g_emb (2)')
+    A('    static_assert(TA <= 2 * LPS, "tail phase does not fit the slab buffers");')
+    A('    constexpr int NSA = (TA * 64 + NTH - 1) / NTH, NSB = (TB * 64 + NTH - 1) / NTH;')
+    A('    u32x4 *tl = &slab[0][0];')
+    A('    const u32x4 *ep = slabs + (size_t)NS * LPS * 64;')
+    A('    u32x4 sb[NSB];')
+    A('#pragma unroll')
+    A('    for (int i = 0; i < NSA; ++i)')
+    A('      if ((TA * 64) % NTH == 0 || tid + NTH * i < TA * 64) tl[tid + NTH * i] = ep[tid + NTH * i];')
+    A('#pragma unroll')
+    A('    for (int i = 0; i < NSB; ++i)  // phase-2 fragments wait in registers while phase 1 computes')
+    A('      if ((TB * 64) % NTH == 0 || tid + NTH * i < TB * 64) sb[i] = ep[TA * 64 + tid + NTH * i];')
+    A('    auto frag = [&](int f, bf16x8 (&a)[NT]) {')
+    A('#pragma unroll')
+    A('      for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(tl[(f * NT + tm) * 64 + lane]);')
+    A('    };')
+    A('    const int nb = tail.nb, act = tail.act;')
+    A('    const float cst = tail.cst;')
+    A('    float ev[8];')
+    A('#pragma unroll')
+    A('    for (int t = 0; t < 8; t += 4) {')
+    A('      f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};')
+    A('      if (8 * g + t < nb) q = *reinterpret_cast<const f32x4 *>(tail.emb + (size_t)e * nb + 8 * g + t);')
+    A('      ev[t] = q[0]; ev[t + 1] = q[1]; ev[t + 2] = q[2]; ev[t + 3] = q[3];')
+    A('    }')
+    A('    const SplitN<NT> eb = splitn8<NT>(ev);')
+    A('    __syncthreads();')
+    A('    f32x4 z1[4], z2[4];')
+    A('#pragma unroll')
+    A('    for (int m = 0; m < 4; ++m) {')
+    A('      bf16x8 a[NT];')
+    A('      frag(m, a);')
+    A('      z1[m] = mfma16_split<NT>(a, eb, f32x4{0.f, 0.f, 0.f, 0.f});')
+    A('      z2[m] = f32x4{0.f, 0.f, 0.f, 0.f};')
+    A('    }')
+    A('    f32x4 a1[4], d1[4];  // act(z1) cst and cst act\'(z1): one sigmoid for both')
+    A('#pragma unroll')
+    A('    for (int m = 0; m < 4; ++m)')
+    A('#pragma unroll')
+    A('      for (int r = 0; r < 4; ++r) {')
+    A('        float f_, g_;')
+    A('        snet::act_both_fast(z1[m][r], act, f_, g_);')
+    A('        a1[m][r] = f_ * cst;')
+    A('        d1[m][r] = g_ * cst;')
+    A('      }')
+    A('#pragma unroll')
+    A('    for (int s = 0; s < 2; ++s) {')
+    A('      float v[8];')
+    A('#pragma unroll')
+    A('      for (int t = 0; t < 8; ++t) v[t] = a1[2 * s + (t >> 2)][t & 3];')
+    A('      const SplitN<NT> b = splitn8<NT>(v);')
+    A('#pragma unroll')
+    A('      for (int m = 0; m < 4; ++m) {')
+    A('        bf16x8 a[NT];')
+    A('        frag(4 + 2 * m + s, a);')
+    A('        z2[m] = mfma16_split<NT>(a, b, z2[m]);')
+    A('      }')
+    A('    }')
+    A('    __syncthreads();  // every wave is done with the phase-1 fragments')
+    A('#pragma unroll')
+    A('    for (int i = 0; i < NSB; ++i)')
+    A('      if ((TB * 64) % NTH == 0 || tid + NTH * i < TB * 64) tl[tid + NTH * i] = sb[i];')
+    A('    __syncthreads();')
+    A('    f32x4 ga1[4];')
+    A('#pragma unroll')
+    A('    for (int m = 0; m < 4; ++m) ga1[m] = f32x4{0.f, 0.f, 0.f, 0.f};')
+    A('#pragma unroll')
+    A('    for (int s = 0; s < 2; ++s) {')
+    A('      float v[8];')
+    A('#pragma unroll')
+    A('      for (int t = 0; t < 8; ++t) {')
+    A('        float f_, g_;')
+    A('        snet::act_both_fast(z2[2 * s + (t >> 2)][t & 3], act, f_, g_);')
+    A('        v[t] = ga[2 * s + (t >> 2)][t & 3] * cst * g_;')
+    A('      }')
+    A('      const SplitN<NT> b = splitn8<NT>(v);')
+    A('#pragma unroll')
+    A('      for (int m = 0; m < 4; ++m) {')
+    A('        bf16x8 a[NT];')
+    A('        frag(2 * m + s, a);')
+    A('        ga1[m] = mfma16_split<NT>(a, b, ga1[m]);')
+    A('      }')
+    A('    }')
+    A('    f32x4 ge = f32x4{0.f, 0.f, 0.f, 0.f};')
+    A('#pragma unroll')
+    A('    for (int s = 0; s < 2; ++s) {')
+    A('      float v[8];')
+    A('#pragma unroll')
+    A('      for (int t = 0; t < 8; ++t) v[t] = ga1[2 * s + (t >> 2)][t & 3] * d1[2 * s + (t >> 2)][t & 3];')
+    A('      const SplitN<NT> b = splitn8<NT>(v);')
+    A('      bf16x8 a[NT];')
+    A('      frag(8 + s, a);')
+    A('      ge = mfma16_split<NT>(a, b, ge);')
+    A('    }')
+    A('    if (valid && 4 * g < nb) {  // accumulator rows 4 g + r = basis index')
+    A('      f32x4 *o = reinterpret_cast<f32x4 *>(tail.g_emb + (size_t)e * nb + 4 * g);')
+    A('      *o = *o + ge;')
+    A('    }')
     A('  }')
     A('  // d/d(edge_vec) = sum_i gy_i dY_i/dr (Y_0 is constant).  The 4 channel groups of an edge (lanes j, j+16, j+32,')
     A('  // j+48) are summed with two permlane swaps per value; only the g == 0 lanes then touch dsh and g_vec.')
@@ -605,18 +713,18 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('template <int NT, int NWV, bool GLDS, int OCC>')
     A('void launch_bwd_t(const float *x, const float *sh, const float *dsh, const float *h2, const int32_t *w_row,')
     A('                  const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, const int32_t *tile_node, int64_t n_tiles,')
-    A('                  const void *slabs, float scale, const float *g_out, float *g_xe, float *g_h2, float *g_vec, hipStream_t st) {')
+    A('                  const void *slabs, float scale, const float *g_out, float *g_xe, float *g_h2, float *g_vec, snet::FusedTail tail, hipStream_t st) {')
     A('  const unsigned grid = (unsigned)((n_tiles + NWV - 1) / NWV);')
     A('  int diag = 0;')
     if exp:
         A('  if (const char *e = getenv("SNET_FV_DIAG")) diag = atoi(e);')
     A(f'  conv_bwdf_{tag}<NT, NWV, GLDS, OCC><<<dim3(grid), dim3(64 * NWV), 0, st>>>(x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node,')
-    A('      (int)n_tiles, static_cast<const u32x4 *>(slabs), scale, g_out, g_xe, g_h2, g_vec, diag);')
+    A('      (int)n_tiles, static_cast<const u32x4 *>(slabs), scale, g_out, g_xe, g_h2, g_vec, tail, diag);')
     A('}')
     A('void launch_bwd(int nt, const float *x, const float *sh, const float *dsh, const float *h2, const int32_t *w_row,')
     A('                const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, const int32_t *tile_node, int64_t n_tiles,')
-    A('                const void *slabs, float scale, const float *g_out, float *g_xe, float *g_h2, float *g_vec, hipStream_t st) {')
-    args_b = 'x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node, n_tiles, slabs, scale, g_out, g_xe, g_h2, g_vec, st'
+    A('                const void *slabs, float scale, const float *g_out, float *g_xe, float *g_h2, float *g_vec, snet::FusedTail tail, hipStream_t st) {')
+    args_b = 'x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node, n_tiles, slabs, scale, g_out, g_xe, g_h2, g_vec, tail, st'
     if exp:
         A('  int vw = %d, vg = %d, vo = %d;' % def_b)
         A('  if (const char *e = getenv("SNET_FV_BWD")) sscanf(e, "%d,%d,%d", &vw, &vg, &vo);')

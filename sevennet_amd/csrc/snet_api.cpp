@@ -55,7 +55,8 @@ struct snet_conv_plan {
 struct snet_fused_plan {
   const snet::FusedKernels *k;
   int terms;
-  void *slabs;  // device: W2 as pre-split MFMA fragments in the kernels' sub-step order
+  void *slabs;  // device: W2 as pre-split MFMA fragments in the kernels' sub-step order, then the hidden-layer tail
+  snet::MlpHidden hidden;  // w0 == nullptr: no tail (g_h2 is always written)
 };
 
 extern "C" {
@@ -113,11 +114,16 @@ int snet_fused_plan_create(const snet_conv_plan *plan, const snet_mlp_plan *mlp,
   SNET_REQUIRE(snet::mlp_plan_wn(mlp) == k->wn && snet::mlp_plan_w2_host(mlp) != nullptr,
                "snet_fused_plan_create: the radial-MLP plan does not match the shape's weight_numel");
   void *dev = nullptr;
-  if (snet::pack_fused_slabs(snet::mlp_plan_w2_host(mlp), k->wn, k->n_sub, k->sub_cols, terms, &dev) != 0) {
+  // the reverse kernels can run the MLP's two hidden layers backwards themselves when the basis fits one
+  // 16-row operand tile and its rows are whole float4s
+  snet::MlpHidden hid = snet::mlp_plan_hidden(mlp);
+  if (hid.w0 != nullptr && !(hid.nb <= 16 && hid.nb % 4 == 0)) hid.w0 = nullptr;
+  if (snet::pack_fused_slabs(snet::mlp_plan_w2_host(mlp), k->wn, k->n_sub, k->sub_cols, terms,
+                             hid.w0 ? &hid : nullptr, &dev) != 0) {
     snet::set_error("snet_fused_plan_create: device allocation / upload of the W2 fragment stream failed");
     return 1;
   }
-  *out = new snet_fused_plan{k, terms, dev};
+  *out = new snet_fused_plan{k, terms, dev, hid};
   return 0;
 }
 void snet_fused_plan_destroy(snet_fused_plan *p) {
@@ -136,16 +142,22 @@ int snet_conv_fwd_fused(const snet_fused_plan *fp, const float *x, const float *
   SNET_CHECK_LAUNCH("snet_conv_fwd_fused");
   return 0;
 }
+int snet_fused_plan_has_mlp_tail(const snet_fused_plan *fp) { return fp != nullptr && fp->hidden.w0 != nullptr; }
+
 int snet_conv_bwd_fused(const snet_fused_plan *fp, const float *x, const float *sh, const float *dsh, const float *h2,
                         const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr,
                         const int32_t *tile_node, int64_t n_tiles, float scale, const float *g_out, float *g_xe,
-                        float *g_h2, float *g_vec, void *stream) {
+                        float *g_h2, const float *emb, float *g_emb, float *g_vec, void *stream) {
   SNET_REQUIRE(fp != nullptr, "snet_conv_bwd_fused: null plan");
   SNET_REQUIRE(n_tiles < (1ll << 31), "snet_conv_bwd_fused: too many tiles");
   if (n_tiles <= 0) return 0;
   SNET_REQUIRE(tile_ptr != nullptr && tile_node != nullptr, "snet_conv_bwd_fused: null tile list");
+  SNET_REQUIRE((g_h2 != nullptr) != (g_emb != nullptr), "snet_conv_bwd_fused: exactly one of g_h2 / g_emb is the output");
+  SNET_REQUIRE(g_emb == nullptr || (fp->hidden.w0 != nullptr && emb != nullptr),
+               "snet_conv_bwd_fused: g_emb needs emb and a plan with the hidden-layer tail (snet_fused_plan_has_mlp_tail)");
+  const snet::FusedTail tail{emb, g_emb, fp->hidden.nb, fp->hidden.act, fp->hidden.cst};
   fp->k->bwd(fp->terms, x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node, n_tiles, fp->slabs, scale, g_out,
-             g_xe, g_h2, g_vec, static_cast<hipStream_t>(stream));
+             g_xe, g_h2, g_vec, tail, static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_conv_bwd_fused");
   return 0;
 }

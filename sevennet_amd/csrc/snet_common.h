@@ -57,16 +57,25 @@ int mlp_plan_wn(const snet_mlp_plan *plan);
 // gradient g_w[E,wn] exists in memory.  A kernel walks the weight columns in `n_sub` sub-steps of two
 // 16-column tiles; `sub_cols[2 s + tp]` is the first weight column of tile tp of sub-step s (-1: padding).
 // W2 reaches the kernels as a stream of pre-split MFMA A fragments in that order (snet_fused_plan).
+// arguments of the reverse kernels' hidden-layer tail (g_h2 -> g_emb in the same kernel); g_emb == nullptr: the
+// kernel stores g_h2 instead
+struct FusedTail {
+  const float *emb;  // [E, nb] radial basis values per edge
+  float *g_emb;      // [E, nb] +=
+  int nb, act;
+  float cst;
+};
 struct FusedKernels {
   const char *tag;
   int dx, dout, nsh, wn;
   int n_sub;
   const int32_t *sub_cols;
-  // reverse pass of one tile list (snet_edge_tiles): g_xe[E,dx] (nullable), g_h2[E,64], g_vec[E,3] +=
+  // reverse pass of one tile list (snet_edge_tiles): g_xe[E,dx] (nullable), g_vec[E,3] +=, and either g_h2[E,64]
+  // or (tail.g_emb set) the radial MLP's hidden layers reversed in the same kernel: g_emb[E,nb] +=
   void (*bwd)(int nt, const float *x, const float *sh, const float *dsh, const float *h2, const int32_t *w_row,
               const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, const int32_t *tile_node,
               int64_t n_tiles, const void *slabs, float scale, const float *g_out, float *g_xe, float *g_h2,
-              float *g_vec, hipStream_t st);
+              float *g_vec, FusedTail tail, hipStream_t st);
   // forward: out[n_dst, dout]
   void (*fwd)(int nt, const float *x, const float *sh, const float *h2, const int32_t *w_row, const int32_t *row_ptr,
               const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, hipStream_t st);
@@ -81,7 +90,17 @@ const float *mlp_plan_w2_host(const snet_mlp_plan *plan);
 // W2'[64, wn] -> device stream of 1-KB fragment lines, per sub-step: [tile(2)][kstep(2)][term(nt)] (the
 // 16-column tile as A/B operand of w = h2 @ W2) then [mtile(4)][term(nt)] (W2 rows as A operand of
 // g_h2 = g_w @ W2^T over the sub-step's 32 columns).  Returns 0 on success.
-int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols, int nt, void **dev_out);
+// hidden layers of a split-precision radial-MLP plan (host copies, pre-normalised): W0'[nb, 64], W1'[64, 64]
+struct MlpHidden {
+  const float *w0, *w1;
+  int nb, act;
+  float cst;
+};
+MlpHidden mlp_plan_hidden(const snet_mlp_plan *plan);  // w0 == nullptr: the plan has no split-precision hidden layers
+constexpr int FUSED_TAIL_FRAGS = 22;  // z1 (4) + z2 (8) + g_a1 (8) + g_emb (2) operand fragments, nt terms each
+// `tail` (nullable): append the hidden-layer fragments the reverse kernels' g_h2 -> g_emb tail multiplies with.
+int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols, int nt, const MlpHidden *tail,
+                     void **dev_out);
 
 struct ConvRegistrar {
   explicit ConvRegistrar(const ConvKernels *k) { register_conv(k); }
@@ -146,6 +165,18 @@ __device__ __forceinline__ float lane_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), K));
 }
 
+// activation value and derivative in one go, hardware exp2 / rcp (~1 ulp each) instead of the IEEE division and
+// libm exp of act_fwd / act_grad (~25 instructions per call): for code that evaluates it per element of a tile
+__device__ __forceinline__ void act_both_fast(float z, int act, float &f, float &g) {
+  if (act == 0) {  // silu: s = sigmoid(z); f = z s; g = s (1 + z (1 - s))
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+    f = z * s;
+    g = s * fmaf(z, 1.0f - s, 1.0f);
+  } else {
+    f = tanhf(z);
+    g = 1.0f - f * f;
+  }
+}
 __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == 0) return z / (1.0f + expf(-z));  // silu
   return tanhf(z);

@@ -660,6 +660,7 @@ struct snet_mlp_plan {
   float *W0 = nullptr, *W1 = nullptr, *W2 = nullptr, *W2T = nullptr;               // fp32 mode
   u32x4 *W1A = nullptr, *W2B = nullptr, *W2A = nullptr, *W1A2 = nullptr, *W0A = nullptr;  // split mode
   std::vector<float> w2_host;  // W2'[64, wn]: source of the fused tensor-product kernels' fragment stream
+  std::vector<float> w0_host, w1_host;  // W0'[nb, 64], W1'[64, 64]: the fused reverse kernels' hidden-layer tail
 };
 
 namespace {
@@ -755,6 +756,8 @@ extern "C" int snet_radial_mlp_plan_create(int32_t nb, int32_t h1, int32_t h2, i
                   }), (void **)&p->W0A);
   }
   p->w2_host = w2;
+  p->w0_host = w0;
+  p->w1_host = w1;
   if (bad) {
     snet::set_error("snet_radial_mlp_plan_create: device allocation / upload failed");
     delete p;
@@ -806,9 +809,17 @@ const float *mlp_plan_w2_host(const snet_mlp_plan *plan) {
   return (plan && !plan->w2_host.empty()) ? plan->w2_host.data() : nullptr;
 }
 
-int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols, int nt, void **dev_out) {
+MlpHidden mlp_plan_hidden(const snet_mlp_plan *plan) {
+  MlpHidden h{nullptr, nullptr, 0, 0, 0.f};
+  if (plan && plan->mode == 1 && !plan->w0_host.empty())
+    h = MlpHidden{plan->w0_host.data(), plan->w1_host.data(), plan->nb, plan->act, plan->cst};
+  return h;
+}
+int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols, int nt, const MlpHidden *tail,
+                     void **dev_out) {
   const int lps = 8 * nt;  // 1-KB lines per sub-step
-  std::vector<uint16_t> out((size_t)n_sub * lps * 64 * 8, 0);
+  const size_t tail_lines = tail ? (size_t)FUSED_TAIL_FRAGS * nt : 0;
+  std::vector<uint16_t> out(((size_t)n_sub * lps + tail_lines) * 64 * 8, 0);
   auto put = [&](size_t line, int lane, int slot, float v, int term) {
     uint16_t sp[3];
     split3(v, sp);
@@ -834,6 +845,35 @@ int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols
           if (c0 < 0) continue;
           for (int term = 0; term < nt; ++term)
             put(base + (size_t)4 * nt + (size_t)m * nt, lane, t, w2[(size_t)(16 * m + i) * wn + c0 + 4 * gg + (t & 3)], term);
+        }
+    }
+  }
+  if (tail) {
+    // Hidden-layer tail of the reverse kernels (nt terms per fragment like the W2 stream).  All four products run in the
+    // transposed layout of the g_h2 accumulators -- [unit 16 m + 4 g + r][edge] -- so the k slot (gg, t) of k-step s
+    // names hidden unit u(s, gg, t) = 16 (2 s + (t >> 2)) + 4 gg + (t & 3): each lane's own accumulator registers.
+    const float *w0 = tail->w0, *w1 = tail->w1;
+    const int nb = tail->nb;
+    const size_t base = (size_t)n_sub * lps;
+    auto unit = [](int s, int gg, int t) { return 16 * (2 * s + (t >> 2)) + 4 * gg + (t & 3); };
+    for (int lane = 0; lane < 64; ++lane) {
+      const int i = lane & 15, gg = lane >> 4;
+      for (int t = 0; t < 8; ++t)
+        for (int term = 0; term < nt; ++term) {
+          for (int m = 0; m < 4; ++m) {
+            // z1^T[16 m + i][edge] = sum_k W0'[k][16 m + i] emb[edge][k], k = 8 gg + t
+            const int k = 8 * gg + t;
+            put(base + (size_t)(0 + m) * nt, lane, t, k < nb ? w0[(size_t)k * H + 16 * m + i] : 0.f, term);
+            for (int s = 0; s < 2; ++s) {
+              const int u = unit(s, gg, t);
+              // z2^T[16 m + i][edge] = sum_u W1'[u][16 m + i] a1[edge][u]
+              put(base + (size_t)(4 + 2 * m + s) * nt, lane, t, w1[(size_t)u * H + 16 * m + i], term);
+              // g_a1^T[16 m + i][edge] = sum_u W1'[16 m + i][u] g_z2[edge][u]
+              put(base + (size_t)(12 + 2 * m + s) * nt, lane, t, w1[(size_t)(16 * m + i) * H + u], term);
+            }
+          }
+          for (int s = 0; s < 2; ++s)  // g_emb^T[k0 = i][edge] = sum_u W0'[i][u] g_z1[edge][u]
+            put(base + (size_t)(20 + s) * nt, lane, t, i < nb ? w0[(size_t)i * H + unit(s, gg, t)] : 0.f, term);
         }
     }
   }

@@ -613,10 +613,12 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     float *g_m = A.f((size_t)N * L.dmid);
     if ((rc = run_linear(m, L.si2, g_y, g_m, N, true, false, st))) return rc;
     float *g_xe = t > 0 ? A.f((size_t)E * L.dx) : nullptr;
-    if (L.fused) {  // g_w is contracted with W2^T inside the kernel: only g_h2[E,64] leaves it
-      float *g_h2 = A.f((size_t)E * 64);
+    if (L.fused) {  // g_w is contracted with W2^T inside the kernel; with the hidden-layer tail not even g_h2 leaves it
+      const bool tail = snet_fused_plan_has_mlp_tail(L.fused) != 0;
+      float *g_h2 = tail ? nullptr : A.f((size_t)E * 64);
       if (E > 0 && (rc = snet_conv_bwd_fused(L.fused, saved[t].h, sh, dsh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src,
-                                             tile_ptr, tile_node, n_tiles, L.conv_scale, g_m, g_xe, g_h2, g_vec, st)))
+                                             tile_ptr, tile_node, n_tiles, L.conv_scale, g_m, g_xe, g_h2,
+                                             tail ? emb : nullptr, tail ? g_emb : nullptr, g_vec, st)))
         return rc;
       if (t > 0) {
         float *g_h = A.f((size_t)NT * L.dx);
@@ -626,14 +628,14 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
             snet::set_error("snet_model_eval: reverse halo callback failed");
             return rc;
           }
-        if ((rc = snet_radial_mlp_hidden_bwd(L.mlp_plan, emb, g_h2, E, g_emb, st))) return rc;
+        if (!tail && (rc = snet_radial_mlp_hidden_bwd(L.mlp_plan, emb, g_h2, E, g_emb, st))) return rc;
         if ((rc = run_linear(m, L.si1, g_h, gx_next, N, true, false, st))) return rc;
         if (L.sc.present())
           if ((rc = run_linear(m, L.sc, g_y, gx_next, N, true, true, st))) return rc;
         std::swap(g_x, gx_next);
         continue;
       }
-      if ((rc = snet_radial_mlp_hidden_bwd(L.mlp_plan, emb, g_h2, E, g_emb, st))) return rc;
+      if (!tail && (rc = snet_radial_mlp_hidden_bwd(L.mlp_plan, emb, g_h2, E, g_emb, st))) return rc;
       break;  // layer-0 inputs depend on species only
     }
     float *g_w = ov ? gw_buf[t & 1] : A.f((size_t)E * L.wn);

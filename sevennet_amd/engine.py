@@ -230,7 +230,8 @@ class HipForceEngine:
     OVERLAP_MAX_EDGES = 1_000_000
 
     def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6',
-                 linear_mode: str = 'bf16x6', fused='auto', fused_terms: int = 2, modal=None, overlap: bool = True):
+                 linear_mode: str = 'bf16x6', fused='auto', fused_terms: int = 2, modal=None, overlap: bool = True,
+                 mlp_tail: bool = True):
         """mlp_mode / linear_mode: 'bf16x6' (split-precision MFMA, fp32-class accuracy, default) or
         'fp32' (exact fp32 MFMA) for the fused radial MLP / the node-level equivariant linears.
         fused: 'auto' (default) / True / False / 'fwd' / 'bwd' -- run the radial MLP's last layer INSIDE the
@@ -327,6 +328,7 @@ class HipForceEngine:
                 _lib.check(self.lib.snet_conv_plan_create(ls.conv.tag.encode(), C.byref(plan)), 'snet_conv_plan_create')
                 L.plan = plan
                 L.fplan = None
+                L.mlp_tail = False
                 can = bool(L.fused_mlp and mlp_mode == 'bf16x6' and self.lib.snet_conv_fused_available(plan))
                 if fused is True and not can:
                     raise RuntimeError(f'layer {ls.t}: no fused tensor-product kernels for this shape / mlp_mode')
@@ -335,6 +337,8 @@ class HipForceEngine:
                     _lib.check(self.lib.snet_fused_plan_create(plan, L.mlp_plan, self.fused_terms, C.byref(fpl)),
                                'snet_fused_plan_create')
                     L.fplan = fpl
+                    # the reverse kernel also reverses the MLP's hidden layers (g_h2 never reaches memory)
+                    L.mlp_tail = bool(self.lib.snet_fused_plan_has_mlp_tail(fpl)) and mlp_tail
                 L.fused_fwd = L.fplan is not None and fused in ('auto', True, 'fwd')
                 L.fused_bwd = L.fplan is not None and fused in ('auto', True, 'bwd')
                 segs = (_lib.GateSeg * len(ls.gate.segs))()
@@ -611,12 +615,14 @@ class HipForceEngine:
                 g_xe = self._new(E, ls.si1.dim_out) if t > 0 else None
                 g_w = g_h2 = None
                 if L.fused_bwd:
-                    g_h2 = self._new(E, 64)
+                    g_h2 = None if L.mlp_tail else self._new(E, 64)
                     with _Span(self, f'conv_bwd_fused[{ls.conv.tag}]'):
                         if E > 0:
                             _lib.check(lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(w_row),
                                                                _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale,
-                                                               _ptr(g_m), _ptr(g_xe), _ptr(g_h2), _ptr(g_vec), st),
+                                                               _ptr(g_m), _ptr(g_xe), _ptr(g_h2),
+                                                               _ptr(emb) if L.mlp_tail else None, _ptr(g_emb) if L.mlp_tail else None,
+                                                               _ptr(g_vec), st),
                                        'snet_conv_bwd_fused')
                 else:
                     if side is not None:  # double-buffered: the MLP reverse of layer t+2 may still be reading this one
@@ -644,7 +650,9 @@ class HipForceEngine:
                                 pending = halo.reverse_start(g_h, N)
                             else:
                                 halo.reverse(g_h, N)
-                if L.fused_bwd:
+                if L.fused_bwd and L.mlp_tail:
+                    pass
+                elif L.fused_bwd:
                     with _Span(self, 'radial_mlp_hidden_bwd'):
                         _lib.check(lib.snet_radial_mlp_hidden_bwd(L.mlp_plan, _ptr(emb), _ptr(g_h2), E, _ptr(g_emb), st),
                                    'snet_radial_mlp_hidden_bwd')

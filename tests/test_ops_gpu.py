@@ -332,15 +332,28 @@ def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms):
     g_h2 = torch.full((E, 64), float('nan'), device=dev)
     g_vec = torch.ones(E, 3, device=dev)
     L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), _p(tile_node),
-                                    n_tiles.value, scale, _p(g_out), _p(g_xe), _p(g_h2), _p(g_vec), None))
+                                    n_tiles.value, scale, _p(g_out), _p(g_xe), _p(g_h2), None, None, _p(g_vec), None))
     g_emb = torch.ones(E, nb, device=dev)
     L.check(lib.snet_radial_mlp_hidden_bwd(mlp, _p(emb_e), _p(g_h2), E, _p(g_emb), None))
+    # ... and with the MLP's hidden layers reversed inside the same kernel (g_h2 never written)
+    assert lib.snet_fused_plan_has_mlp_tail(fplan) == 1
+    g_emb_t = torch.ones(E, nb, device=dev)
+    g_xe_t = torch.full((E, dx), float('nan'), device=dev)
+    g_vec_t = torch.ones(E, 3, device=dev)
+    L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), _p(tile_node),
+                                    n_tiles.value, scale, _p(g_out), _p(g_xe_t), None, _p(emb_e), _p(g_emb_t), _p(g_vec_t), None))
+    with pytest.raises(RuntimeError):  # exactly one of g_h2 / g_emb
+        L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), _p(tile_node),
+                                        n_tiles.value, scale, _p(g_out), _p(g_xe_t), _p(g_h2), _p(emb_e), _p(g_emb_t), _p(g_vec_t), None))
     torch.cuda.synchronize()
     a1 = torch.nn.functional.silu(c['emb'].double() @ c['W0'].double()) * cst
     a2 = torch.nn.functional.silu(a1 @ c['W1'].double()) * cst
     assert (h2.cpu().double() - a2).abs().max() < 5e-6 * a2.abs().max()
-    for t in (out, g_xe, g_h2, g_vec, g_emb):
+    for t in (out, g_xe, g_h2, g_vec, g_emb, g_emb_t):
         assert not torch.isnan(t).any()
+    assert torch.equal(g_xe_t, g_xe) and torch.equal(g_vec_t, g_vec)
+    # the tail multiplies in the kernel's own precision class (`terms`), the separate hidden-layer kernel in bf16x6
+    assert (g_emb_t - g_emb).abs().max().item() <= {3: 2e-6, 2: 1e-4, 1: 4e-2}[terms] * max(1.0, g_emb.abs().max().item())
     tol = {3: 2e-5, 2: 1e-4, 1: 4e-2}[terms]
     # g_h2 against the fp64 contraction of the separate kernel's g_w with W2^T
     g_h2_ref = g_w.double().cpu() @ c['W2'].double().T
@@ -353,7 +366,7 @@ def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms):
     g_h2b = torch.empty_like(g_h2)
     g_vecb = torch.ones(E, 3, device=dev)
     L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), _p(tile_node),
-                                    n_tiles.value, scale, _p(g_out), None, _p(g_h2b), _p(g_vecb), None))
+                                    n_tiles.value, scale, _p(g_out), None, _p(g_h2b), None, None, _p(g_vecb), None))
     torch.cuda.synchronize()
     assert torch.equal(g_h2, g_h2b) and torch.equal(g_vec, g_vecb)
     lib.snet_fused_plan_destroy(fplan)

@@ -91,8 +91,8 @@ def main():
     ops = {
         'radial_mlp_hidden_fwd': lambda: lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb), E, _ptr(h2), st),
         f'conv_fwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_fwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
-        f'conv_bwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), _ptr(g_xe), _ptr(g_h2), _ptr(g_vec), st),
-        f'conv_bwd_fused_no_gxe[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), None, _ptr(g_h2), _ptr(g_vec), st),
+        f'conv_bwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), _ptr(g_xe), _ptr(g_h2), None, None, _ptr(g_vec), st),
+        f'conv_bwd_fused_no_gxe[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), None, _ptr(g_h2), None, None, _ptr(g_vec), st),
         'radial_mlp_hidden_bwd': lambda: lib.snet_radial_mlp_hidden_bwd(L.mlp_plan, _ptr(emb), _ptr(g_h2), E, _ptr(g_emb), st),
         f'radial_mlp_fwd[wn={wn}]': lambda: eng._mlp_fwd(L, emb, E),
         f'conv_fwd[{ls.conv.tag}]': lambda: lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), None, _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
