@@ -293,22 +293,49 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A('      __builtin_amdgcn_sched_barrier(0);')
             A('      const u32x4 *sl = slab[buf];')
             A('      f32x4 gw0 = f32x4{0.f, 0.f, 0.f, 0.f}, gw1 = gw0;')
+            # kernel-tuning knobs, both measured neutral on MI355X (SevenNet-0 middle layer): wfirst = both tiles' weight
+            # products before the first tensor-product body (6.38 vs 6.26 ms); gpf = the g-part fragments requested
+            # before the tensor-product bodies (+30 VGPRs: only fits two waves per SIMD, 6.72 vs 6.73 ms at three)
+            wfirst, gpf = bool(OPTS.get('wfirst')), bool(OPTS.get('gpf'))
+            if wfirst:
+                for tp, pi in enumerate((pa, pb)):
+                    if pi is None:
+                        continue
+                    A(f'      f32x4 wv{tp} = f32x4{{0.f, 0.f, 0.f, 0.f}};')
+                    A('#pragma unroll')
+                    A('      for (int q = 0; q < 2; ++q) {')
+                    A('        bf16x8 a[NT];')
+                    A('#pragma unroll')
+                    A(f'        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
+                    A(f'        wv{tp} = mfma16_split<NT>(a, hb[q], wv{tp});')
+                    A('      }')
+            if gpf:
+                A('      bf16x8 ag[4][NT];')
+                A('#pragma unroll')
+                A('      for (int m = 0; m < 4; ++m)')
+                A('#pragma unroll')
+                A('        for (int tm = 0; tm < NT; ++tm) ag[m][tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
+            if wfirst or gpf:
+                A('      __builtin_amdgcn_sched_barrier(0);')
             for tp, pi in enumerate((pa, pb)):
                 if pi is None:
                     continue
                 p = spec.paths[pi]
                 d3 = 2 * p.l3 + 1
                 A(f'      {{  // tile {tp}: path {pi}')
-                A('        f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
-                if exp:
-                    A('        if (diag & 4) wv = f32x4{yl[0], yl[16], yl[32], yl[48]}; else')
-                A('#pragma unroll')
-                A('        for (int q = 0; q < 2; ++q) {')
-                A('          bf16x8 a[NT];')
-                A('#pragma unroll')
-                A(f'          for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
-                A('          wv = mfma16_split<NT>(a, hb[q], wv);')
-                A('        }')
+                if wfirst:
+                    A(f'        const f32x4 wv = wv{tp};')
+                else:
+                    A('        f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
+                    if exp:
+                        A('        if (diag & 4) wv = f32x4{yl[0], yl[16], yl[32], yl[48]}; else')
+                    A('#pragma unroll')
+                    A('        for (int q = 0; q < 2; ++q) {')
+                    A('          bf16x8 a[NT];')
+                    A('#pragma unroll')
+                    A(f'          for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
+                    A('          wv = mfma16_split<NT>(a, hb[q], wv);')
+                    A('        }')
                 A(f'        f32x4 G[{d3}];')
                 for m3 in range(d3):
                     A(f'        G[{m3}] = *reinterpret_cast<const f32x4 *>(gl_ + {g_row(ci, pi, m3)} * 16);')
@@ -327,10 +354,13 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A('      if (diag & 2) ga[0] += f32x4{v[0], v[1], v[4], v[5]}; else')
             A('#pragma unroll')
             A('      for (int m = 0; m < 4; ++m) {')
-            A('        bf16x8 a[NT];')
-            A('#pragma unroll')
-            A('        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
-            A('        ga[m] = mfma16_split<NT>(a, b, ga[m]);')
+            if gpf:
+                A('        ga[m] = mfma16_split<NT>(ag[m], b, ga[m]);')
+            else:
+                A('        bf16x8 a[NT];')
+                A('#pragma unroll')
+                A('        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
+                A('        ga[m] = mfma16_split<NT>(a, b, ga[m]);')
             A('      }')
             A('      if (sidx + 1 < NS' + (' && !(diag & 32)' if exp else '') + ') stage_store(buf ^ 1);')
             A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')

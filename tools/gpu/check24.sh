@@ -1,0 +1,33 @@
+#!/bin/bash
+# SQ-level counters of the fused reverse / forward kernels (one --pmc pass per group; kernel trace only)
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out/g24
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_[A-Z_0-9]*" | sort -u > $OUT/sq_counters.txt
+CMD="python $ROOT/tools/microbench.py --terms 2 --iters 2 --only fused"
+i=0
+for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" \
+           "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "SQ_INSTS_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_SCA SQ_INSTS_SALU" \
+           "SQ_WAVES_EQ_64 SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o r -- $CMD > $OUT/p$i.log 2>&1
+  f=$(find $OUT/p$i -name "*counter_collection.csv" | head -1)
+  if [ -n "$f" ]; then
+    python - "$f" <<'PY' | tee -a $OUT/summary.txt
+import csv, sys, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r['Kernel_Name']
+    if 'conv_bwdf' in k or 'conv_fwdf' in k:
+        acc[k[:40]][r['Counter_Name']].append(float(r['Counter_Value']))
+for k, d in acc.items():
+    print(k, {c: sum(v) / len(v) for c, v in d.items()})
+PY
+  else
+    echo "group $i: no counter file"; tail -3 $OUT/p$i.log
+  fi
+  rm -rf $OUT/p$i
+done
