@@ -84,7 +84,7 @@ def species_of(cfg, n_atoms):
     return np.random.default_rng(4).choice(np.array([3, 8, 14, 22]), size=n_atoms).astype(np.int64)
 
 
-def kernel_model(ls, n_nodes, n_edges):
+def kernel_model(ls, n_nodes, n_edges, mlp_tail=False, nb=8):
     """Algorithmic bytes / flops per launch of each kernel class of one layer
     (SURVEY.md §8(d) conventions: dst rows once per node, src rows once per edge,
     radial weights NOT counted for the tensor-product kernels, no cache credit)."""
@@ -92,14 +92,17 @@ def kernel_model(ls, n_nodes, n_edges):
     nsh = ls.conv.irreps_sh.dim
     h = ls.mlp_dims
     mlp_flops = 2.0 * n_edges * sum(h[i] * h[i + 1] for i in range(len(h) - 1))
+    # reverse kernel with the MLP's hidden layers reversed inside: h2 in, emb in, g_emb read + written (no g_h2)
+    bwd_mlp_bytes = (256 + 3 * 4 * nb) if mlp_tail else 512
+    bwd_tail_flops = 2.0 * n_edges * (2 * nb * 64 + 2 * 64 * 64) if mlp_tail else 0.0
     return {
         f'conv_fwd[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 4 * nsh + 8) + n_nodes * 4 * dmid),
         # fused kernels: w = h2 @ W2 and g_h2 = g_w @ W2^T run inside (bf16 x terms products on the matrix cores);
         # per edge they move the source row, Y (+ its Jacobian), src / w_row, h2[64] (+ g_xe, g_h2, g_vec on the way back)
         f'conv_fwd_fused[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 4 * nsh + 8 + 256) + n_nodes * 4 * dmid,
                                                flops=2.0 * n_edges * 64 * wn),
-        f'conv_bwd_fused[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (2 * 4 * dx + 4 * 4 * nsh + 8 + 512 + 24) + n_nodes * 4 * dmid,
-                                               flops=2.0 * 2.0 * n_edges * 64 * wn),
+        f'conv_bwd_fused[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (2 * 4 * dx + 4 * 4 * nsh + 8 + bwd_mlp_bytes + 24) + n_nodes * 4 * dmid,
+                                               flops=2.0 * 2.0 * n_edges * 64 * wn + bwd_tail_flops),
         f'conv_bwd_edge[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 2 * 4 * nsh + 8) + n_nodes * 4 * dmid),
         f'conv_bwd_node[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dmid + 4 * nsh + 12) + n_nodes * 4 * dx),
         f'radial_mlp_fwd[wn={wn}]': dict(bound='mfma', flops=mlp_flops),
@@ -257,8 +260,8 @@ def main():
     for name, t in eng.kernel_times_ms().items():
         probe[name] = float(np.sum(t))
     models0 = {}
-    for ls in eng.spec.layers:
-        models0.update(kernel_model(ls, graph.n_local, graph.n_edges))
+    for ls, L in zip(eng.spec.layers, eng.layers):
+        models0.update(kernel_model(ls, graph.n_local, graph.n_edges, getattr(L, 'mlp_tail', False), eng.spec.n_basis))
     dominant0 = max((k for k in probe if k in models0), key=lambda k: probe[k])
     eng.events, eng.event_filter = [], {dominant0}
     t0 = time.perf_counter()
@@ -284,8 +287,8 @@ def main():
     totals = {k: float(np.sum(v)) for k, v in times.items()}
     counts = {k: len(v) for k, v in times.items()}
     models = {}
-    for ls in eng.spec.layers:
-        models.update(kernel_model(ls, graph.n_local, graph.n_edges))
+    for ls, L in zip(eng.spec.layers, eng.layers):
+        models.update(kernel_model(ls, graph.n_local, graph.n_edges, getattr(L, 'mlp_tail', False), eng.spec.n_basis))
     # classes tagged '@side' ran on the second stream, overlapped with main-stream kernels: their event brackets
     # are not exclusive time, so the dominant class is chosen among the main-stream ones
     dominant = dominant0
