@@ -769,6 +769,11 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         # VGPRs) beat two; when the slab does not leave room for three, two 4-wave workgroups at 256 VGPRs
         if 'fnwv' in OPTS:
             return def_b
+        # first interaction layer (scalar inputs only, one x block): one 8-wave workgroup sharing each slab beats three
+        # 4-wave ones (in the step: 1.76 vs 2.01 ms).  NOT the last layer's shape (three one-path x blocks): 8 waves
+        # win its stand-alone timing (3.21 vs 3.46 ms) but lose inside the step with the hidden-layer tail (4.04 vs 3.53)
+        if len(cats) == 1 and bwd_lds(nt, 8) <= 80 * 1024:
+            return (8, 0, 2)
         if bwd_lds(nt, 4) <= 53 * 1024:
             return (4, 0, 3)
         if bwd_lds(nt, 4) <= 80 * 1024:
@@ -808,6 +813,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         # global->LDS staging) where the LDS and the register count of this nt allow it, 8 or 4 waves otherwise
         if 'fnwvf' in OPTS:
             return def_f
+        if len(cats) == 1 and fwd_lds(nt, 8) <= 80 * 1024:   # first layer (scalar inputs only): 0.87 vs 1.03 ms
+            return (8, 1, 2)
         if nt <= 2 and fwd_lds(nt, 12) <= 160 * 1024:
             return (12, 1, 3)
         for w in (8, 4, 2, 1):
