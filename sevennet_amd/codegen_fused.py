@@ -636,14 +636,21 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A(f'    stage_store({first_n}, 0);')
     A('    __syncthreads();  // also orders the wave\'s s_ys stores before its reads')
     A('    int sidx = 0, buf = 0;')
+    A(f'    f32x4 xq[{MAXD1}];  // the next stage\'s slice, in flight: lane L holds channels 4 (L & 3) .. + 3 of edge L >> 2')
+
+    def emit_x_loads(ind, ci_, ct_expr, tl_):
+        cat_ = cats[ci_]
+        A(f'{ind}{{ const float *xs_ = x + {cat_.x_off} + 16 * ({ct_expr}) + 4 * (lane & 3) + (size_t)srs[{tl_}] * DX;')
+        for m in range(2 * cat_.l1 + 1):
+            A(f'{ind}  xq[{m}] = *reinterpret_cast<const f32x4 *>(xs_ + {m * cat_.mul});')
+        A(f'{ind}}}')
+    emit_x_loads('    ', 0, '0', 0)
     for ci, cat in enumerate(cats):
         d1 = 2 * cat.l1 + 1
         nct = cat.mul // 16
         npairs = len(pairs_of[ci])
         A(f'    // ---- x block {cat.i_x}: {cat.mul}x l={cat.l1}, {len(cat.paths)} paths')
         A(f'    for (int ct = 0; ct < {nct}; ++ct) {{')
-        # staged slice: lane L holds channels 4 (L & 3) .. + 3 of edge L >> 2
-        A(f'      const float *xb = x + {cat.x_off} + 16 * ct + 4 * (lane & 3);')
         for gi, grp in enumerate(fgroups[ci]):
             n_here = len(grp)
             # what the next block is (for the slab prefetch): next group of this ct, next ct, or the next x block
@@ -656,8 +663,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             ol = olists[(ci, gi)]
             A('      {')
             A(f'        const int n_next = (sidx + {n_here} < NS) ? {nxt} : 0;')
-            A(f'        if (n_next) stage_load(sidx + {n_here}, n_next, buf ^ 1);')
-            A('        __builtin_amdgcn_sched_barrier(0);  // the scheduler would sink the prefetch next to its use')
             A('        const u32x4 *sl = slab[buf];')
             for _, pr in grp:
                 for pi in pr:
@@ -665,45 +670,68 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                         A(f'        float acc{pi}[{2 * spec.paths[pi].l3 + 1}];')
                         A('#pragma unroll')
                         A(f'        for (int i = 0; i < {2 * spec.paths[pi].l3 + 1}; ++i) acc{pi}[i] = 0.f;')
-            A('#pragma unroll')
-            A('        for (int tl = 0; tl < 2; ++tl) {')
-            A('          if (tl == 0 || two) {')
-            A('            {  // stage the 16 source rows\' slice: [m][r][g][channel], conflict-free for the reads below')
-            A('              const float *xs = xb + (size_t)srs[tl] * DX;')
-            A(f'              f32x4 xv[{d1}];')
-            for m in range(d1):
-                A(f'              xv[{m}] = *reinterpret_cast<const f32x4 *>(xs + {m * cat.mul});')
-            A('              __builtin_amdgcn_wave_barrier();  // every read of the previous tile\'s slice has been issued')
-            A('              float *xw = &s_x[wave][(((lane >> 2) & 3) * 4 + (lane >> 4)) * 16 + 4 * (lane & 3)];')
-            for m in range(d1):
-                A(f'              *reinterpret_cast<f32x4 *>(xw + {m * 256}) = xv[{m}];')
-            A('              __builtin_amdgcn_wave_barrier();')
-            A('            }')
-            A(f'            float xr[4][{d1}];')
-            A('#pragma unroll')
-            A('            for (int r = 0; r < 4; ++r)')
-            A('#pragma unroll')
-            A(f'              for (int m = 0; m < {d1}; ++m) xr[r][m] = s_x[wave][m * 256 + r * 64 + lane];')
-            A('            const float *ysl = &s_ys[wave][(16 * tl + 4 * g) * NSH];')
-            for ls, pr in grp:
-                for tp, pi in enumerate(pr):
-                    if pi is None:
-                        continue
-                    A(f'            {{  // sub-step {ls} of the block, tile {tp}: path {pi}')
-                    A('              f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
-                    A('#pragma unroll')
-                    A('              for (int q = 0; q < 2; ++q) {')
-                    A('                bf16x8 bfr[NT];')
-                    A('#pragma unroll')
-                    A(f'                for (int tm = 0; tm < NT; ++tm) bfr[tm] = as_bf16x8(sl[(({ls - grp[0][0]} * 4 + {tp} * 2 + q) * NT + tm) * 64 + lane]);')
-                    A('                wv = mfma16_split<NT>(ha[tl][q], bfr, wv);')
-                    A('              }')
-                    A('#pragma unroll')
-                    A('              for (int r = 0; r < 4; ++r) wv[r] = (16 * tl + 4 * g + r < n_e) ? wv[r] : 0.f;')
-                    A(f'              if (!(diag & 1)) fwdf_p{pi}(xr, ysl, wv, acc{pi});  // opaque branch: see the reverse kernel')
+            # The 16 source rows' slice of a tile reaches LDS through registers that were loaded ONE STAGE AHEAD (stage =
+            # (block, tile)): without the prefetch every stage exposed a full gather latency -- the waves of this kernel
+            # spent 50 % of their cycles in s_waitcnt (SQ_WAIT_ANY, profiles/r02_pmc_sq_fused_kernels.txt).
+            def emit_next_block_loads(ind):
+                if gi + 1 < len(fgroups[ci]):
+                    emit_x_loads(ind, ci, 'ct', 0)        # the next group of this (x block, channel tile): same slice
+                    return
+                has_next_cat = ci + 1 < len(cats)
+                if nct > 1:
+                    A(f'{ind}if (ct + 1 < {nct}) {{')
+                    emit_x_loads(ind + '  ', ci, 'ct + 1', 0)
+                    A(f'{ind}}}' + (' else {' if has_next_cat else ''))
+                    if has_next_cat:
+                        emit_x_loads(ind + '  ', ci + 1, '0', 0)
+                        A(f'{ind}}}')
+                elif has_next_cat:
+                    emit_x_loads(ind, ci + 1, '0', 0)
+            for tl in range(2):
+                A(f'        if ({"true" if tl == 0 else "two"}) {{  // tile {tl}')
+                A('          {  // stage the 16 source rows\' slice: [m][r][g][channel], conflict-free for the reads below')
+                A('            __builtin_amdgcn_wave_barrier();  // every read of the previous tile\'s slice has been issued')
+                A('            float *xw = &s_x[wave][(((lane >> 2) & 3) * 4 + (lane >> 4)) * 16 + 4 * (lane & 3)];')
+                for m in range(d1):
+                    A(f'            *reinterpret_cast<f32x4 *>(xw + {m * 256}) = xq[{m}];')
+                if tl == 0:
+                    A('            if (two) {')
+                    emit_x_loads('              ', ci, 'ct', 1)
+                    A('            } else {')
+                    emit_next_block_loads('              ')
                     A('            }')
-            A('          }')
-            A('        }')
+                    # the next block's weight fragments are requested AFTER the slice prefetch: vmcnt retires in order,
+                    # and the wait in front of the next slice store must not also wait for a slab that was just requested
+                    A(f'            if (n_next) stage_load(sidx + {n_here}, n_next, buf ^ 1);')
+                else:
+                    emit_next_block_loads('            ')
+                A('            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch up here')
+                A('            __builtin_amdgcn_wave_barrier();')
+                A('          }')
+                A(f'          float xr[4][{d1}];')
+                A('#pragma unroll')
+                A('          for (int r = 0; r < 4; ++r)')
+                A('#pragma unroll')
+                A(f'            for (int m = 0; m < {d1}; ++m) xr[r][m] = s_x[wave][m * 256 + r * 64 + lane];')
+                A(f'          const float *ysl = &s_ys[wave][(16 * {tl} + 4 * g) * NSH];')
+                for ls, pr in grp:
+                    for tp, pi in enumerate(pr):
+                        if pi is None:
+                            continue
+                        A(f'          {{  // sub-step {ls} of the block, tile {tp}: path {pi}')
+                        A('            f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
+                        A('#pragma unroll')
+                        A('            for (int q = 0; q < 2; ++q) {')
+                        A('              bf16x8 bfr[NT];')
+                        A('#pragma unroll')
+                        A(f'              for (int tm = 0; tm < NT; ++tm) bfr[tm] = as_bf16x8(sl[(({ls - grp[0][0]} * 4 + {tp} * 2 + q) * NT + tm) * 64 + lane]);')
+                        A(f'              wv = mfma16_split<NT>(ha[{tl}][q], bfr, wv);')
+                        A('            }')
+                        A('#pragma unroll')
+                        A(f'            for (int r = 0; r < 4; ++r) wv[r] = (16 * {tl} + 4 * g + r < n_e) ? wv[r] : 0.f;')
+                        A(f'            if (!(diag & 1)) fwdf_p{pi}(xr, ysl, wv, acc{pi});  // opaque branch: see the reverse kernel')
+                        A('          }')
+                A('        }')
             # reduce over the 4 edge groups, park in LDS, write out with 16-byte stores
             for q, (pi, m3) in enumerate(ol):
                 A(f'        acc{pi}[{m3}] = snet::swap_add16(acc{pi}[{m3}], acc{pi}[{m3}]);')
