@@ -714,12 +714,44 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A('#pragma unroll')
                 A(f'            for (int m = 0; m < {d1}; ++m) xr[r][m] = s_x[wave][m * 256 + r * 64 + lane];')
                 A(f'          const float *ysl = &s_ys[wave][(16 * {tl} + 4 * g) * NSH];')
-                for ls, pr in grp:
-                    for tp, pi in enumerate(pr):
-                        if pi is None:
-                            continue
-                        A(f'          {{  // sub-step {ls} of the block, tile {tp}: path {pi}')
-                        A('            f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
+                # kernel-tuning knob, measured neutral (7.83 / 7.94 vs 7.75 ms per step over the three middle layers): weight
+                # fragments of a path tile requested one path tile ahead (fpf: 1 = its first k-step, 2 = both), so that the
+                # LDS latency in front of each chain of matrix products overlaps the previous tensor-product body
+                fpf = int(OPTS.get('fpf', 0))
+                chain = [(ls, tp, pi) for ls, pr in grp for tp, pi in enumerate(pr) if pi is not None]
+
+                def frag_reads(ind, k, q, dst):
+                    ls_, tp_, _ = chain[k]
+                    A(f'{ind}for (int tm = 0; tm < NT; ++tm) {dst}[tm] = as_bf16x8(sl[(({ls_ - grp[0][0]} * 4 + {tp_} * 2 + {q}) * NT + tm) * 64 + lane]);')
+                if fpf:
+                    A('          bf16x8 bn0[NT]' + (', bn1[NT]' if fpf > 1 else '') + ';')
+                    A('#pragma unroll')
+                    frag_reads('          ', 0, 0, 'bn0')
+                    if fpf > 1:
+                        A('#pragma unroll')
+                        frag_reads('          ', 0, 1, 'bn1')
+                for k, (ls, tp, pi) in enumerate(chain):
+                    A(f'          {{  // sub-step {ls} of the block, tile {tp}: path {pi}')
+                    A('            f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
+                    if fpf:
+                        A('            bf16x8 b0[NT], b1[NT];')
+                        A('#pragma unroll')
+                        A('            for (int tm = 0; tm < NT; ++tm) b0[tm] = bn0[tm];')
+                        A('#pragma unroll')
+                        if fpf > 1:
+                            A('            for (int tm = 0; tm < NT; ++tm) b1[tm] = bn1[tm];')
+                        else:
+                            frag_reads('            ', k, 1, 'b1')
+                        A(f'            wv = mfma16_split<NT>(ha[{tl}][0], b0, wv);')
+                        A(f'            wv = mfma16_split<NT>(ha[{tl}][1], b1, wv);')
+                        if k + 1 < len(chain):
+                            A('#pragma unroll')
+                            frag_reads('            ', k + 1, 0, 'bn0')
+                            if fpf > 1:
+                                A('#pragma unroll')
+                                frag_reads('            ', k + 1, 1, 'bn1')
+                        A('            __builtin_amdgcn_sched_barrier(0);')
+                    else:
                         A('#pragma unroll')
                         A('            for (int q = 0; q < 2; ++q) {')
                         A('              bf16x8 bfr[NT];')
@@ -727,10 +759,10 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                         A(f'              for (int tm = 0; tm < NT; ++tm) bfr[tm] = as_bf16x8(sl[(({ls - grp[0][0]} * 4 + {tp} * 2 + q) * NT + tm) * 64 + lane]);')
                         A(f'              wv = mfma16_split<NT>(ha[{tl}][q], bfr, wv);')
                         A('            }')
-                        A('#pragma unroll')
-                        A(f'            for (int r = 0; r < 4; ++r) wv[r] = (16 * {tl} + 4 * g + r < n_e) ? wv[r] : 0.f;')
-                        A(f'            if (!(diag & 1)) fwdf_p{pi}(xr, ysl, wv, acc{pi});  // opaque branch: see the reverse kernel')
-                        A('          }')
+                    A('#pragma unroll')
+                    A(f'            for (int r = 0; r < 4; ++r) wv[r] = (16 * {tl} + 4 * g + r < n_e) ? wv[r] : 0.f;')
+                    A(f'            if (!(diag & 1)) fwdf_p{pi}(xr, ysl, wv, acc{pi});  // opaque branch: see the reverse kernel')
+                    A('          }')
                 A('        }')
             # reduce over the 4 edge groups, park in LDS, write out with 16-byte stores
             for q, (pi, m3) in enumerate(ol):
