@@ -348,6 +348,16 @@ int64_t snet_halo_send_rows(const snet_halo *halo);
 int snet_halo_forward(void *halo, float *x, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
 int snet_halo_reverse(void *halo, float *gx, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
 int snet_model_set_rccl_halo(snet_model *model, snet_halo *halo, int32_t fold_forces);
+/* In-process stand-in for the RCCL communicator -- TEST infrastructure for one GPU: W host threads play W ranks; a
+ * send posts {device pointer, ready event}, the matching receive copies device to device on the receiver's stream
+ * and acknowledges with an event the sender's stream waits on (ncclSend / ncclRecv inside one ncclGroup: FIFO per
+ * ordered pair, the group end blocks until the peers arrived).  A communicator made by snet_loopback_comm_create is
+ * accepted wherever one from snet_rccl_comm_create is (snet_halo_create ...; not the all-reduce) and is destroyed with
+ * snet_rccl_comm_destroy; everything above the transport is the code the RCCL path runs.                          */
+int snet_loopback_hub_create(int32_t world, void **hub);
+void snet_loopback_hub_abort(void *hub);
+void snet_loopback_hub_destroy(void *hub);
+int snet_loopback_comm_create(void *hub, int32_t rank, void **comm);
 
 /* One energy/force evaluation.  Device inputs: types[n_total] species index, row_ptr[n_local+1] /
  * src[E] edges sorted by center (CSR), col_ptr[n_total+1] / eperm[E] the same edges grouped by source,

@@ -116,6 +116,10 @@ SIGNATURES = {
     'snet_rccl_comm_create': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     'snet_rccl_comm_destroy': (None, [C.c_void_p]),
     'snet_rccl_allreduce_sum_f64': (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_stream]),
+    'snet_loopback_hub_create': (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
+    'snet_loopback_hub_abort': (None, [C.c_void_p]),
+    'snet_loopback_hub_destroy': (None, [C.c_void_p]),
+    'snet_loopback_comm_create': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     'snet_halo_create': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     'snet_halo_destroy': (None, [C.c_void_p]),
     'snet_halo_ghost_rows': (C.c_int64, [C.c_void_p]),

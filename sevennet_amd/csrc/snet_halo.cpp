@@ -18,7 +18,10 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -86,6 +89,136 @@ int fail(const char *what, int rc) {
   return 1;
 }
 
+// ---- transport: RCCL, or an in-process stand-in with the same group semantics ---------------------------------
+// The in-process ("loopback") transport exists for tests on ONE GPU: W host threads play W ranks, a send posts
+// {device pointer, ready event} into a mailbox, the matching receive copies device-to-device on the receiver's stream
+// and acknowledges with an event the sender's stream then waits on -- i.e. ncclSend / ncclRecv inside one ncclGroup
+// (FIFO per ordered pair, group end blocks until every peer arrived).  Everything above the transport -- the pack /
+// land / permute / reverse-accumulate plan, its offsets for several peers -- is the code the RCCL path runs.
+struct LoopMsg {
+  const void *ptr;
+  size_t bytes;
+  hipEvent_t ready;
+};
+struct LoopHub {
+  int world = 1;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::deque<LoopMsg>> box;      // [src * world + dst]
+  std::vector<std::deque<hipEvent_t>> ack;   // [src * world + dst]: "dst has copied src's message"
+  bool aborted = false;
+};
+struct CommBox {  // what the C-ABI's opaque communicator pointer points to
+  int kind = 0;   // 0: RCCL, 1: loopback
+  Comm nccl = nullptr;
+  LoopHub *hub = nullptr;
+  int world = 1, rank = 0;
+  struct Pending {
+    void *dst;
+    size_t bytes;
+    int peer;
+    hipStream_t st;
+    bool is_send;
+  };
+  std::vector<Pending> pending;  // loopback: the operations of the open group
+};
+
+int x_group_start(CommBox *c) {
+  if (c->kind == 0) {
+    const int rc = rccl()->GroupStart();
+    return rc ? fail("ncclGroupStart", rc) : 0;
+  }
+  c->pending.clear();
+  return 0;
+}
+int x_send(CommBox *c, const float *buf, size_t count, int peer, hipStream_t st) {
+  if (c->kind == 0) {
+    const int rc = rccl()->Send(buf, count, kFloat, peer, c->nccl, st);
+    return rc ? fail("ncclSend", rc) : 0;
+  }
+  LoopMsg m{buf, count * sizeof(float), nullptr};
+  if (hipEventCreateWithFlags(&m.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(m.ready, st) != hipSuccess) {
+    snet::set_error("loopback send: event creation failed");
+    return 1;
+  }
+  {
+    std::lock_guard<std::mutex> lk(c->hub->mu);
+    c->hub->box[(size_t)c->rank * c->world + peer].push_back(m);
+  }
+  c->hub->cv.notify_all();
+  c->pending.push_back({nullptr, 0, peer, st, true});
+  return 0;
+}
+int x_recv(CommBox *c, float *buf, size_t count, int peer, hipStream_t st) {
+  if (c->kind == 0) {
+    const int rc = rccl()->Recv(buf, count, kFloat, peer, c->nccl, st);
+    return rc ? fail("ncclRecv", rc) : 0;
+  }
+  c->pending.push_back({buf, count * sizeof(float), peer, st, false});
+  return 0;
+}
+int x_group_end(CommBox *c) {
+  if (c->kind == 0) {
+    const int rc = rccl()->GroupEnd();
+    return rc ? fail("ncclGroupEnd", rc) : 0;
+  }
+  LoopHub *h = c->hub;
+  for (const auto &p : c->pending) {  // receives first: nobody waits for an acknowledgement before having copied
+    if (p.is_send) continue;
+    LoopMsg m;
+    {
+      std::unique_lock<std::mutex> lk(h->mu);
+      auto &q = h->box[(size_t)p.peer * c->world + c->rank];
+      h->cv.wait(lk, [&] { return !q.empty() || h->aborted; });
+      if (h->aborted) {
+        snet::set_error("loopback transport aborted");
+        return 1;
+      }
+      m = q.front();
+      q.pop_front();
+    }
+    hipEvent_t done = nullptr;
+    bool ok = m.bytes == p.bytes;
+    ok = ok && hipStreamWaitEvent(p.st, m.ready, 0) == hipSuccess;
+    ok = ok && (p.bytes == 0 || hipMemcpyAsync(p.dst, m.ptr, p.bytes, hipMemcpyDeviceToDevice, p.st) == hipSuccess);
+    ok = ok && hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess && hipEventRecord(done, p.st) == hipSuccess;
+    (void)hipEventDestroy(m.ready);
+    {
+      std::lock_guard<std::mutex> lk(h->mu);
+      if (!ok) h->aborted = true;
+      else h->ack[(size_t)p.peer * c->world + c->rank].push_back(done);
+    }
+    h->cv.notify_all();
+    if (!ok) {
+      snet::set_error("loopback receive: size mismatch between the two ends of an exchange, or a HIP call failed");
+      return 1;
+    }
+  }
+  for (const auto &p : c->pending) {  // a send is complete (its buffer reusable) once the peer's copy is ordered before us
+    if (!p.is_send) continue;
+    hipEvent_t done;
+    {
+      std::unique_lock<std::mutex> lk(h->mu);
+      auto &q = h->ack[(size_t)c->rank * c->world + p.peer];
+      h->cv.wait(lk, [&] { return !q.empty() || h->aborted; });
+      if (h->aborted) {
+        snet::set_error("loopback transport aborted");
+        return 1;
+      }
+      done = q.front();
+      q.pop_front();
+    }
+    const bool ok = hipStreamWaitEvent(p.st, done, 0) == hipSuccess;
+    (void)hipEventDestroy(done);
+    if (!ok) {
+      snet::set_error("loopback send: hipStreamWaitEvent failed");
+      return 1;
+    }
+  }
+  c->pending.clear();
+  return 0;
+}
+
 template <class T>
 struct Dev {
   T *p = nullptr;
@@ -111,8 +244,7 @@ struct Dev {
 }  // namespace
 
 struct snet_halo {
-  Comm comm = nullptr;
-  bool own_comm = false;
+  CommBox *comm = nullptr;
   int world = 1, rank = 0;
   std::vector<int64_t> send_cnt, recv_cnt, send_off, recv_off;  // rows per peer and their prefix sums
   int64_t n_send = 0, n_ghost = 0, n_seg = 0;
@@ -145,29 +277,74 @@ int snet_rccl_comm_create(const void *id128, int32_t world, int32_t rank, void *
   Comm c = nullptr;
   const int rc = r->CommInitRank(&c, world, id, rank);
   if (rc) return fail("ncclCommInitRank", rc);
-  *comm = c;
+  auto *box = new CommBox;
+  box->kind = 0;
+  box->nccl = c;
+  box->world = world;
+  box->rank = rank;
+  *comm = box;
   return 0;
 }
 
 void snet_rccl_comm_destroy(void *comm) {
+  auto *box = static_cast<CommBox *>(comm);
+  if (!box) return;
   Rccl *r = rccl();
-  if (r && comm) (void)r->CommDestroy(comm);
+  if (box->kind == 0 && r && box->nccl) (void)r->CommDestroy(box->nccl);
+  delete box;
 }
 
 // sum of n doubles over all ranks, in place (total energy, virial): one tiny all-reduce per step
 int snet_rccl_allreduce_sum_f64(void *comm, double *dev_values, int64_t n, void *stream) {
+  auto *box = static_cast<CommBox *>(comm);
+  SNET_REQUIRE(box != nullptr && dev_values != nullptr, "snet_rccl_allreduce_sum_f64: bad argument");
+  SNET_REQUIRE(box->kind == 0, "snet_rccl_allreduce_sum_f64: not available on the in-process test transport");
   Rccl *r = rccl();
-  SNET_REQUIRE(r != nullptr && comm != nullptr && dev_values != nullptr, "snet_rccl_allreduce_sum_f64: bad argument");
-  const int rc = r->AllReduce(dev_values, dev_values, (size_t)n, kFloat64, kSum, comm, static_cast<hipStream_t>(stream));
+  SNET_REQUIRE(r != nullptr, "snet_rccl_allreduce_sum_f64: RCCL not loaded");
+  const int rc = r->AllReduce(dev_values, dev_values, (size_t)n, kFloat64, kSum, box->nccl, static_cast<hipStream_t>(stream));
   return rc ? fail("ncclAllReduce", rc) : 0;
+}
+
+// ---- in-process transport for tests (one GPU, one host thread per rank) ----
+int snet_loopback_hub_create(int32_t world, void **hub) {
+  SNET_REQUIRE(hub != nullptr && world >= 1 && world <= 64, "snet_loopback_hub_create: bad argument");
+  auto *h = new LoopHub;
+  h->world = world;
+  h->box.resize((size_t)world * world);
+  h->ack.resize((size_t)world * world);
+  *hub = h;
+  return 0;
+}
+void snet_loopback_hub_abort(void *hub) {  // wake every rank blocked in an exchange (a test thread died)
+  auto *h = static_cast<LoopHub *>(hub);
+  if (!h) return;
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->aborted = true;
+  }
+  h->cv.notify_all();
+}
+void snet_loopback_hub_destroy(void *hub) { delete static_cast<LoopHub *>(hub); }
+int snet_loopback_comm_create(void *hub, int32_t rank, void **comm) {
+  auto *h = static_cast<LoopHub *>(hub);
+  SNET_REQUIRE(h != nullptr && comm != nullptr && rank >= 0 && rank < h->world, "snet_loopback_comm_create: bad argument");
+  auto *box = new CommBox;
+  box->kind = 1;
+  box->hub = h;
+  box->world = h->world;
+  box->rank = rank;
+  *comm = box;
+  return 0;
 }
 
 int snet_halo_create(void *comm, int32_t world, int32_t rank, const int32_t *send_counts, const int32_t *send_idx_host,
                      const int32_t *recv_counts, const int32_t *recv_perm_host, snet_halo **out) {
   SNET_REQUIRE(comm != nullptr && out != nullptr && send_counts && recv_counts && world >= 1 && rank >= 0 && rank < world,
                "snet_halo_create: bad argument");
+  auto *box = static_cast<CommBox *>(comm);
+  SNET_REQUIRE(box->world == world && box->rank == rank, "snet_halo_create: world / rank differ from the communicator's");
   auto *h = new snet_halo;
-  h->comm = comm;
+  h->comm = box;
   h->world = world;
   h->rank = rank;
   h->send_cnt.assign(send_counts, send_counts + world);
@@ -235,8 +412,7 @@ int snet_halo_forward(void *user, float *x, int64_t n_total, int64_t n_local, in
   auto *h = static_cast<snet_halo *>(user);
   SNET_REQUIRE(h != nullptr && x != nullptr && dim > 0, "snet_halo_forward: bad argument");
   SNET_REQUIRE(n_total - n_local == h->n_ghost, "snet_halo_forward: ghost row count does not match the exchange plan");
-  Rccl *r = rccl();
-  SNET_REQUIRE(r != nullptr, "snet_halo_forward: RCCL not loaded");
+  SNET_REQUIRE(h->comm->kind != 0 || rccl() != nullptr, "snet_halo_forward: RCCL not loaded");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (h->n_send > 0) {
     SNET_REQUIRE(h->send_buf.ensure((size_t)h->n_send * dim), "snet_halo_forward: allocation failed");
@@ -247,17 +423,15 @@ int snet_halo_forward(void *user, float *x, int64_t n_total, int64_t n_local, in
     SNET_REQUIRE(h->ghost_buf.ensure((size_t)h->n_ghost * dim), "snet_halo_forward: allocation failed");
     land = h->ghost_buf.p;
   }
-  int rc = r->GroupStart();
-  if (rc) return fail("ncclGroupStart", rc);
+  if (int rc = x_group_start(h->comm)) return rc;
+  int rc = 0;
   for (int p = 0; p < h->world && !rc; ++p) {
-    if (h->send_cnt[p])
-      rc = r->Send(h->send_buf.p + h->send_off[p] * dim, (size_t)h->send_cnt[p] * dim, kFloat, p, h->comm, st);
-    if (!rc && h->recv_cnt[p])
-      rc = r->Recv(land + h->recv_off[p] * dim, (size_t)h->recv_cnt[p] * dim, kFloat, p, h->comm, st);
+    if (h->send_cnt[p]) rc = x_send(h->comm, h->send_buf.p + h->send_off[p] * dim, (size_t)h->send_cnt[p] * dim, p, st);
+    if (!rc && h->recv_cnt[p]) rc = x_recv(h->comm, land + h->recv_off[p] * dim, (size_t)h->recv_cnt[p] * dim, p, st);
   }
-  const int rc2 = r->GroupEnd();
-  if (rc) return fail("ncclSend/ncclRecv", rc);
-  if (rc2) return fail("ncclGroupEnd", rc2);
+  const int rc2 = x_group_end(h->comm);
+  if (rc) return rc;
+  if (rc2) return rc2;
   if (h->permuted)  // ghost row g <- stream row inv[g]
     return snet_gather_rows(h->ghost_buf.p, h->ghost_inv.p, x + n_local * dim, h->n_ghost, dim, stream);
   return 0;
@@ -268,8 +442,7 @@ int snet_halo_reverse(void *user, float *gx, int64_t n_total, int64_t n_local, i
   auto *h = static_cast<snet_halo *>(user);
   SNET_REQUIRE(h != nullptr && gx != nullptr && dim > 0, "snet_halo_reverse: bad argument");
   SNET_REQUIRE(n_total - n_local == h->n_ghost, "snet_halo_reverse: ghost row count does not match the exchange plan");
-  Rccl *r = rccl();
-  SNET_REQUIRE(r != nullptr, "snet_halo_reverse: RCCL not loaded");
+  SNET_REQUIRE(h->comm->kind != 0 || rccl() != nullptr, "snet_halo_reverse: RCCL not loaded");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (h->n_send > 0)
     SNET_REQUIRE(h->recv_buf.ensure((size_t)h->n_send * dim) && h->seg_buf.ensure((size_t)h->n_seg * dim),
@@ -280,17 +453,17 @@ int snet_halo_reverse(void *user, float *gx, int64_t n_total, int64_t n_local, i
     if (int e = snet_gather_rows(gx + n_local * dim, h->ghost_perm.p, h->ghost_buf.p, h->n_ghost, dim, stream)) return e;
     home = h->ghost_buf.p;
   }
-  int rc = r->GroupStart();
-  if (rc) return fail("ncclGroupStart", rc);
+  if (int rc = x_group_start(h->comm)) return rc;
+  int rc = 0;
   for (int p = 0; p < h->world && !rc; ++p) {
     if (h->recv_cnt[p])  // my ghost rows owned by p go home
-      rc = r->Send(home + h->recv_off[p] * dim, (size_t)h->recv_cnt[p] * dim, kFloat, p, h->comm, st);
+      rc = x_send(h->comm, home + h->recv_off[p] * dim, (size_t)h->recv_cnt[p] * dim, p, st);
     if (!rc && h->send_cnt[p])  // p returns the gradients of the rows I sent it
-      rc = r->Recv(h->recv_buf.p + h->send_off[p] * dim, (size_t)h->send_cnt[p] * dim, kFloat, p, h->comm, st);
+      rc = x_recv(h->comm, h->recv_buf.p + h->send_off[p] * dim, (size_t)h->send_cnt[p] * dim, p, st);
   }
-  const int rc2 = r->GroupEnd();
-  if (rc) return fail("ncclSend/ncclRecv", rc);
-  if (rc2) return fail("ncclGroupEnd", rc2);
+  const int rc2 = x_group_end(h->comm);
+  if (rc) return rc;
+  if (rc2) return rc2;
   if (h->n_seg > 0) {
     if (int e = snet_segment_sum_rows(h->recv_buf.p, h->red_ptr.p, h->red_perm.p, h->n_seg, dim, h->seg_buf.p, stream)) return e;
     if (int e = snet_scatter_add_rows(h->seg_buf.p, h->red_rows.p, gx, h->n_seg, dim, stream)) return e;

@@ -277,6 +277,40 @@ class RcclComm:
             pass
 
 
+class LoopbackHub:
+    """TEST transport for one GPU (csrc/snet_halo.cpp): W host threads play W ranks of the native halo exchange;
+    sends and receives are device-to-device copies with RCCL's group semantics.  `comm(rank)` gives what NativeHalo
+    takes in place of an RcclComm."""
+
+    def __init__(self, world: int):
+        from . import _lib
+        self.lib, self.world = _lib.load(), world
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.snet_loopback_hub_create(world, C.byref(self.handle)), 'snet_loopback_hub_create')
+        self.comms = []
+
+    def comm(self, rank: int):
+        from . import _lib
+        c = _LoopbackComm()
+        c.lib, c.world, c.rank, c.hub = self.lib, self.world, rank, self
+        c.handle = C.c_void_p()
+        _lib.check(self.lib.snet_loopback_comm_create(self.handle, rank, C.byref(c.handle)), 'snet_loopback_comm_create')
+        return c
+
+    def abort(self):
+        self.lib.snet_loopback_hub_abort(self.handle)
+
+
+class _LoopbackComm:
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.snet_rccl_comm_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class NativeHalo:
     """The ghost exchange implemented INSIDE libsnet_hip.so (csrc/snet_halo.cpp: one ncclGroup of send / recv
     pairs per call on the compute stream, pack / reverse-accumulate kernels of the library) -- what replaces

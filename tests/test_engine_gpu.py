@@ -574,6 +574,132 @@ def test_native_rccl_halo_self_exchange():
         NativeHalo(comm, [send], [len(send)], recv_perm=np.zeros(len(send), np.int32))
 
 
+def _run_ranks(world, fn, hub):
+    """fn(rank) on one host thread per rank (each with its own HIP stream); a failing rank aborts the hub"""
+    import threading
+    errors, results = [], [None] * world
+
+    def run(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device='cuda:0')):
+                results[r] = fn(r)
+                torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, e))
+            hub.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize('world', [2, 3, 5])
+def test_native_halo_multi_rank_plan_on_the_loopback_transport(world):
+    """csrc/snet_halo.cpp with SEVERAL peers on one GPU: `world` host threads, one rank each, exchange through the
+    library's in-process transport (device-to-device copies with ncclGroup semantics) -- the pack / land / permute /
+    reverse-accumulate plan and its per-peer offsets are the code the RCCL path runs.  Random send lists with repeats,
+    self-sends and empty pairs; one rank numbers its ghost rows in its own order (recv_perm)."""
+    from sevennet_amd.parallel import LoopbackHub, NativeHalo
+    dev = 'cuda:0'
+    rng = np.random.default_rng(100 + world)
+    n_local = [int(rng.integers(20, 60)) for _ in range(world)]
+    send = [[rng.integers(0, n_local[r], int(rng.integers(0, 25))) if rng.random() > 0.2 else np.zeros(0, np.int64)
+             for _ in range(world)] for r in range(world)]          # send[r][p]: rows of r that p holds as ghosts
+    recv_counts = [[len(send[p][r]) for p in range(world)] for r in range(world)]
+    n_ghost = [sum(c) for c in recv_counts]
+    perm_rank = world - 1
+    perm = rng.permutation(n_ghost[perm_rank])
+    hub = LoopbackHub(world)
+    halos = [NativeHalo(hub.comm(r), send[r], recv_counts[r], recv_perm=perm if r == perm_rank else None) for r in range(world)]
+    for dim in (96, 5):
+        g = torch.Generator().manual_seed(dim)
+        x0 = [torch.randn(n_local[r] + n_ghost[r], dim, generator=g) for r in range(world)]
+        gx0 = [torch.randn(n_local[r] + n_ghost[r], dim, generator=g) for r in range(world)]
+
+        def fn(r):
+            x, gx = x0[r].to(dev), gx0[r].to(dev)
+            halos[r].forward(x, n_local[r])
+            halos[r].reverse(gx, n_local[r])
+            halos[r].forward(gx, n_local[r])      # a second forward on the reverse's result: buffers are reused in order
+            return x.cpu(), gx.cpu()
+        out = _run_ranks(world, fn, hub)
+        gx_sum = []
+        for r in range(world):
+            stream = torch.cat([x0[p][:n_local[p]][torch.as_tensor(send[p][r]).long()] for p in range(world)]) \
+                if n_ghost[r] else torch.zeros(0, dim)
+            want = stream
+            if r == perm_rank and n_ghost[r]:
+                want = torch.empty_like(stream)
+                want[torch.as_tensor(perm).long()] = stream
+            assert torch.equal(out[r][0][:n_local[r]], x0[r][:n_local[r]])
+            assert torch.equal(out[r][0][n_local[r]:], want), (world, dim, r)
+            # reverse: my local rows += every ghost copy of them held by any peer (peer order, fp32 sums)
+            acc = gx0[r][:n_local[r]].double().clone()
+            for p in range(world):
+                gp = gx0[p][n_local[p]:]
+                if p == perm_rank and n_ghost[p]:
+                    gp = gp[torch.as_tensor(perm).long()]       # back to peer-stream order
+                off = sum(recv_counts[p][:r])
+                rows = gp[off:off + len(send[r][p])]
+                if len(rows):
+                    acc.index_add_(0, torch.as_tensor(send[r][p]).long(), rows.double())
+            gx_sum.append(acc)
+        for r in range(world):
+            assert (out[r][1][:n_local[r]].double() - gx_sum[r]).abs().max() < 1e-5, (world, dim, r)
+            stream = torch.cat([gx_sum[p][torch.as_tensor(send[p][r]).long()] for p in range(world)]) if n_ghost[r] \
+                else torch.zeros(0, dim, dtype=torch.float64)
+            want = stream
+            if r == perm_rank and n_ghost[r]:
+                want = torch.empty_like(stream)
+                want[torch.as_tensor(perm).long()] = stream
+            assert (out[r][1][n_local[r]:].double() - want).abs().max() < 1e-5, (world, dim, r)
+
+
+@pytest.mark.parametrize('world,host', [(2, 'native'), (4, 'native'), (8, 'native'), (4, 'python')])
+def test_bricks_through_the_native_halo_equal_single_graph(world, host):
+    """The whole multi-rank evaluation path of `bench.py --gpus N` / a LAMMPS e3gnn/parallel run on one GPU: `world`
+    bricks of one cell, one host thread each, ghost features and gradients exchanged by csrc/snet_halo.cpp (loopback
+    transport) INSIDE snet_model_eval (native host, no Python callback) or from HipForceEngine.compute == the un-split
+    evaluation (reference analogue: tests/lammps_tests/test_lammps.py:540-578, serial vs parallel pair style)."""
+    from sevennet_amd.engine import HipForceEngine, build_graph
+    from sevennet_amd.native_model import NativeModel
+    from sevennet_amd.parallel import LoopbackHub, NativeHalo, build_brick_graph
+    from sevennet_amd.shapes import mini_sevennet_0_config
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = mini_sevennet_0_config()
+    sd = random_state_dict(cfg, seed=9)
+    types, pos, cell, ei, ev = synthetic_system((4, 4, 4), sigma=0.06, seed=4, cutoff=5.0, n_species=2)
+    ref = HipForceEngine(cfg, sd, device='cuda:0').compute(build_graph(types, ei, ev, device='cuda:0'))
+    torch.cuda.synchronize()
+    bricks = [build_brick_graph(pos, cell, types, 5.0, world, r, neighbors=(ei, ev)) for r in range(world)]
+    hub = LoopbackHub(world)
+    halos = [NativeHalo(hub.comm(r), bricks[r].send_lists, bricks[r].recv_counts) for r in range(world)]
+    models = [NativeModel(cfg, sd) if host == 'native' else HipForceEngine(cfg, sd, device='cuda:0') for _ in range(world)]
+
+    def fn(r):
+        b = bricks[r]
+        g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, device='cuda:0')
+        if host == 'native':
+            models[r].set_halo(halos[r])
+            out = models[r].compute(g)
+        else:
+            out = models[r].compute(g, halo=halos[r])
+        return float(out['energy'].cpu()), out['forces'].cpu().numpy()
+    res = _run_ranks(world, fn, hub)
+    F = np.zeros((len(types), 3), np.float32)
+    for b, (_, f) in zip(bricks, res):
+        F[b.global_ids[:b.n_local]] = f[:b.n_local]
+    e_tot = sum(e for e, _ in res)
+    e_ref = float(ref['energy'].cpu())
+    assert abs(e_tot - e_ref) < 2e-6 * abs(e_ref)
+    fr = ref['forces'].cpu().numpy()
+    assert np.abs(F - fr).max() <= max(1e-8, 2e-5 * np.abs(fr).max())
+
+
 @pytest.mark.parametrize('model,n_tile', [('sevennet_l3i5', 19), ('sevennet_mf_ompa', 15)])
 def test_lmax3_shapes_full_size_equal_tiled_small_cell(model, n_tile):
     """BASELINE config 4 / 5 sizes through the size-independent tiling property: SevenNet-l3i5 shape at
