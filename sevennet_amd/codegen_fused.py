@@ -184,39 +184,15 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  __shared__ u32x4 slab[2][LPS * 64];')
     A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
     A('  const int j = lane & 15, g = lane >> 4;')
+    # Prologue order: every load is requested as soon as its address is known -- the first weight slab at once, the
+    # node's g_out entries with the row pointers, the first source rows with h2 -- so the tile pays four dependent
+    # memory latencies (tile -> node -> edge -> rows) instead of seven before its first matrix product.
+    _emit_staging(A, 'LPS')
+    A('  stage_load(0, 0);')
     A('  const int t_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
     A('  const bool live = t_raw < n_tiles;')
     A('  const int t = __builtin_amdgcn_readfirstlane(live ? t_raw : n_tiles - 1);  // idle waves shadow the last tile, stores masked')
     A('  const int node = __builtin_amdgcn_readfirstlane(tile_node[t]);')
-    A('  const int e0 = row_ptr[node] + 16 * (t - tile_ptr[node]);')
-    A('  const int cnt = min(16, row_ptr[node + 1] - e0);')
-    A('  const bool valid = live && j < cnt;')
-    A('  const int e = e0 + min(j, cnt - 1);')
-    A('  const int s_src = src[e];')
-    A('  const int wr = w_row ? w_row[e] : e;')
-    A('  // the edge\'s spherical harmonics wait in wave-private LDS ([component][edge]: conflict-free, the four channel')
-    A('  // groups of an edge read the same word) and are re-read per path: 9 .. 16 fewer live registers per lane')
-    A('  __shared__ float s_y[NWV][NSH * 16];')
-    A('  if (g == 0) {')
-    A('#pragma unroll')
-    A('    for (int k = 0; k < NSH; ++k) s_y[wave][k * 16 + j] = sh[(size_t)e * NSH + k];')
-    A('  }')
-    A('  const float *yl = &s_y[wave][j];')
-    A('  SplitN<NT> hb[2];  // h2^T as B operand: column = edge, k slots (g, 0..7) <-> hidden unit 32 q + 8 g + slot')
-    A('#pragma unroll')
-    A('  for (int q = 0; q < 2; ++q) {')
-    A('    const f32x4 lo4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wr * 64 + 32 * q + 8 * g);')
-    A('    const f32x4 hi4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wr * 64 + 32 * q + 8 * g + 4);')
-    A('    const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};')
-    A('    hb[q] = splitn8<NT>(v);')
-    A('  }')
-    A('  f32x4 ga[4];  // g_h2^T[k = 16 m + 4 g + r][edge]')
-    A('#pragma unroll')
-    A('  for (int m = 0; m < 4; ++m) ga[m] = f32x4{0.f, 0.f, 0.f, 0.f};')
-    A('  float gy[NSH];')
-    A('#pragma unroll')
-    A('  for (int k = 0; k < NSH; ++k) gy[k] = 0.f;')
-    _emit_staging(A, 'LPS')
     # The node's g_out entries of one (x block, 16-channel tile) are shared by the 16 edge lanes of a group.  They
     # are fetched ONCE per wave, one block ahead, by one or two 16-byte loads per lane (lane L: channels 4 (L & 3)
     # .. +3 of entry 16 k + (L >> 2); vector-memory instructions, not bytes, are what this kernel runs out of),
@@ -250,8 +226,40 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         return glists[ci].index((pi, m3))
 
     emit_g_loads('  ', 0, '0')
+    A('  const int e0 = row_ptr[node] + 16 * (t - tile_ptr[node]);')
+    A('  const int cnt = min(16, row_ptr[node + 1] - e0);')
+    A('  const bool valid = live && j < cnt;')
+    A('  const int e = e0 + min(j, cnt - 1);')
+    A('  const int s_src = src[e];')
+    A('  const int wr = w_row ? w_row[e] : e;')
+    _c0 = cats[0]
+    A(f'  const float *xs0 = x + (size_t)s_src * DX + {_c0.x_off} + 4 * g;')
+    A(f'  f32x4 xr0[{2 * _c0.l1 + 1}], xn0[{2 * _c0.l1 + 1}];')
+    for m in range(2 * _c0.l1 + 1):
+        A(f'  xr0[{m}] = *reinterpret_cast<const f32x4 *>(xs0 + {m * _c0.mul});')
+    A('  // the edge\'s spherical harmonics wait in wave-private LDS ([component][edge]: conflict-free, the four channel')
+    A('  // groups of an edge read the same word) and are re-read per path: 9 .. 16 fewer live registers per lane')
+    A('  __shared__ float s_y[NWV][NSH * 16];')
+    A('  if (g == 0) {')
+    A('#pragma unroll')
+    A('    for (int k = 0; k < NSH; ++k) s_y[wave][k * 16 + j] = sh[(size_t)e * NSH + k];')
+    A('  }')
+    A('  const float *yl = &s_y[wave][j];')
+    A('  SplitN<NT> hb[2];  // h2^T as B operand: column = edge, k slots (g, 0..7) <-> hidden unit 32 q + 8 g + slot')
+    A('#pragma unroll')
+    A('  for (int q = 0; q < 2; ++q) {')
+    A('    const f32x4 lo4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wr * 64 + 32 * q + 8 * g);')
+    A('    const f32x4 hi4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wr * 64 + 32 * q + 8 * g + 4);')
+    A('    const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};')
+    A('    hb[q] = splitn8<NT>(v);')
+    A('  }')
+    A('  f32x4 ga[4];  // g_h2^T[k = 16 m + 4 g + r][edge]')
+    A('#pragma unroll')
+    A('  for (int m = 0; m < 4; ++m) ga[m] = f32x4{0.f, 0.f, 0.f, 0.f};')
+    A('  float gy[NSH];')
+    A('#pragma unroll')
+    A('  for (int k = 0; k < NSH; ++k) gy[k] = 0.f;')
     emit_g_park('  ', 0, '0')
-    A('  stage_load(0, 0);')
     A('  stage_store(0);')
     A('  __syncthreads();')
     A('  int sidx = 0, buf = 0, gbuf = 0;')
@@ -260,10 +268,11 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         A(f'  // ---- x block {cat.i_x}: {cat.mul}x l={cat.l1}, {len(cat.paths)} paths')
         nct = cat.mul // 16
         # source rows: the next channel tile's slice is requested one block ahead (gather latency ~1-2 us)
-        A(f'  const float *xs{ci} = x + (size_t)s_src * DX + {cat.x_off} + 4 * g;')
-        A(f'  f32x4 xr{ci}[{d1}], xn{ci}[{d1}];')
-        for m in range(d1):
-            A(f'  xr{ci}[{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {m * cat.mul});')
+        if ci > 0:   # (the first x block's rows were requested in the prologue)
+            A(f'  const float *xs{ci} = x + (size_t)s_src * DX + {cat.x_off} + 4 * g;')
+            A(f'  f32x4 xr{ci}[{d1}], xn{ci}[{d1}];')
+            for m in range(d1):
+                A(f'  xr{ci}[{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {m * cat.mul});')
         A(f'  for (int ct = 0; ct < {nct}; ++ct) {{')
         A(f'    f32x4 (&xr)[{d1}] = xr{ci};')
         A(f'    f32x4 gx[{d1}];')
