@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ-level counters of the fused reverse / forward kernels (one --pmc pass per group; kernel trace only)
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/g24
+OUT=$ROOT/gpurun_out/sq
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_[A-Z_0-9]*" | sort -u > $OUT/sq_counters.txt
