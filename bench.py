@@ -65,6 +65,8 @@ def parse():
     ap.add_argument('--halo', default='auto', choices=['auto', 'native', 'torch'],
                     help="N > 1: ghost exchange by libsnet_hip.so's own RCCL send/recv groups ('native', default with the "
                          "nccl backend) or by torch.distributed.all_to_all_single ('torch'; the only choice over gloo)")
+    ap.add_argument('--no-halo-overlap', action='store_true', help='N > 1, native halo: run the forward ghost exchange on the '
+                    'compute stream instead of a second stream beside the self-connection / hidden radial layers')
     ap.add_argument('--no-h2d', action='store_true', help='keep the edge vectors resident (no per-step host -> device copy)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-reps', type=int, default=6, help='CPU-baseline sample: cells per axis (6 -> 1728 atoms, 11 -> 10 648)')
@@ -213,7 +215,7 @@ def main():
         if use_native:
             from sevennet_amd.parallel import NativeHalo, RcclComm
             rccl_comm = RcclComm(world, rank)
-            halo = NativeHalo(rccl_comm, bg.send_lists, bg.recv_counts)
+            halo = NativeHalo(rccl_comm, bg.send_lists, bg.recv_counts, overlap=not a.no_halo_overlap)
         else:
             halo = HaloExchange(bg.send_lists, bg.recv_counts, dev)
         ne = torch.tensor([graph.n_edges], device=dev, dtype=torch.int64)
@@ -367,6 +369,7 @@ def main():
                        'fused': a.fused, 'terms': a.terms,
                        'halo': (None if world == 1 else ('libsnet_hip RCCL send/recv groups' if type(halo).__name__ == 'NativeHalo'
                                                           else f'torch.distributed all_to_all_single ({backend})')),
+                       'halo_overlap': (None if world == 1 else bool(getattr(halo, 'overlap', True))),
                        'ghost_rows_rank0': (None if world == 1 else int(graph.n_total - graph.n_local)),
                        'halo_ms_per_step_rank0': (None if world == 1 else round(sum(v for k, v in totals.items() if k.startswith('halo')) / n_break, 4)),
                        'kernel_ms_per_step_rank0': round(sum(v for k, v in totals.items() if not k.startswith('halo')) / n_break, 3),

@@ -319,9 +319,14 @@ class NativeHalo:
     (HipForceEngine, NativeModel) accept it; NativeModel installs it with snet_model_set_rccl_halo, i.e. the
     evaluation then runs without a single Python callback."""
 
-    def __init__(self, comm: RcclComm, send_lists: Sequence[np.ndarray], recv_counts: Sequence[int], recv_perm=None):
+    def __init__(self, comm: RcclComm, send_lists: Sequence[np.ndarray], recv_counts: Sequence[int], recv_perm=None,
+                 overlap: bool = True):
         from . import _lib
         self.lib, self.comm = _lib.load(), comm
+        # overlap: forward_start runs the exchange on a second HIP stream so that the ghost rows travel while the
+        # caller's stream goes on with work that does not read them (HipForceEngine: self-connection, hidden radial
+        # layers); forward_finish makes the caller's stream wait for it
+        self.overlap, self._side = overlap, None
         world = comm.world
         assert len(send_lists) == world and len(recv_counts) == world
         sc = np.asarray([len(s) for s in send_lists], np.int32)
@@ -349,6 +354,27 @@ class NativeHalo:
         assert gx.is_contiguous() and gx.dtype == torch.float32
         _lib.check(self.lib.snet_halo_reverse(self.handle, C.c_void_p(gx.data_ptr()), gx.shape[0], n_local, gx.shape[1],
                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'snet_halo_reverse')
+
+    def forward_start(self, x: torch.Tensor, n_local: int):
+        """Begin filling the ghost rows (same split interface as HaloExchange); returns a handle for forward_finish."""
+        if not self.overlap:
+            self.forward(x, n_local)
+            return None
+        from . import _lib
+        assert x.is_contiguous() and x.dtype == torch.float32
+        cur = torch.cuda.current_stream(x.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=x.device)
+        self._side.wait_stream(cur)          # the rows to send are complete
+        _lib.check(self.lib.snet_halo_forward(self.handle, C.c_void_p(x.data_ptr()), x.shape[0], n_local, x.shape[1],
+                                              C.c_void_p(self._side.cuda_stream)), 'snet_halo_forward')
+        done = torch.cuda.Event()
+        done.record(self._side)
+        return done, x                       # x stays referenced until the caller's stream has waited
+
+    def forward_finish(self, handle):
+        if handle is not None:
+            torch.cuda.current_stream(handle[1].device).wait_event(handle[0])
 
     def __del__(self):
         try:

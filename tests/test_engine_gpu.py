@@ -549,6 +549,14 @@ def test_native_rccl_halo_self_exchange():
     halo.forward(y, n_local)
     torch.cuda.synchronize()
     assert torch.equal(y[n_local:], y0[torch.as_tensor(send, device=dev).long()])
+    # split exchange: RCCL on the halo's second stream, the caller's stream waits in forward_finish
+    z = torch.randn(n_local + len(send), dim, generator=g).to(dev)
+    z0 = z.clone()
+    pending = halo.forward_start(z, n_local)
+    busy = torch.randn(512, 512, device=dev) @ torch.randn(512, 512, device=dev)   # work beside the transfer
+    halo.forward_finish(pending)
+    torch.cuda.synchronize()
+    assert pending is not None and torch.equal(z[n_local:], z0[torch.as_tensor(send, device=dev).long()]) and busy.isfinite().all()
     e = torch.tensor([1.5, -2.0], dtype=torch.float64, device=dev)
     comm.all_reduce_f64(e)
     torch.cuda.synchronize()
@@ -659,7 +667,7 @@ def test_native_halo_multi_rank_plan_on_the_loopback_transport(world):
             assert (out[r][1][n_local[r]:].double() - want).abs().max() < 1e-5, (world, dim, r)
 
 
-@pytest.mark.parametrize('world,host', [(2, 'native'), (4, 'native'), (8, 'native'), (4, 'python')])
+@pytest.mark.parametrize('world,host', [(2, 'native'), (4, 'native'), (8, 'native'), (4, 'python'), (4, 'python-inline')])
 def test_bricks_through_the_native_halo_equal_single_graph(world, host):
     """The whole multi-rank evaluation path of `bench.py --gpus N` / a LAMMPS e3gnn/parallel run on one GPU: `world`
     bricks of one cell, one host thread each, ghost features and gradients exchanged by csrc/snet_halo.cpp (loopback
@@ -677,7 +685,10 @@ def test_bricks_through_the_native_halo_equal_single_graph(world, host):
     torch.cuda.synchronize()
     bricks = [build_brick_graph(pos, cell, types, 5.0, world, r, neighbors=(ei, ev)) for r in range(world)]
     hub = LoopbackHub(world)
-    halos = [NativeHalo(hub.comm(r), bricks[r].send_lists, bricks[r].recv_counts) for r in range(world)]
+    # 'python': the forward exchange runs on each rank's second stream beside the self-connection (forward_start /
+    # forward_finish); 'python-inline': on the compute stream
+    halos = [NativeHalo(hub.comm(r), bricks[r].send_lists, bricks[r].recv_counts, overlap=host != 'python-inline')
+             for r in range(world)]
     models = [NativeModel(cfg, sd) if host == 'native' else HipForceEngine(cfg, sd, device='cuda:0') for _ in range(world)]
 
     def fn(r):
