@@ -15,10 +15,14 @@ Two kernels per convolution shape (all channel multiplicities must be multiples 
                g_h2^T[k, edge] += W2[k, cols] (A, from LDS) x g_w^T (B = the registers just produced)
              -- accumulator layout == next operand layout, no transposition, no LDS round trip.
              d/dY is accumulated per lane over all channels (no cross-lane reduction per edge).
-             Outputs: g_xe[E,dx] (per-edge source-row gradient), g_h2[E,64], g_vec[E,3] +=.
+             Epilogue (FusedTail): the MLP's two hidden layers reversed on the g_h2 accumulators -- same layout
+             trick, fragments staged through the idle slab buffers -- so g_h2 is not written either.
+             Outputs: g_xe[E,dx] (per-edge source-row gradient), g_vec[E,3] +=, g_emb[E,nb] += (or g_h2[E,64]).
   conv_fwdf  forward.  One wavefront = one destination node, up to two 16-edge tiles per pass
              (lane & 15 = channel, lane >> 4 = group of 4 edges): w[edge, col] = h2 (A) x W2-tile (B),
              tensor product accumulated over the lane's edges, two permlane adds per output value.
+             The 16 source rows' slice of a (block, tile) stage is loaded one stage ahead and parked in
+             wave-private LDS; output rows leave through LDS as 16-byte stores.
 
 W2 reaches both kernels as one stream of pre-split bf16 MFMA fragments in sub-step order
 (`sub_cols`, packed by snet_fused_plan_create); a workgroup's wavefronts walk the stream in
@@ -657,7 +661,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     for ci, cat in enumerate(cats):
         d1 = 2 * cat.l1 + 1
         nct = cat.mul // 16
-        npairs = len(pairs_of[ci])
         A(f'    // ---- x block {cat.i_x}: {cat.mul}x l={cat.l1}, {len(cat.paths)} paths')
         A(f'    for (int ct = 0; ct < {nct}; ++ct) {{')
         for gi, grp in enumerate(fgroups[ci]):
