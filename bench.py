@@ -378,6 +378,13 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, sd, a.cpu_reps)
+        # RCCL writes a version banner through C stdio, which a pipe buffers until exit: flush it now so that the JSON
+        # line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
