@@ -107,7 +107,10 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('#include "snet_split.h"')
     A('namespace {')
     A('using namespace snet;')
-    A(f'constexpr int DX = {DX}, DOUT = {DOUT}, NSH = {NSH}, WN = {WN}, NS = {NS};')
+    # row stride of the forward kernel's spherical-harmonics staging: the four edge groups of a wave read rows 4 apart,
+    # which for nsh = 16 (lmax 3) all fall on one LDS bank (measured: 36 % of the kernel's LDS cycles were conflicts)
+    NSHP = NSH + 1 if (4 * NSH) % 32 == 0 else NSH
+    A(f'constexpr int DX = {DX}, DOUT = {DOUT}, NSH = {NSH}, NSHP = {NSHP}, WN = {WN}, NS = {NS};')
     A('const int32_t SUB_COLS[NS * 2] = {' + ', '.join(f'{a}, {b}' for a, b in cols) + '};')
     A('')
 
@@ -161,7 +164,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             for i in range(d3):
                 A(f'    float s{i} = 0.f;')
             for b_ in sorted({b_ for (_, b_) in byab}):
-                A(f'    const float y{b_} = ysl[{r} * NSH + {p.sh_off + b_}];')
+                A(f'    const float y{b_} = ysl[{r} * NSHP + {p.sh_off + b_}];')
             for (a_, b_), cl in sorted(byab.items()):
                 A(f'    {{ const float xy = xr[{r}][{a_}] * y{b_};')
                 for cc, v in cl:
@@ -567,7 +570,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  constexpr int NSTB = (LPB * LPF * 64 + NTH - 1) / NTH;')
     A('  __shared__ u32x4 slab[2][LPB * LPF * 64];')
     A('  __shared__ int s_pass[NWV];')
-    A('  __shared__ __attribute__((aligned(16))) float s_ys[NWV][32 * NSH];  // spherical harmonics of the pass\'s edges')
+    A('  __shared__ __attribute__((aligned(16))) float s_ys[NWV][32 * NSHP];  // spherical harmonics of the pass\'s edges (rows padded: NSHP)')
     A(f'  __shared__ __attribute__((aligned(16))) float s_x[NWV][{MAXD1} * 256];  // source-row slice of one tile: [m][r][g][channel]')
     A(f'  __shared__ __attribute__((aligned(16))) float s_o[NWV][{NOEP} * 16];      // output rows of one block: [entry][channel]')
     A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
@@ -642,7 +645,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    }')
     A('    for (int i = lane; i < 32 * NSH; i += 64) {')
     A('      const int el = i / NSH;')
-    A('      s_ys[wave][i] = has_e ? sh[(size_t)min(eb + el, e_last) * NSH + (i - el * NSH)] : 0.f;')
+    A('      s_ys[wave][el * NSHP + (i - el * NSH)] = has_e ? sh[(size_t)min(eb + el, e_last) * NSH + (i - el * NSH)] : 0.f;')
     A('    }')
     first_n = len(fgroups[0][0])
     A(f'    stage_load(0, {first_n}, 0);')
@@ -725,7 +728,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A('          for (int r = 0; r < 4; ++r)')
                 A('#pragma unroll')
                 A(f'            for (int m = 0; m < {d1}; ++m) xr[r][m] = s_x[wave][m * 256 + r * 64 + lane];')
-                A(f'          const float *ysl = &s_ys[wave][(16 * {tl} + 4 * g) * NSH];')
+                A(f'          const float *ysl = &s_ys[wave][(16 * {tl} + 4 * g) * NSHP];')
                 # kernel-tuning knob, measured neutral (7.83 / 7.94 vs 7.75 ms per step over the three middle layers): weight
                 # fragments of a path tile requested one path tile ahead (fpf: 1 = its first k-step, 2 = both), so that the
                 # LDS latency in front of each chain of matrix products overlaps the previous tensor-product body
@@ -878,7 +881,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                     continue   # would not fit the 160-KB LDS
                 A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_fwd_t<{nt_}, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
     def fwd_lds(nt, nwv):
-        return 2 * LPB * 4 * nt * 1024 + nwv * (32 * NSH * 4 + MAXD1 * 1024 + NOEP * 64) + 4 * nwv
+        return 2 * LPB * 4 * nt * 1024 + nwv * (32 * NSHP * 4 + MAXD1 * 1024 + NOEP * 64) + 4 * nwv
 
     def fwd_cfg(nt):
         # measured: occupancy decides -- one 12-wave workgroup per CU at <= 168 VGPRs (3 waves per SIMD, direct
