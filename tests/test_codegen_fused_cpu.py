@@ -1,0 +1,70 @@
+"""CPU: invariants of the fused tensor-product kernel generator (sevennet_amd/codegen_fused.py) that the kernels
+and the host-side fragment packer (csrc/snet_mlp.hip: pack_fused_slabs) both rely on."""
+import re
+
+import pytest
+
+from sevennet_amd import codegen_fused
+from sevennet_amd.shapes import aot_conv_specs
+
+SPECS = aot_conv_specs()
+FUSABLE = {tag: sp for tag, sp in SPECS.items() if codegen_fused.fusable(sp)}
+
+
+def test_released_shapes_are_fusable():
+    """every layer of the three benchmark models gets the fused kernels (channel multiplicities % 16 == 0)"""
+    from sevennet_amd.model_spec import build_model_spec
+    from sevennet_amd.shapes import sevennet_0_config, sevennet_l3i5_config, sevennet_mf_ompa_config
+    for cfg in (sevennet_0_config(), sevennet_l3i5_config(), sevennet_mf_ompa_config()):
+        for ls in build_model_spec(cfg).layers:
+            assert codegen_fused.fusable(ls.conv), ls.conv.tag
+    assert any(not codegen_fused.fusable(sp) for sp in SPECS.values())   # the 4-channel unit-test shapes are not
+
+
+@pytest.mark.parametrize('tag', sorted(FUSABLE))
+def test_sub_step_schedule_covers_every_weight_column_once(tag):
+    """the weight stream: sub-steps of two 16-column tiles, every column of every path exactly once, tiles of one
+    sub-step belong to the same x block and channel tile (they share the staged source-row slice)"""
+    sp = FUSABLE[tag]
+    cats, pairs_of, cols = codegen_fused.schedule(sp)
+    seen = []
+    for a, b in cols:
+        assert a >= 0 and a % 16 == 0
+        seen.extend(range(a, a + 16))
+        if b >= 0:
+            assert b % 16 == 0
+            seen.extend(range(b, b + 16))
+    assert sorted(seen) == list(range(sp.weight_numel))
+    # stream order = for x block: for channel tile: for path pair
+    k = 0
+    for cat, pairs in zip(cats, pairs_of):
+        paths_of_cat = {pi for pi, _ in cat.paths}
+        for ct in range(cat.mul // 16):
+            for pa, pb in pairs:
+                assert pa in paths_of_cat and (pb is None or pb in paths_of_cat)
+                assert cols[k][0] == sp.paths[pa].w_off + 16 * ct
+                assert cols[k][1] == (sp.paths[pb].w_off + 16 * ct if pb is not None else -1)
+                k += 1
+    assert k == len(cols)
+
+
+@pytest.mark.parametrize('tag', sorted(FUSABLE)[:4] + ['22d6a77ad5ac', '1cad2f51cbd0'])
+def test_generated_source_is_consistent(tag):
+    sp = FUSABLE[tag]
+    src = codegen_fused.gen_conv_fused(sp)
+    _, _, cols = codegen_fused.schedule(sp)
+    m = re.search(r'constexpr int DX = (\d+), DOUT = (\d+), NSH = (\d+), NSHP = (\d+), WN = (\d+), NS = (\d+);', src)
+    dx, dout, nsh, nshp, wn, ns = map(int, m.groups())
+    assert (dx, dout, nsh, wn, ns) == (sp.irreps_x.dim, sp.irreps_out.dim, sp.irreps_sh.dim, sp.weight_numel, len(cols))
+    # spherical-harmonics staging rows of the forward kernel: padded exactly when four rows span whole bank periods
+    assert nshp == (nsh + 1 if (4 * nsh) % 32 == 0 else nsh)
+    tab = re.search(r'SUB_COLS\[NS \* 2\] = \{([^}]*)\}', src).group(1)
+    assert [int(v) for v in tab.split(',')] == [c for ab in cols for c in ab]
+    # one reverse and one forward body per path, both kernels, the registrar
+    for pi in range(len(sp.paths)):
+        assert f'void bwdf_p{pi}(' in src and f'void fwdf_p{pi}(' in src
+    assert f'conv_bwdf_{tag}' in src and f'conv_fwdf_{tag}' in src and 'FusedRegistrar registrar' in src
+    # every g_out entry a reverse body reads is listed in its x block's fetch table
+    for line in re.findall(r'static const int32_t GOFF\d+_\d+\[16\] = \{([^}]*)\}', src):
+        vals = [int(v) for v in line.split(',')]
+        assert all(v == -1 or 0 <= v < dout for v in vals)
