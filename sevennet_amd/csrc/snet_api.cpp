@@ -78,8 +78,8 @@ int snet_conv_plan_create(const char *tag, snet_conv_plan **plan) {
     }
   }
   snet::set_error(std::string("snet_conv_plan_create: tensor-product shape '") + tag +
-                  "' is not compiled into libsnet_hip.so (register the model config in "
-                  "sevennet_amd/shapes.py and rebuild)");
+                  "' is not compiled into libsnet_hip.so (rebuild with the model's config: "
+                  "sevennet_amd.build.build(extra_configs=[config]), or register it in sevennet_amd/shapes.py)");
   return 3;
 }
 void snet_conv_plan_destroy(snet_conv_plan *plan) { delete plan; }
