@@ -42,6 +42,18 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (the split-precision products
 STEP_WORK = {'sevennet_0': (0.992e6, 44.5e6), 'sevennet_l3i5': (1.584e6, 119e6), 'sevennet_mf_ompa': (3.225e6, 305e6)}
 
 
+# what the path computes in: fp32 storage, accumulation, tensor product, gate, force reduction everywhere; the dense
+# contractions run on the matrix cores with every fp32 operand split into low-precision terms (fp32 accumulate)
+DTYPE_LABEL = {
+    0: 'f32 (storage / accumulate / tensor product; dense products as bf16x6 splits: fp32-rounding class)',
+    4: 'f32 (storage / accumulate / tensor product; in-kernel W2 products f16x3 = two fp16 terms per operand, '
+       'three matrix-core products: fp32-rounding class; node linears bf16x6)',
+    3: 'f32 (storage / accumulate / tensor product; in-kernel W2 products bf16x6: fp32-rounding class)',
+    2: 'f32 storage / accumulate; in-kernel W2 products bf16x3 (NOT fp32 class: up to 3.5e-4 eV/A at max|F| = 8 eV/A)',
+    1: 'f32 storage / accumulate; in-kernel W2 products plain bf16 (1e-2 relative)',
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -58,9 +70,10 @@ def parse():
     ap.add_argument('--fused', default='auto', choices=['auto', 'off', 'fwd', 'bwd'],
                     help="radial-MLP last layer inside the tensor-product kernels (w / g_w never materialised): "
                          "'auto' = forward and reverse (default), 'off' = separate kernels")
-    ap.add_argument('--terms', type=int, default=2, choices=[1, 2, 3],
-                    help='bf16 terms per operand of the fused in-kernel products: 2 = bf16x3 (engine default, force error vs fp64 '
-                         '6e-7 eV/A), 3 = bf16x6 (fp32-rounding class), 1 = plain bf16 (outside the 1e-4 eV/A bar)')
+    ap.add_argument('--terms', type=int, default=4, choices=[1, 2, 3, 4],
+                    help='precision mode of the fused in-kernel products: 4 = f16x3 (two fp16 terms per operand, three products; '
+                         'fp32-rounding class; engine default), 3 = bf16x6 (fp32-rounding class, six products), 2 = bf16x3 '
+                         '(outside the 1e-4 eV/A bar at MD-scale forces), 1 = plain bf16')
     ap.add_argument('--no-overlap', action='store_true', help='radial MLPs on the main stream (no second stream)')
     ap.add_argument('--halo', default='auto', choices=['auto', 'native', 'torch'],
                     help="N > 1: ghost exchange by libsnet_hip.so's own RCCL send/recv groups ('native', default with the "
@@ -87,9 +100,10 @@ def species_of(cfg, n_atoms):
 
 
 def kernel_model(ls, n_nodes, n_edges, mlp_tail=False, nb=8):
-    """Algorithmic bytes / flops per launch of each kernel class of one layer
-    (SURVEY.md §8(d) conventions: dst rows once per node, src rows once per edge,
-    radial weights NOT counted for the tensor-product kernels, no cache credit)."""
+    """Algorithmic bytes / flops per launch of each kernel class of one layer.
+    `bytes` is SURVEY.md section 8(d)'s count, literally: per edge fwd = 4 dx + 12 + 8, reverse = 2 * 4 dx + 12 + 8 + 12,
+    plus the destination rows once per node (4 dmid); radial weights NOT counted, no cache credit.  `bytes_incl_staging`
+    adds what the fused kernels really move besides (spherical harmonics and their Jacobian, h2, emb / g_emb rows)."""
     dx, dmid, wn = ls.conv.irreps_x.dim, ls.conv.irreps_out.dim, ls.conv.weight_numel
     nsh = ls.conv.irreps_sh.dim
     h = ls.mlp_dims
@@ -101,9 +115,11 @@ def kernel_model(ls, n_nodes, n_edges, mlp_tail=False, nb=8):
         f'conv_fwd[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 4 * nsh + 8) + n_nodes * 4 * dmid),
         # fused kernels: w = h2 @ W2 and g_h2 = g_w @ W2^T run inside (bf16 x terms products on the matrix cores);
         # per edge they move the source row, Y (+ its Jacobian), src / w_row, h2[64] (+ g_xe, g_h2, g_vec on the way back)
-        f'conv_fwd_fused[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 4 * nsh + 8 + 256) + n_nodes * 4 * dmid,
+        f'conv_fwd_fused[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 12 + 8) + n_nodes * 4 * dmid,
+                                               bytes_incl_staging=n_edges * (4 * dx + 4 * nsh + 8 + 256) + n_nodes * 4 * dmid,
                                                flops=2.0 * n_edges * 64 * wn),
-        f'conv_bwd_fused[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (2 * 4 * dx + 4 * 4 * nsh + 8 + bwd_mlp_bytes + 24) + n_nodes * 4 * dmid,
+        f'conv_bwd_fused[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (2 * 4 * dx + 12 + 8 + 12) + n_nodes * 4 * dmid,
+                                               bytes_incl_staging=n_edges * (2 * 4 * dx + 4 * 4 * nsh + 8 + bwd_mlp_bytes + 24) + n_nodes * 4 * dmid,
                                                flops=2.0 * 2.0 * n_edges * 64 * wn + bwd_tail_flops),
         f'conv_bwd_edge[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dx + 2 * 4 * nsh + 8) + n_nodes * 4 * dmid),
         f'conv_bwd_node[{ls.conv.tag}]': dict(bound='hbm', bytes=n_edges * (4 * dmid + 4 * nsh + 12) + n_nodes * 4 * dx),
@@ -123,10 +139,29 @@ def cpu_model_name():
     return 'unknown CPU'
 
 
+def physical_cores():
+    """distinct (package, core) pairs of /proc/cpuinfo (SMT siblings counted once); os.cpu_count() if unreadable"""
+    try:
+        seen, pkg = set(), None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('physical id'):
+                    pkg = line.split(':')[1].strip()
+                elif line.startswith('core id'):
+                    seen.add((pkg, line.split(':')[1].strip()))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(cfg, sd, reps):
-    """The oracle = this repo's CPU restatement of the reference's e3nn/PyTorch path, fp32, on a bounded
-    sample: >= 3 evaluations after one warm-up, about 30 s of CPU work at the default sample size
-    (6^3 cells = 1728 atoms; `--cpu-reps 11` times the 10 648-atom cell of BASELINE config 2, ~4 min)."""
+    """The oracle = this repo's CPU restatement of the reference's e3nn/PyTorch path, fp32, on a bounded sample
+    (default 6^3 cells = 1728 atoms; `--cpu-reps 11` times the 10 648-atom cell of BASELINE config 2, ~4 min).
+    Timed with BOTH thread counts SURVEY.md 8(d) names -- every physical core of the box, and the 32 threads that
+    were the best setting found for this eager many-small-ops workload -- two evaluations each after a warm-up;
+    the faster one is `value` with its thread count in `cores`, the other is reported next to it."""
     from oracle.model import OracleModel
     from sevennet_amd.neighbor import diamond_cubic, neighbor_list
     pos, cell = diamond_cubic(5.431, (reps,) * 3, 0.05, 2)
@@ -134,22 +169,27 @@ def cpu_baseline(cfg, sd, reps):
     types = species_of(cfg, len(pos))
     m = OracleModel(cfg, sd, dtype=torch.float32, modal='mpa' if cfg.get('use_modality') else None)
     default_threads = torch.get_num_threads()
-    # eager PyTorch on many small ops does not scale to every core: 32 threads were the best of {default, 32}
-    # on the 128-core host of the GPU box (round 1); the count actually used is reported in `cores`
-    threads = min(32, default_threads)
-    torch.set_num_threads(threads)
-    m.forward(types, ei, ev)  # warm-up
-    n_eval = 3
-    t0 = time.perf_counter()
-    for _ in range(n_eval):
-        m.forward(types, ei, ev)
-    dt = time.perf_counter() - t0
+    phys = physical_cores()
+    runs = {}
+    for threads in sorted({min(32, phys), phys}):
+        torch.set_num_threads(threads)
+        m.forward(types, ei, ev)  # warm-up
+        n_eval = 2
+        t0 = time.perf_counter()
+        for _ in range(n_eval):
+            m.forward(types, ei, ev)
+        dt = time.perf_counter() - t0
+        runs[threads] = (len(pos) * n_eval / dt, n_eval, dt)
     torch.set_num_threads(default_threads)
-    return dict(value=len(pos) * n_eval / dt, unit='atom-steps/s', cores=threads, kind='port', cpu=cpu_model_name(),
-                logical_cpus=os.cpu_count(),
+    best = max(runs, key=lambda k: runs[k][0])
+    rate, n_eval, dt = runs[best]
+    return dict(value=rate, unit='atom-steps/s', cores=best, kind='port', cpu=cpu_model_name(),
+                logical_cpus=os.cpu_count(), physical_cores=phys,
+                by_threads={str(k): round(v[0], 1) for k, v in runs.items()},
                 sample=f'SevenNet-0 shape, {len(pos)}-atom Si cell ({ei.shape[1]} edges), {n_eval} energy+force '
                        f'evaluations in {dt:.1f} s after one warm-up, fp32 torch CPU oracle (oracle/model.py), '
-                       f'{threads} torch threads on {cpu_model_name()} ({os.cpu_count()} logical CPUs)')
+                       f'{best} torch threads on {cpu_model_name()} ({phys} physical cores, {os.cpu_count()} logical CPUs); '
+                       f'atom-steps/s by thread count: ' + ', '.join(f'{k}: {v[0]:.0f}' for k, v in runs.items()))
 
 
 def main():
@@ -302,9 +342,14 @@ def main():
         ach = km['bytes'] / (avg_ms * 1e-3) / 1e9
         roof = dict(bound='hbm', kernel=dominant, achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=ach / HBM_PEAK_GBS, traffic=None, avg_ms=avg_ms,
-                    algorithmic_bytes_per_launch=km['bytes'])
+                    algorithmic_bytes_per_launch=km['bytes'],
+                    byte_model='SURVEY.md section 8(d): E (2*4*dx + 12 + 8 + 12) + N 4 dmid for a reverse launch, '
+                               'E (4 dx + 12 + 8) + N 4 dmid for a forward launch')
+        if 'bytes_incl_staging' in km:   # what the kernel really moves besides (Y, dY, h2, emb, g_emb): a second view
+            roof['frac_incl_staging'] = km['bytes_incl_staging'] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof['bytes_incl_staging_per_launch'] = km['bytes_incl_staging']
         if 'flops' in km:  # fused kernels also carry the radial MLP's last layer on the matrix cores
-            n_prod = {3: 6, 2: 3, 1: 1}[a.terms]
+            n_prod = {4: 3, 3: 6, 2: 3, 1: 1}[a.terms]
             roof['mfma'] = dict(algorithmic_flops_per_launch=km['flops'], bf16_products_per_flop=n_prod,
                                 achieved_tflops=km['flops'] * n_prod / (avg_ms * 1e-3) / 1e12, peak_tflops=MFMA_BF16_PEAK_TF,
                                 frac=km['flops'] * n_prod / (avg_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF)
@@ -356,7 +401,7 @@ def main():
             else f'atom-steps/sec (energy+forces), {a.model} shape',
             'value': n_atoms * a.steps / dt, 'unit': 'atom-steps/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': step_ms, 'higher_is_better': True, 'scaling': 'strong',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': DTYPE_LABEL[a.terms if a.fused != 'off' else 0], 'data': 'synthetic',
             'config': {'workload': f'{a.model} shape (5 interaction layers), {n_atoms}-atom periodic diamond-Si '
                                    f'cell (a=5.431 A x {a.reps}^3, {wl_note}), cutoff {cfg["cutoff"]} A, '
                                    f'{n_edges_total} directed edges, seeded synthetic weights',

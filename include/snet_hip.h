@@ -130,6 +130,11 @@ int snet_act_bwd(const float *z, const float *g_a, float *g_z, int64_t n, int32_
 typedef struct snet_conv_plan snet_conv_plan;
 int snet_conv_plan_create(const char *tag, snet_conv_plan **plan);
 void snet_conv_plan_destroy(snet_conv_plan *plan);
+/* Shapes are compiled ahead of time (sevennet_amd/shapes.py) or ON DEMAND: a shape library is a small .so holding
+ * the generated kernels of one or more shapes (python -m sevennet_amd.jit <irreps...>, sevennet_amd.jit.ensure_conv_shape,
+ * which the Python plug-in and engine call themselves for an unknown shape -- the reference's accelerator back ends JIT
+ * theirs the same way, convolution.py:237-247).  Loading it registers its shapes with this library. */
+int snet_conv_register_library(const char *path);
 int snet_conv_plan_dims(const snet_conv_plan *plan, int32_t *dx, int32_t *dout, int32_t *nsh, int32_t *wn);
 
 /* w_row (nullable, int32[E]): row of w that edge e reads.  NULL = edge e reads row e (the reference's
@@ -148,9 +153,14 @@ int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, c
  * the fly.  What crosses HBM per edge is h2[64] in and g_h2[64] out instead of w[wn] and g_w[wn].
  *   h2[R,64]   hidden activations a2 of the MLP (snet_radial_mlp_hidden_fwd), R = edges or undirected
  *              pairs; edge e reads row w_row[e] (NULL: row e)
- *   terms      bf16 terms per operand of the in-kernel products: 2 = bf16x3 (a0b0 + a0b1 + a1b0, ~2^-16 relative per
- *              product; the default of both hosts: whole-model force error vs fp64 6e-7 eV/A against 2e-7 for the
- *              fp32-class paths), 3 = bf16x6 (fp32-rounding class), 1 = plain bf16 (~4e-4 eV/A: outside the 1e-4 bar)
+ *   terms      precision mode of the in-kernel products (both operands split into low-precision terms, fp32 accumulate):
+ *              4 = f16x3 (default of both hosts): two fp16 terms per operand, hi*hi + hi*lo + lo*hi on
+ *              v_mfma_f32_16x16x32_f16, operands scaled by powers of two (W2 per matrix at plan creation, h2 / g_w per
+ *              16-edge tile in the kernel) -- 22 significand bits per operand: fp32-rounding class;
+ *              3 = bf16x6 (three bf16 terms, six products: fp32-rounding class at twice the matrix-core work);
+ *              2 = bf16x3 (two bf16 terms: ~2^-17 per product; whole-model force error at max|F| = 8 eV/A up to
+ *              3.5e-4 eV/A, i.e. outside the 1e-4 bar -- kept for throughput comparisons);
+ *              1 = plain bf16 (1e-2 relative)
  *   tile_ptr   int32[n_dst+1], exclusive scan of ceil(degree/16), and tile_node int32[n_tiles] (tile -> node), both
  *              from snet_edge_tiles: the reverse kernel gives each 16-edge tile of a node's CSR segment to one
  *              wavefront (tile_node capacity: n_dst + n_edges / 16 entries always suffice)
@@ -160,8 +170,9 @@ int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, c
  *   g_emb[E,nb] ACCUMULATED: the kernel also reverses the MLP's two hidden layers per 16-edge tile (it reads
  *               emb[E,nb], the radial basis values per DIRECTED edge), so g_h2 never reaches memory either.
  *               Needs snet_fused_plan_has_mlp_tail(plan) != 0 (n_basis <= 16 and a multiple of 4).
+ * x_rowmax[n_rows of x] / g_rowmax[n_dst]: snet_row_absmax of x and g_out; required for terms = 4, ignored (NULL) otherwise.
  * snet_conv_fused_available() != 0 iff the shape has these kernels (channel multiplicities % 16 == 0). */
-#define SNET_FUSED_TERMS_DEFAULT 2
+#define SNET_FUSED_TERMS_DEFAULT 4
 typedef struct snet_fused_plan snet_fused_plan;
 int snet_radial_mlp_hidden_fwd(const snet_mlp_plan *plan, const float *emb, int64_t n_edges, float *h2, void *stream);
 int snet_radial_mlp_hidden_bwd(const snet_mlp_plan *plan, const float *emb, const float *g_h2, int64_t n_edges,
@@ -178,8 +189,12 @@ int snet_conv_bwd_fused(const snet_fused_plan *plan, const float *x, const float
                         const float *h2, const int32_t *w_row, const int32_t *row_ptr, const int32_t *src,
                         const int32_t *tile_ptr, const int32_t *tile_node, int64_t n_tiles, float scale,
                         const float *g_out, float *g_xe, float *g_h2, const float *emb, float *g_emb, float *g_vec,
-                        void *stream);
+                        const float *x_rowmax, const float *g_rowmax, void *stream);
 int snet_fused_plan_has_mlp_tail(const snet_fused_plan *plan);
+/* out[r] = max_k |x[r,k]| for r < n_rows.  The f16x3 reverse kernel (terms = 4) scales its fp16 operand g_w per edge by a
+ * power of two derived from a BOUND of |g_w| -- (sum |C|) max|g_out[node]| max|x[src]| max|Y_e| -- so that no entry can
+ * overflow fp16 whatever the model's feature magnitudes are; the two row maxima come from this kernel. */
+int snet_row_absmax(const float *x, int64_t n_rows, int32_t dim, float *out, void *stream);
 /* per-edge gradients given g_out[n_dst,dout]: g_w[E,wn] (overwritten), g_sh[E,nsh] (ACCUMULATED,
  * so one buffer collects all layers) and, if g_xe != NULL, this edge's contribution to the gradient
  * of its source row, g_xe[E,dx] (overwritten; sum it per source node with snet_segment_sum_rows --

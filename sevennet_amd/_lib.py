@@ -62,6 +62,7 @@ SIGNATURES = {
     'snet_act_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_stream]),
     'snet_conv_plan_create': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     'snet_conv_plan_destroy': (None, [C.c_void_p]),
+    'snet_conv_register_library': (C.c_int, [C.c_char_p]),
     'snet_conv_plan_dims': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'snet_conv_fwd': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_float,
@@ -75,8 +76,10 @@ SIGNATURES = {
     'snet_conv_fwd_fused': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_float,
                                       c_f32p, c_stream]),
     'snet_conv_bwd_fused': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, c_i32p,
-                                      c_i32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+                                      c_i32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                      c_stream]),
     'snet_fused_plan_has_mlp_tail': (C.c_int, [C.c_void_p]),
+    'snet_row_absmax': (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, c_stream]),
     'snet_conv_bwd_edge': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_float,
                                      c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     'snet_segment_sum_rows': (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, c_f32p, c_stream]),

@@ -82,6 +82,103 @@ def _emit_staging(A, lines: str):
     A('  };')
 
 
+def reverse_plan(p):
+    """Nonzero pattern the reverse tensor-product body walks: per x component a, per output component c,
+    the spherical-harmonic components b it couples with and C[a,b,c] (incl. the sqrt(2 l3 + 1) path norm)."""
+    plan: Dict[int, Dict[int, List[tuple]]] = {}
+    for a, b, c, v in _path_terms(p):
+        plan.setdefault(a, {}).setdefault(c, []).append((b, v))
+    return [(a, sorted(cd.items())) for a, cd in sorted(plan.items())]
+
+
+def reverse_body_reference(p, x, y, w, G):
+    """NumPy statement of exactly the arithmetic `_emit_reverse_body` generates for one (edge, channel):
+    x[2 l1 + 1], y[nsh] (all spherical harmonics of the edge), w scalar, G[2 l3 + 1] -> (g_w, g_y[nsh], g_x[2 l1 + 1]).
+    Checked against the dense contraction in tests/test_codegen_fused_cpu.py."""
+    import numpy as np
+    gy = np.zeros(len(y))
+    gx = np.zeros(2 * p.l1 + 1)
+    gw = 0.0
+    for a, cl in reverse_plan(p):
+        wx = w * x[a]
+        P = 0.0
+        for c, bl in cl:
+            V = sum(v * y[p.sh_off + b] for b, v in bl)      # contraction of C with the edge's harmonics: per edge, not per channel
+            P += V * G[c]
+            s = wx * G[c]                                    # (summed over the lane's channels in the kernel)
+            for b, v in bl:
+                gy[p.sh_off + b] += v * s
+        gw += x[a] * P
+        gx[a] += w * P
+    return gw, gy, gx
+
+
+def _emit_reverse_body(A, pi, p):
+    """Reverse tensor product of one path for a lane's 4 channels (lane = edge).  The Clebsch-Gordan tensor is
+    contracted with the edge's spherical harmonics FIRST (V_ac = sum_b C_abc Y_b: per edge, shared by the 4 channels),
+    so the per-channel work is two multiply-adds per nonzero (a, c) pair instead of one per nonzero C_abc plus four
+    per (a, b) pair:   P_a = sum_c V_ac G_c;  g_w = sum_a x_a P_a;  g_x_a += w P_a;
+                       g_Y_b += sum_ac C_abc s_ac  with  s_ac = sum_channels (w x_a) G_c   (one dot product per (a, c)).
+    SevenNet-0 middle layer: 6 340 instead of 9 584 vector instructions per 16-edge tile; lmax-3 shapes gain more."""
+    d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
+    A(f'__device__ __forceinline__ void bwdf_p{pi}(const f32x4 (&xr)[{d1}], const float (&ys)[NSH], const f32x4 w,')
+    A(f'    const f32x4 (&G)[{d3}], f32x4 &gw, float (&gy)[NSH], f32x4 (&gx)[{d1}]) {{')
+    A('  float gw0 = 0.f, gw1 = 0.f, gw2 = 0.f, gw3 = 0.f;')
+    for a, cl in reverse_plan(p):
+        A(f'  {{  // x component {a}')
+        for r in range(4):
+            A(f'    const float wx{r} = w[{r}] * xr[{a}][{r}];')
+        A('    float P0, P1, P2, P3;')
+        for k, (c, bl) in enumerate(cl):
+            tl = [f'{_f(v)} * ys[{p.sh_off + b}]' for b, v in bl]
+            A(f'    {{ const float V = {_sum_expr(tl)};')
+            for r in range(4):
+                A(f'      P{r} = ' + (f'V * G[{c}][{r}];' if k == 0 else f'fmaf(V, G[{c}][{r}], P{r});'))
+            A(f'      const float s = fmaf(wx3, G[{c}][3], fmaf(wx2, G[{c}][2], fmaf(wx1, G[{c}][1], wx0 * G[{c}][0])));')
+            for b, v in bl:
+                A(f'      gy[{p.sh_off + b}] = fmaf({_f(v)}, s, gy[{p.sh_off + b}]);')
+            A('    }')
+        for r in range(4):
+            A(f'    gw{r} = fmaf(xr[{a}][{r}], P{r}, gw{r});')
+            A(f'    gx[{a}][{r}] = fmaf(w[{r}], P{r}, gx[{a}][{r}]);')
+        A('  }')
+    A('  gw = f32x4{gw0, gw1, gw2, gw3};')
+    A('}')
+
+
+def _emit_reverse_body_v1(A, pi, p, terms, byab):
+    """round-2 formulation (SNET_CODEGEN_OPTS=tpold=1, kept for A/B runs): one (a, b) entry at a time,
+    U_ab = sum_c C[a,b,c] G_c consumed at once by the three products it feeds (g_w, d/dY_b, d/dx_a)"""
+    d1, d2, d3 = 2 * p.l1 + 1, 2 * p.l2 + 1, 2 * p.l3 + 1
+    A(f'__device__ __forceinline__ void bwdf_p{pi}(const f32x4 (&xr)[{d1}], const float (&ys)[NSH], const f32x4 w,')
+    A(f'    const f32x4 (&G)[{d3}], f32x4 &gw, float (&gy)[NSH], f32x4 (&gx)[{d1}]) {{')
+    for r in range(4):
+        A(f'  {{  // channel {r} of the lane\'s group')
+        A('    float gw_ = 0.f;')
+        for i in range(d2):
+            A(f'    float sy{i} = 0.f;')
+        for i in range(d1):
+            A(f'    float sx{i} = 0.f;')
+        for (a_, b_), cl in sorted(byab.items()):
+            yb = p.sh_off + b_
+            tl = [f'{_f(v)} * G[{cc}][{r}]' for cc, v in cl]
+            A('    {')
+            A(f'      const float U = {_sum_expr(tl)};')
+            A(f'      const float t = U * xr[{a_}][{r}];')
+            A(f'      gw_ = fmaf(t, ys[{yb}], gw_);')
+            A(f'      sy{b_} += t;')
+            A(f'      sx{a_} = fmaf(U, ys[{yb}], sx{a_});')
+            A('    }')
+        A(f'    gw[{r}] = gw_;')
+        A(f'    const float w_ = w[{r}];')
+        for b_ in sorted({b_ for (_, b_) in byab}):
+            A(f'    gy[{p.sh_off + b_}] = fmaf(w_, sy{b_}, gy[{p.sh_off + b_}]);')
+        for a_ in sorted({a_ for (a_, _) in byab}):
+            A(f'    gx[{a_}][{r}] = fmaf(w_, sx{a_}, gx[{a_}][{r}]);')
+        A('  }')
+    A('}')
+
+
 def gen_conv_fused(spec: ConvSpec) -> str:
     tag = spec.tag
     # default configuration of the two kernels: (waves per workgroup, direct global->LDS staging, waves per SIMD the
@@ -123,39 +220,14 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         terms = _path_terms(p)
         # ---- reverse: lane = edge, 4 channels in the vector components
         A(f'// path {pi}: ({p.l1} x {p.l2} -> {p.l3})')
-        A(f'__device__ __forceinline__ void bwdf_p{pi}(const f32x4 (&xr)[{d1}], const float (&ys)[NSH], const f32x4 w,')
-        A(f'    const f32x4 (&G)[{d3}], f32x4 &gw, float (&gy)[NSH], f32x4 (&gx)[{d1}]) {{')
         d2 = 2 * p.l2 + 1
         byab: Dict[tuple, List[tuple]] = {}
         for a_, b_, cc, v in terms:
             byab.setdefault((a_, b_), []).append((cc, v))
-        for r in range(4):
-            # one (a, b) entry at a time: U_ab = sum_c C[a,b,c] G_c is consumed at once by the three products
-            # it feeds (g_w, d/dY_b, d/dx_a), so only d1 + d2 + 1 partial sums stay live
-            A(f'  {{  // channel {r} of the lane\'s group')
-            A('    float gw_ = 0.f;')
-            for i in range(d2):
-                A(f'    float sy{i} = 0.f;')
-            for i in range(d1):
-                A(f'    float sx{i} = 0.f;')
-            for (a_, b_), cl in sorted(byab.items()):
-                yb = p.sh_off + b_
-                tl = [f'{_f(v)} * G[{cc}][{r}]' for cc, v in cl]
-                A('    {')
-                A(f'      const float U = {_sum_expr(tl)};')
-                A(f'      const float t = U * xr[{a_}][{r}];')
-                A(f'      gw_ = fmaf(t, ys[{yb}], gw_);')
-                A(f'      sy{b_} += t;')
-                A(f'      sx{a_} = fmaf(U, ys[{yb}], sx{a_});')
-                A('    }')
-            A(f'    gw[{r}] = gw_;')
-            A(f'    const float w_ = w[{r}];')
-            for b_ in sorted({b_ for (_, b_) in byab}):
-                A(f'    gy[{p.sh_off + b_}] = fmaf(w_, sy{b_}, gy[{p.sh_off + b_}]);')
-            for a_ in sorted({a_ for (a_, _) in byab}):
-                A(f'    gx[{a_}][{r}] = fmaf(w_, sx{a_}, gx[{a_}][{r}]);')
-            A('  }')
-        A('}')
+        if not OPTS.get('tpold'):
+            _emit_reverse_body(A, pi, p)
+        else:
+            _emit_reverse_body_v1(A, pi, p, terms, byab)
         # ---- forward: lane = channel, the 4 edges of the lane's group in the vector components
         A(f'__device__ __forceinline__ void fwdf_p{pi}(const float (&xr)[4][{d1}], const float *ysl, const f32x4 w,')
         A(f'    float (&acc)[{d3}]) {{')
@@ -177,7 +249,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('')
 
     # ------------------------------------------------------------------ reverse kernel
-    A('template <int NT, int NWV, bool GLDS, int OCC>')
+    A('template <int NT, bool F16, int NWV, bool GLDS, int OCC>')
     A(f'__global__ __launch_bounds__(64 * NWV, OCC) void conv_bwdf_{tag}(const float *__restrict__ x, const float *__restrict__ sh,')
     A('    const float *__restrict__ dsh, const float *__restrict__ h2, const int32_t *__restrict__ w_row,')
     A('    const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ src, const int32_t *__restrict__ tile_ptr,')
@@ -239,6 +311,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  const int e = e0 + min(j, cnt - 1);')
     A('  const int s_src = src[e];')
     A('  const int wr = w_row ? w_row[e] : e;')
+    A('  float x_bound = 0.f;')
+    A('  if constexpr (F16) x_bound = tail.x_max[s_src] * tail.g_max[node];')
     _c0 = cats[0]
     A(f'  const float *xs0 = x + (size_t)s_src * DX + {_c0.x_off} + 4 * g;')
     A(f'  f32x4 xr0[{2 * _c0.l1 + 1}], xn0[{2 * _c0.l1 + 1}];')
@@ -253,12 +327,27 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  }')
     A('  const float *yl = &s_y[wave][j];')
     A('  SplitN<NT> hb[2];  // h2^T as B operand: column = edge, k slots (g, 0..7) <-> hidden unit 32 q + 8 g + slot')
+    A('  float w_unscale = 1.f;  // fp16 terms: h2 is scaled per tile (wave-uniform power of two), W2 per matrix on the host')
+    A('  {')
+    A('    float hv[2][8];')
     A('#pragma unroll')
-    A('  for (int q = 0; q < 2; ++q) {')
-    A('    const f32x4 lo4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wr * 64 + 32 * q + 8 * g);')
-    A('    const f32x4 hi4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wr * 64 + 32 * q + 8 * g + 4);')
-    A('    const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};')
-    A('    hb[q] = splitn8<NT>(v);')
+    A('    for (int q = 0; q < 2; ++q) {')
+    A('      const f32x4 lo4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wr * 64 + 32 * q + 8 * g);')
+    A('      const f32x4 hi4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wr * 64 + 32 * q + 8 * g + 4);')
+    A('#pragma unroll')
+    A('      for (int i = 0; i < 4; ++i) { hv[q][i] = lo4[i]; hv[q][4 + i] = hi4[i]; }')
+    A('    }')
+    A('    if constexpr (F16) {')
+    A('      const int kh = snet::F16_TOP - snet::bound_exp(snet::wave_max(fmaxf(snet::max8(hv[0]), snet::max8(hv[1]))));')
+    A('      const float sc = snet::pow2f(kh);')
+    A('#pragma unroll')
+    A('      for (int q = 0; q < 2; ++q)')
+    A('#pragma unroll')
+    A('        for (int i = 0; i < 8; ++i) hv[q][i] *= sc;')
+    A('      w_unscale = snet::pow2f(-(kh + tail.w2_exp));')
+    A('    }')
+    A('    hb[0] = splitn8<NT, F16>(hv[0]);')
+    A('    hb[1] = splitn8<NT, F16>(hv[1]);')
     A('  }')
     A('  f32x4 ga[4];  // g_h2^T[k = 16 m + 4 g + r][edge]')
     A('#pragma unroll')
@@ -269,6 +358,19 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     emit_g_park('  ', 0, '0')
     A('  stage_store(0);')
     A('  __syncthreads();')
+    # fp16 terms, g_h2 += W2 g_w^T: the operand g_w[edge, channel] = sum_abc C_abc G_c x_a Y_b of a path is bounded by
+    # (sum |C|) max|G| max|x| max|Y|; every edge (= operand column = lane) scales its g_w by the power of two that puts
+    # this bound below 2^F16_TOP -- no entry can overflow fp16, and entries down to 2^-17 of the bound keep all 22 bits
+    KC = max(sum(abs(v) for _, _, _, v in _path_terms(p)) for p in spec.paths)
+    A('  float g_sc = 1.f, g_unsc = 1.f;')
+    A('  if constexpr (F16) {')
+    A('    float ym = 0.f;')
+    A('#pragma unroll')
+    A('    for (int k = 0; k < NSH; ++k) ym = fmaxf(ym, fabsf(yl[k * 16]));')
+    A(f'    const int kg = snet::F16_TOP - snet::bound_exp({_f(KC)} * fabsf(scale) * x_bound * ym);')
+    A('    g_sc = snet::pow2f(kg);')
+    A('    g_unsc = snet::pow2f(-(kg + tail.w2_exp));')
+    A('  }')
     A('  int sidx = 0, buf = 0, gbuf = 0;')
     for ci, cat in enumerate(cats):
         d1 = 2 * cat.l1 + 1
@@ -323,8 +425,9 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                     A('        bf16x8 a[NT];')
                     A('#pragma unroll')
                     A(f'        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
-                    A(f'        wv{tp} = mfma16_split<NT>(a, hb[q], wv{tp});')
+                    A(f'        wv{tp} = mfma16_split<NT, F16>(a, hb[q], wv{tp});')
                     A('      }')
+                    A(f'      if constexpr (F16) wv{tp} *= w_unscale;')
             if gpf:
                 A('      bf16x8 ag[4][NT];')
                 A('#pragma unroll')
@@ -350,8 +453,9 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                     A('          bf16x8 a[NT];')
                     A('#pragma unroll')
                     A(f'          for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
-                    A('          wv = mfma16_split<NT>(a, hb[q], wv);')
+                    A('          wv = mfma16_split<NT, F16>(a, hb[q], wv);')
                     A('        }')
+                    A('        if constexpr (F16) wv *= w_unscale;')
                 A(f'        f32x4 G[{d3}];')
                 for m3 in range(d3):
                     A(f'        G[{m3}] = *reinterpret_cast<const f32x4 *>(gl_ + {g_row(ci, pi, m3)} * 16);')
@@ -364,19 +468,23 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A(f'        gw{tp} = f32x4{{0.f, 0.f, 0.f, 0.f}};')
                 A(f'        if (!(diag & 1)) bwdf_p{pi}(xr, ys, wv, G, gw{tp}, gy, gx);')
                 A('      }')
-            A('      const float v[8] = {gw0[0], gw0[1], gw0[2], gw0[3], gw1[0], gw1[1], gw1[2], gw1[3]};')
-            A('      const SplitN<NT> b = splitn8<NT>(v);')
+            A('      float v[8] = {gw0[0], gw0[1], gw0[2], gw0[3], gw1[0], gw1[1], gw1[2], gw1[3]};')
+            A('      if constexpr (F16) {')
+            A('#pragma unroll')
+            A('        for (int i = 0; i < 8; ++i) v[i] *= g_sc;')
+            A('      }')
+            A('      const SplitN<NT> b = splitn8<NT, F16>(v);')
             if exp:
                 A('      if (diag & 2) ga[0] += f32x4{v[0], v[1], v[4], v[5]}; else')
             A('#pragma unroll')
             A('      for (int m = 0; m < 4; ++m) {')
             if gpf:
-                A('        ga[m] = mfma16_split<NT>(ag[m], b, ga[m]);')
+                A('        ga[m] = mfma16_split<NT, F16>(ag[m], b, ga[m]);')
             else:
                 A('        bf16x8 a[NT];')
                 A('#pragma unroll')
                 A('        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
-                A('        ga[m] = mfma16_split<NT>(a, b, ga[m]);')
+                A('        ga[m] = mfma16_split<NT, F16>(a, b, ga[m]);')
             A('      }')
             A('      if (sidx + 1 < NS' + (' && !(diag & 32)' if exp else '') + ') stage_store(buf ^ 1);')
             A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
@@ -413,6 +521,10 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A(f'    for (int q = 4 * g; q < {mul_d * (2 * l_d + 1)}; q += 16)')
             A(f'      *reinterpret_cast<f32x4 *>(g_xe + (size_t)e * DX + {offs_x[i]} + q) = f32x4{{0.f, 0.f, 0.f, 0.f}};')
         A('  }')
+    A('  if constexpr (F16) {  // back to g_h2 itself')
+    A('#pragma unroll')
+    A('    for (int m = 0; m < 4; ++m) ga[m] *= g_unsc;')
+    A('  }')
     A('  if (tail.g_emb == nullptr) {')
     A('    if (valid) {')
     A('#pragma unroll')
@@ -443,6 +555,32 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    };')
     A('    const int nb = tail.nb, act = tail.act;')
     A('    const float cst = tail.cst;')
+    A('    // fp16 terms: every dynamic operand of the tail is scaled by a wave-uniform power of two (its largest magnitude')
+    A('    // in the tile lands below 2^F16_TOP), the result is multiplied by the inverse together with the weight matrix\'s')
+    A('    auto scale8 = [&](float (&q)[8]) -> int {')
+    A('      const int k = snet::F16_TOP - snet::bound_exp(snet::wave_max(snet::max8(q)));')
+    A('      const float sc = snet::pow2f(k);')
+    A('#pragma unroll')
+    A('      for (int i = 0; i < 8; ++i) q[i] *= sc;')
+    A('      return k;')
+    A('    };')
+    A('    auto scale16 = [&](f32x4 (&q)[4]) -> int {')
+    A('      float m = 0.f;')
+    A('#pragma unroll')
+    A('      for (int i = 0; i < 4; ++i)')
+    A('#pragma unroll')
+    A('        for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(q[i][r]));')
+    A('      const int k = snet::F16_TOP - snet::bound_exp(snet::wave_max(m));')
+    A('      const float sc = snet::pow2f(k);')
+    A('#pragma unroll')
+    A('      for (int i = 0; i < 4; ++i) q[i] *= sc;')
+    A('      return k;')
+    A('    };')
+    A('    auto unscale16 = [&](f32x4 (&q)[4], int k) {')
+    A('      const float us = snet::pow2f(-k);')
+    A('#pragma unroll')
+    A('      for (int i = 0; i < 4; ++i) q[i] *= us;')
+    A('    };')
     A('    float ev[8];')
     A('#pragma unroll')
     A('    for (int t = 0; t < 8; t += 4) {')
@@ -450,16 +588,19 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('      if (8 * g + t < nb) q = *reinterpret_cast<const f32x4 *>(tail.emb + (size_t)e * nb + 8 * g + t);')
     A('      ev[t] = q[0]; ev[t + 1] = q[1]; ev[t + 2] = q[2]; ev[t + 3] = q[3];')
     A('    }')
-    A('    const SplitN<NT> eb = splitn8<NT>(ev);')
+    A('    int k_e = 0;')
+    A('    if constexpr (F16) k_e = scale8(ev);')
+    A('    const SplitN<NT> eb = splitn8<NT, F16>(ev);')
     A('    __syncthreads();')
     A('    f32x4 z1[4], z2[4];')
     A('#pragma unroll')
     A('    for (int m = 0; m < 4; ++m) {')
     A('      bf16x8 a[NT];')
     A('      frag(m, a);')
-    A('      z1[m] = mfma16_split<NT>(a, eb, f32x4{0.f, 0.f, 0.f, 0.f});')
+    A('      z1[m] = mfma16_split<NT, F16>(a, eb, f32x4{0.f, 0.f, 0.f, 0.f});')
     A('      z2[m] = f32x4{0.f, 0.f, 0.f, 0.f};')
     A('    }')
+    A('    if constexpr (F16) unscale16(z1, k_e + tail.w0_exp);')
     A('    f32x4 a1[4], d1[4];  // act(z1) cst and cst act\'(z1): one sigmoid for both')
     A('#pragma unroll')
     A('    for (int m = 0; m < 4; ++m)')
@@ -470,55 +611,69 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('        a1[m][r] = f_ * cst;')
     A('        d1[m][r] = g_ * cst;')
     A('      }')
+    A('    int k_a = 0;')
+    A('    if constexpr (F16) k_a = scale16(a1);')
     A('#pragma unroll')
     A('    for (int s = 0; s < 2; ++s) {')
     A('      float v[8];')
     A('#pragma unroll')
     A('      for (int t = 0; t < 8; ++t) v[t] = a1[2 * s + (t >> 2)][t & 3];')
-    A('      const SplitN<NT> b = splitn8<NT>(v);')
+    A('      const SplitN<NT> b = splitn8<NT, F16>(v);')
     A('#pragma unroll')
     A('      for (int m = 0; m < 4; ++m) {')
     A('        bf16x8 a[NT];')
     A('        frag(4 + 2 * m + s, a);')
-    A('        z2[m] = mfma16_split<NT>(a, b, z2[m]);')
+    A('        z2[m] = mfma16_split<NT, F16>(a, b, z2[m]);')
     A('      }')
     A('    }')
+    A('    if constexpr (F16) unscale16(z2, k_a + tail.w1_exp);')
     A('    __syncthreads();  // every wave is done with the phase-1 fragments')
     A('#pragma unroll')
     A('    for (int i = 0; i < NSB; ++i)')
     A('      if ((TB * 64) % NTH == 0 || tid + NTH * i < TB * 64) tl[tid + NTH * i] = sb[i];')
     A('    __syncthreads();')
-    A('    f32x4 ga1[4];')
+    A('    f32x4 ga1[4], gz[4];  // gz = dE/dz2 = g_h2 cst act\'(z2)')
     A('#pragma unroll')
-    A('    for (int m = 0; m < 4; ++m) ga1[m] = f32x4{0.f, 0.f, 0.f, 0.f};')
+    A('    for (int m = 0; m < 4; ++m) {')
+    A('      ga1[m] = f32x4{0.f, 0.f, 0.f, 0.f};')
+    A('#pragma unroll')
+    A('      for (int r = 0; r < 4; ++r) {')
+    A('        float f_, g_;')
+    A('        snet::act_both_fast(z2[m][r], act, f_, g_);')
+    A('        gz[m][r] = ga[m][r] * cst * g_;')
+    A('      }')
+    A('    }')
+    A('    int k_z = 0;')
+    A('    if constexpr (F16) k_z = scale16(gz);')
     A('#pragma unroll')
     A('    for (int s = 0; s < 2; ++s) {')
     A('      float v[8];')
     A('#pragma unroll')
-    A('      for (int t = 0; t < 8; ++t) {')
-    A('        float f_, g_;')
-    A('        snet::act_both_fast(z2[2 * s + (t >> 2)][t & 3], act, f_, g_);')
-    A('        v[t] = ga[2 * s + (t >> 2)][t & 3] * cst * g_;')
-    A('      }')
-    A('      const SplitN<NT> b = splitn8<NT>(v);')
+    A('      for (int t = 0; t < 8; ++t) v[t] = gz[2 * s + (t >> 2)][t & 3];')
+    A('      const SplitN<NT> b = splitn8<NT, F16>(v);')
     A('#pragma unroll')
     A('      for (int m = 0; m < 4; ++m) {')
     A('        bf16x8 a[NT];')
     A('        frag(2 * m + s, a);')
-    A('        ga1[m] = mfma16_split<NT>(a, b, ga1[m]);')
+    A('        ga1[m] = mfma16_split<NT, F16>(a, b, ga1[m]);')
     A('      }')
     A('    }')
+    A('#pragma unroll')
+    A('    for (int m = 0; m < 4; ++m) ga1[m] *= d1[m];  // dE/dz1 (fp16 terms: still times 2^(k_z + w1_exp))')
+    A('    int k_d = 0;')
+    A('    if constexpr (F16) k_d = scale16(ga1);')
     A('    f32x4 ge = f32x4{0.f, 0.f, 0.f, 0.f};')
     A('#pragma unroll')
     A('    for (int s = 0; s < 2; ++s) {')
     A('      float v[8];')
     A('#pragma unroll')
-    A('      for (int t = 0; t < 8; ++t) v[t] = ga1[2 * s + (t >> 2)][t & 3] * d1[2 * s + (t >> 2)][t & 3];')
-    A('      const SplitN<NT> b = splitn8<NT>(v);')
+    A('      for (int t = 0; t < 8; ++t) v[t] = ga1[2 * s + (t >> 2)][t & 3];')
+    A('      const SplitN<NT> b = splitn8<NT, F16>(v);')
     A('      bf16x8 a[NT];')
     A('      frag(8 + s, a);')
-    A('      ge = mfma16_split<NT>(a, b, ge);')
+    A('      ge = mfma16_split<NT, F16>(a, b, ge);')
     A('    }')
+    A('    if constexpr (F16) ge *= snet::pow2f(-(k_z + tail.w1_exp + k_d + tail.w0_exp));')
     A('    if (valid && 4 * g < nb) {  // accumulator rows 4 g + r = basis index')
     A('      f32x4 *o = reinterpret_cast<f32x4 *>(tail.g_emb + (size_t)e * nb + 4 * g);')
     A('      *o = *o + ge;')
@@ -562,10 +717,10 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     NOE = max(sum(2 * spec.paths[pi].l3 + 1 for _, pr in grp for pi in pr if pi is not None) for gl in fgroups for grp in gl)
     NOEP = (NOE + 15) // 16 * 16
     MAXD1 = max(2 * cat.l1 + 1 for cat in cats)
-    A('template <int NT, int NWV, bool GLDS, int OCC>')
+    A('template <int NT, bool F16, int NWV, bool GLDS, int OCC>')
     A(f'__global__ __launch_bounds__(64 * NWV, OCC) void conv_fwdf_{tag}(const float *__restrict__ x, const float *__restrict__ sh,')
     A('    const float *__restrict__ h2, const int32_t *__restrict__ w_row, const int32_t *__restrict__ row_ptr,')
-    A('    const int32_t *__restrict__ src, int n_nodes, const u32x4 *__restrict__ slabs, float scale, float *__restrict__ out, int diag) {')
+    A('    const int32_t *__restrict__ src, int n_nodes, const u32x4 *__restrict__ slabs, float scale, float *__restrict__ out, int w2_exp, int diag) {')
     A(f'  constexpr int LPS = 8 * NT, LPF = 4 * NT, LPB = {LPB}, NTH = 64 * NWV;  // lines per sub-step (all / w part), sub-steps per block')
     A('  constexpr int NSTB = (LPB * LPF * 64 + NTH - 1) / NTH;')
     A('  __shared__ u32x4 slab[2][LPB * LPF * 64];')
@@ -627,10 +782,12 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    // per tile: A fragments of h2 (row = edge lane & 15) and the source row this lane stages (edge lane >> 2)')
     A('    SplitN<NT> ha[2][2];')
     A('    int srs[2];')
+    A('    float w_unscale[2] = {1.f, 1.f};  // fp16 terms: h2 is scaled per 16-edge tile (wave-uniform), W2 per matrix on the host')
     A('#pragma unroll')
     A('    for (int tl = 0; tl < 2; ++tl) {')
     A('      const int ea = min(eb + 16 * tl + c, e_last);')
     A('      const int wra = has_e ? (w_row ? w_row[ea] : ea) : 0;')
+    A('      float hv[2][8];')
     A('#pragma unroll')
     A('      for (int q = 0; q < 2; ++q) {')
     A('        f32x4 lo4 = f32x4{0.f, 0.f, 0.f, 0.f}, hi4 = lo4;')
@@ -638,9 +795,20 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('          lo4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wra * 64 + 32 * q + 8 * g);')
     A('          hi4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wra * 64 + 32 * q + 8 * g + 4);')
     A('        }')
-    A('        const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};')
-    A('        ha[tl][q] = splitn8<NT>(v);')
+    A('#pragma unroll')
+    A('        for (int i = 0; i < 4; ++i) { hv[q][i] = lo4[i]; hv[q][4 + i] = hi4[i]; }')
     A('      }')
+    A('      if constexpr (F16) {')
+    A('        const int kh = snet::F16_TOP - snet::bound_exp(snet::wave_max(fmaxf(snet::max8(hv[0]), snet::max8(hv[1]))));')
+    A('        const float sc = snet::pow2f(kh);')
+    A('#pragma unroll')
+    A('        for (int q = 0; q < 2; ++q)')
+    A('#pragma unroll')
+    A('          for (int i = 0; i < 8; ++i) hv[q][i] *= sc;')
+    A('        w_unscale[tl] = snet::pow2f(-(kh + w2_exp));')
+    A('      }')
+    A('      ha[tl][0] = splitn8<NT, F16>(hv[0]);')
+    A('      ha[tl][1] = splitn8<NT, F16>(hv[1]);')
     A('      srs[tl] = has_e ? src[min(eb + 16 * tl + (lane >> 2), e_last)] : 0;')
     A('    }')
     A('    for (int i = lane; i < 32 * NSH; i += 64) {')
@@ -757,8 +925,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                             A('            for (int tm = 0; tm < NT; ++tm) b1[tm] = bn1[tm];')
                         else:
                             frag_reads('            ', k, 1, 'b1')
-                        A(f'            wv = mfma16_split<NT>(ha[{tl}][0], b0, wv);')
-                        A(f'            wv = mfma16_split<NT>(ha[{tl}][1], b1, wv);')
+                        A(f'            wv = mfma16_split<NT, F16>(ha[{tl}][0], b0, wv);')
+                        A(f'            wv = mfma16_split<NT, F16>(ha[{tl}][1], b1, wv);')
                         if k + 1 < len(chain):
                             A('#pragma unroll')
                             frag_reads('            ', k + 1, 0, 'bn0')
@@ -772,10 +940,10 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                         A('              bf16x8 bfr[NT];')
                         A('#pragma unroll')
                         A(f'              for (int tm = 0; tm < NT; ++tm) bfr[tm] = as_bf16x8(sl[(({ls - grp[0][0]} * 4 + {tp} * 2 + q) * NT + tm) * 64 + lane]);')
-                        A(f'              wv = mfma16_split<NT>(ha[{tl}][q], bfr, wv);')
+                        A(f'              wv = mfma16_split<NT, F16>(ha[{tl}][q], bfr, wv);')
                         A('            }')
                     A('#pragma unroll')
-                    A(f'            for (int r = 0; r < 4; ++r) wv[r] = (16 * {tl} + 4 * g + r < n_e) ? wv[r] : 0.f;')
+                    A(f'            for (int r = 0; r < 4; ++r) wv[r] = (16 * {tl} + 4 * g + r < n_e) ? (F16 ? wv[r] * w_unscale[{tl}] : wv[r]) : 0.f;')
                     A(f'            if (!(diag & 1)) fwdf_p{pi}(xr, ysl, wv, acc{pi});  // opaque branch: see the reverse kernel')
                     A('          }')
                 A('        }')
@@ -815,7 +983,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             combos += [v for v in cand if v != default]
         return combos
 
-    A('template <int NT, int NWV, bool GLDS, int OCC>')
+    A('template <int NT, bool F16, int NWV, bool GLDS, int OCC>')
     A('void launch_bwd_t(const float *x, const float *sh, const float *dsh, const float *h2, const int32_t *w_row,')
     A('                  const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, const int32_t *tile_node, int64_t n_tiles,')
     A('                  const void *slabs, float scale, const float *g_out, float *g_xe, float *g_h2, float *g_vec, snet::FusedTail tail, hipStream_t st) {')
@@ -823,7 +991,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  int diag = 0;')
     if exp:
         A('  if (const char *e = getenv("SNET_FV_DIAG")) diag = atoi(e);')
-    A(f'  conv_bwdf_{tag}<NT, NWV, GLDS, OCC><<<dim3(grid), dim3(64 * NWV), 0, st>>>(x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node,')
+    A(f'  conv_bwdf_{tag}<NT, F16, NWV, GLDS, OCC><<<dim3(grid), dim3(64 * NWV), 0, st>>>(x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node,')
     A('      (int)n_tiles, static_cast<const u32x4 *>(slabs), scale, g_out, g_xe, g_h2, g_vec, tail, diag);')
     A('}')
     A('void launch_bwd(int nt, const float *x, const float *sh, const float *dsh, const float *h2, const int32_t *w_row,')
@@ -835,7 +1003,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         A('  if (const char *e = getenv("SNET_FV_BWD")) sscanf(e, "%d,%d,%d", &vw, &vg, &vo);')
         for (w, gl, oc) in variants(def_b):
             for nt_ in (3, 2):
-                A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<{nt_}, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
+                A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
+            A(f'  if (nt == 4 && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
     def bwd_lds(nt, nwv):
         return 2 * 8 * nt * 1024 + nwv * (2 * NGP * 64 + NSH * 64)
 
@@ -854,24 +1023,26 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         if bwd_lds(nt, 4) <= 80 * 1024:
             return (4, 0, 2)
         return (2, 0, 2)
-    for nt_, kw in ((3, 'if'), (2, 'else if'), (1, 'else')):
+    w, gl, oc = bwd_cfg(2)
+    A(f'  if (nt == 4) launch_bwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
+    for nt_, kw in ((3, 'else if'), (2, 'else if'), (1, 'else')):
         w, gl, oc = bwd_cfg(nt_)
         cond = f' (nt == {nt_})' if kw != 'else' else ''
-        A(f'  {kw}{cond} launch_bwd_t<{nt_}, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
+        A(f'  {kw}{cond} launch_bwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
     A('}')
-    A('template <int NT, int NWV, bool GLDS, int OCC>')
+    A('template <int NT, bool F16, int NWV, bool GLDS, int OCC>')
     A('void launch_fwd_t(const float *x, const float *sh, const float *h2, const int32_t *w_row, const int32_t *row_ptr,')
-    A('                  const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, hipStream_t st) {')
+    A('                  const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, int w2_exp, hipStream_t st) {')
     A('  const unsigned grid = (unsigned)((n_dst + NWV - 1) / NWV);')
     A('  int diag = 0;')
     if exp:
         A('  if (const char *e = getenv("SNET_FV_DIAG")) diag = atoi(e);')
-    A(f'  conv_fwdf_{tag}<NT, NWV, GLDS, OCC><<<dim3(grid), dim3(64 * NWV), 0, st>>>(x, sh, h2, w_row, row_ptr, src, (int)n_dst,')
-    A('      static_cast<const u32x4 *>(slabs), scale, out, diag);')
+    A(f'  conv_fwdf_{tag}<NT, F16, NWV, GLDS, OCC><<<dim3(grid), dim3(64 * NWV), 0, st>>>(x, sh, h2, w_row, row_ptr, src, (int)n_dst,')
+    A('      static_cast<const u32x4 *>(slabs), scale, out, w2_exp, diag);')
     A('}')
     A('void launch_fwd(int nt, const float *x, const float *sh, const float *h2, const int32_t *w_row, const int32_t *row_ptr,')
-    A('                const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, hipStream_t st) {')
-    args_f = 'x, sh, h2, w_row, row_ptr, src, n_dst, slabs, scale, out, st'
+    A('                const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, int w2_exp, hipStream_t st) {')
+    args_f = 'x, sh, h2, w_row, row_ptr, src, n_dst, slabs, scale, out, w2_exp, st'
     if exp:
         A('  int vw = %d, vg = %d, vo = %d;' % def_f)
         A('  if (const char *e = getenv("SNET_FV_FWD")) sscanf(e, "%d,%d,%d", &vw, &vg, &vo);')
@@ -879,7 +1050,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             for nt_ in (3, 2):
                 if nt_ == 3 and w > 8:
                     continue   # would not fit the 160-KB LDS
-                A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_fwd_t<{nt_}, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
+                A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_fwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
+            A(f'  if (nt == 4 && vw == {w} && vg == {gl} && vo == {oc}) return launch_fwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
     def fwd_lds(nt, nwv):
         return 2 * LPB * 4 * nt * 1024 + nwv * (32 * NSHP * 4 + MAXD1 * 1024 + NOEP * 64) + 4 * nwv
 
@@ -896,10 +1068,12 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             if fwd_lds(nt, w) <= 160 * 1024:
                 return (w, 1, 2)
         raise NotImplementedError(f'conv shape {spec.key}: the fused forward kernel does not fit the LDS')
-    for nt_, kw in ((3, 'if'), (2, 'else if'), (1, 'else')):
+    w, gl, oc = fwd_cfg(2)
+    A(f'  if (nt == 4) launch_fwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
+    for nt_, kw in ((3, 'else if'), (2, 'else if'), (1, 'else')):
         w, gl, oc = fwd_cfg(nt_)
         cond = f' (nt == {nt_})' if kw != 'else' else ''
-        A(f'  {kw}{cond} launch_fwd_t<{nt_}, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
+        A(f'  {kw}{cond} launch_fwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
     A('}')
     A(f'const snet::FusedKernels kernels = {{"{tag}", DX, DOUT, NSH, WN, NS, SUB_COLS, launch_bwd, launch_fwd}};')
     A('const snet::FusedRegistrar registrar(&kernels);')

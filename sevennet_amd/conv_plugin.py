@@ -182,6 +182,10 @@ class HipUvuConvolution(torch.nn.Module):
             raise NotImplementedError('HipUvuConvolution: per-edge external weights only')
         self.lib = _lib.load()
         self.spec = conv_spec_from_instructions(irreps_in1, irreps_in2, irreps_out, instructions)
+        # any irreps the reference's hook may construct (convolution.py:237-247): a shape that is not in the library
+        # yet is generated, compiled with hipcc and registered now (cached on disk: sevennet_amd/jit.py)
+        from .jit import ensure_conv_shape
+        ensure_conv_shape(self.spec)
         plan = C.c_void_p()
         _lib.check(self.lib.snet_conv_plan_create(self.spec.tag.encode(), C.byref(plan)), 'snet_conv_plan_create')
         self.plan = plan

@@ -2,6 +2,8 @@
 #include <map>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "snet_common.h"
 
 namespace snet {
@@ -57,6 +59,7 @@ struct snet_fused_plan {
   int terms;
   void *slabs;  // device: W2 as pre-split MFMA fragments in the kernels' sub-step order, then the hidden-layer tail
   snet::MlpHidden hidden;  // w0 == nullptr: no tail (g_h2 is always written)
+  int32_t exps[3];         // mode 4: power-of-two scales of W2 / W1 / W0 in the fragment stream
 };
 
 extern "C" {
@@ -83,6 +86,22 @@ int snet_conv_plan_create(const char *tag, snet_conv_plan **plan) {
   return 3;
 }
 void snet_conv_plan_destroy(snet_conv_plan *plan) { delete plan; }
+int snet_conv_register_library(const char *path) {
+  SNET_REQUIRE(path != nullptr, "snet_conv_register_library: null path");
+  const size_t before = snet::registry().size() + snet::fused_registry().size();
+  // the library's static registrars (generated conv_<tag>.hip / convf_<tag>.hip) run inside dlopen
+  void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (h == nullptr) {
+    const char *why = dlerror();
+    snet::set_error(std::string("snet_conv_register_library: dlopen(") + path + ") failed: " + (why ? why : "?"));
+    return 2;
+  }
+  if (snet::registry().size() + snet::fused_registry().size() == before) {
+    snet::set_error(std::string("snet_conv_register_library: ") + path + " registered no tensor-product shape");
+    return 3;
+  }
+  return 0;
+}
 int snet_conv_plan_dims(const snet_conv_plan *plan, int32_t *dx, int32_t *dout, int32_t *nsh, int32_t *wn) {
   SNET_REQUIRE(plan != nullptr, "snet_conv_plan_dims: null plan");
   if (dx) *dx = plan->k->dx;
@@ -107,7 +126,8 @@ int snet_conv_fused_available(const snet_conv_plan *plan) {
 
 int snet_fused_plan_create(const snet_conv_plan *plan, const snet_mlp_plan *mlp, int32_t terms, snet_fused_plan **out) {
   SNET_REQUIRE(plan != nullptr && mlp != nullptr && out != nullptr, "snet_fused_plan_create: null argument");
-  SNET_REQUIRE(terms >= 1 && terms <= 3, "snet_fused_plan_create: terms must be 1 (bf16), 2 (bf16x3) or 3 (bf16x6)");
+  SNET_REQUIRE(terms >= 1 && terms <= 4,
+               "snet_fused_plan_create: terms must be 1 (bf16), 2 (bf16x3), 3 (bf16x6) or 4 (f16x3: two fp16 terms)");
   const snet::FusedKernels *k = snet::find_fused(plan->k->tag);
   SNET_REQUIRE(k != nullptr, "snet_fused_plan_create: this tensor-product shape has no fused kernels (channel "
                              "multiplicities must be multiples of 16)");
@@ -118,12 +138,13 @@ int snet_fused_plan_create(const snet_conv_plan *plan, const snet_mlp_plan *mlp,
   // 16-row operand tile and its rows are whole float4s
   snet::MlpHidden hid = snet::mlp_plan_hidden(mlp);
   if (hid.w0 != nullptr && !(hid.nb <= 16 && hid.nb % 4 == 0)) hid.w0 = nullptr;
+  int32_t exps[3] = {0, 0, 0};
   if (snet::pack_fused_slabs(snet::mlp_plan_w2_host(mlp), k->wn, k->n_sub, k->sub_cols, terms,
-                             hid.w0 ? &hid : nullptr, &dev) != 0) {
+                             hid.w0 ? &hid : nullptr, &dev, exps) != 0) {
     snet::set_error("snet_fused_plan_create: device allocation / upload of the W2 fragment stream failed");
     return 1;
   }
-  *out = new snet_fused_plan{k, terms, dev, hid};
+  *out = new snet_fused_plan{k, terms, dev, hid, {exps[0], exps[1], exps[2]}};
   return 0;
 }
 void snet_fused_plan_destroy(snet_fused_plan *p) {
@@ -138,7 +159,8 @@ int snet_conv_fwd_fused(const snet_fused_plan *fp, const float *x, const float *
   SNET_REQUIRE(fp != nullptr, "snet_conv_fwd_fused: null plan");
   SNET_REQUIRE(n_dst < (1ll << 31) / 4, "snet_conv_fwd_fused: too many nodes");
   if (n_dst <= 0) return 0;
-  fp->k->fwd(fp->terms, x, sh, h2, w_row, row_ptr, src, n_dst, fp->slabs, scale, out, static_cast<hipStream_t>(stream));
+  fp->k->fwd(fp->terms, x, sh, h2, w_row, row_ptr, src, n_dst, fp->slabs, scale, out, fp->exps[0],
+             static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_conv_fwd_fused");
   return 0;
 }
@@ -147,15 +169,19 @@ int snet_fused_plan_has_mlp_tail(const snet_fused_plan *fp) { return fp != nullp
 int snet_conv_bwd_fused(const snet_fused_plan *fp, const float *x, const float *sh, const float *dsh, const float *h2,
                         const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr,
                         const int32_t *tile_node, int64_t n_tiles, float scale, const float *g_out, float *g_xe,
-                        float *g_h2, const float *emb, float *g_emb, float *g_vec, void *stream) {
+                        float *g_h2, const float *emb, float *g_emb, float *g_vec, const float *x_rowmax,
+                        const float *g_rowmax, void *stream) {
   SNET_REQUIRE(fp != nullptr, "snet_conv_bwd_fused: null plan");
+  SNET_REQUIRE(fp->terms != 4 || (x_rowmax != nullptr && g_rowmax != nullptr),
+               "snet_conv_bwd_fused: terms = 4 (fp16 operands) needs x_rowmax and g_rowmax (snet_row_absmax of x and g_out)");
   SNET_REQUIRE(n_tiles < (1ll << 31), "snet_conv_bwd_fused: too many tiles");
   if (n_tiles <= 0) return 0;
   SNET_REQUIRE(tile_ptr != nullptr && tile_node != nullptr, "snet_conv_bwd_fused: null tile list");
   SNET_REQUIRE((g_h2 != nullptr) != (g_emb != nullptr), "snet_conv_bwd_fused: exactly one of g_h2 / g_emb is the output");
   SNET_REQUIRE(g_emb == nullptr || (fp->hidden.w0 != nullptr && emb != nullptr),
                "snet_conv_bwd_fused: g_emb needs emb and a plan with the hidden-layer tail (snet_fused_plan_has_mlp_tail)");
-  const snet::FusedTail tail{emb, g_emb, fp->hidden.nb, fp->hidden.act, fp->hidden.cst};
+  const snet::FusedTail tail{emb, g_emb, fp->hidden.nb, fp->hidden.act, fp->hidden.cst, fp->exps[0], fp->exps[1], fp->exps[2],
+                             x_rowmax, g_rowmax};
   fp->k->bwd(fp->terms, x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node, n_tiles, fp->slabs, scale, g_out,
              g_xe, g_h2, g_vec, tail, static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_conv_bwd_fused");

@@ -64,6 +64,11 @@ struct FusedTail {
   float *g_emb;      // [E, nb] +=
   int nb, act;
   float cst;
+  // precision mode 4 (fp16 terms): powers of two the host scaled W2 / W1 / W0 by before splitting them
+  int w2_exp, w1_exp, w0_exp;
+  // precision mode 4: max |x[row]| per source row and max |g_out[node]| per destination node (snet_row_absmax):
+  // the bound the per-edge power-of-two scale of the fp16 operand g_w is derived from
+  const float *x_max, *g_max;
 };
 struct FusedKernels {
   const char *tag;
@@ -72,13 +77,14 @@ struct FusedKernels {
   const int32_t *sub_cols;
   // reverse pass of one tile list (snet_edge_tiles): g_xe[E,dx] (nullable), g_vec[E,3] +=, and either g_h2[E,64]
   // or (tail.g_emb set) the radial MLP's hidden layers reversed in the same kernel: g_emb[E,nb] +=
+  // nt = precision mode of the in-kernel products: 1 / 2 / 3 bf16 terms per operand, 4 = two fp16 terms ("f16x3")
   void (*bwd)(int nt, const float *x, const float *sh, const float *dsh, const float *h2, const int32_t *w_row,
               const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, const int32_t *tile_node,
               int64_t n_tiles, const void *slabs, float scale, const float *g_out, float *g_xe, float *g_h2,
               float *g_vec, FusedTail tail, hipStream_t st);
   // forward: out[n_dst, dout]
   void (*fwd)(int nt, const float *x, const float *sh, const float *h2, const int32_t *w_row, const int32_t *row_ptr,
-              const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, hipStream_t st);
+              const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, int w2_exp, hipStream_t st);
 };
 void register_fused(const FusedKernels *k);
 const FusedKernels *find_fused(const char *tag);
@@ -99,8 +105,9 @@ struct MlpHidden {
 MlpHidden mlp_plan_hidden(const snet_mlp_plan *plan);  // w0 == nullptr: the plan has no split-precision hidden layers
 constexpr int FUSED_TAIL_FRAGS = 22;  // z1 (4) + z2 (8) + g_a1 (8) + g_emb (2) operand fragments, nt terms each
 // `tail` (nullable): append the hidden-layer fragments the reverse kernels' g_h2 -> g_emb tail multiplies with.
-int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols, int nt, const MlpHidden *tail,
-                     void **dev_out);
+// mode: 1 / 2 / 3 bf16 terms per value, or 4 = two fp16 terms of the value times 2^exps[i] (i = 0 W2, 1 W1, 2 W0)
+int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols, int mode, const MlpHidden *tail,
+                     void **dev_out, int32_t (&exps)[3]);
 
 struct ConvRegistrar {
   explicit ConvRegistrar(const ConvKernels *k) { register_conv(k); }

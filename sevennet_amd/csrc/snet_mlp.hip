@@ -13,6 +13,8 @@
 // cross-lane traffic between the layers.  W2 (64 x wn, up to 450 KB) streams from L2 as B fragments
 // (one coalesced 128-B row segment per half-wave per step); the output tile is stored as 128-B row
 // segments of w.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <initializer_list>
 #include <vector>
@@ -815,14 +817,72 @@ MlpHidden mlp_plan_hidden(const snet_mlp_plan *plan) {
     h = MlpHidden{plan->w0_host.data(), plan->w1_host.data(), plan->nb, plan->act, plan->cst};
   return h;
 }
-int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols, int nt, const MlpHidden *tail,
-                     void **dev_out) {
+// fp32 -> fp16 bits, round-to-nearest-even, subnormals kept (what v_cvt_pk_f16_f32 does on the device)
+static uint16_t f16_rne(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+  const uint32_t a = u & 0x7fffffffu;
+  if (a >= 0x7f800000u) return sign | (a > 0x7f800000u ? 0x7e00u : 0x7c00u);
+  if (a >= 0x477ff000u) return sign | 0x7c00u;                 // rounds to >= 2^16: infinity
+  if (a < 0x33000001u) return sign;                             // <= 2^-25: zero
+  if (a < 0x38800000u) {                                        // subnormal result: quantum 2^-24
+    const int shift = 126 - (int)(a >> 23);                     // 14 .. 24
+    const uint32_t m = (a & 0x7fffffu) | 0x800000u;
+    const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    return sign | (uint16_t)(q + ((rem > half || (rem == half && (q & 1))) ? 1 : 0));
+  }
+  const uint32_t r = a + 0xfffu + ((a >> 13) & 1);              // normal: round the 13 dropped bits
+  return sign | (uint16_t)((r - 0x38000000u) >> 13);
+}
+static float f16_f(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31, m = h & 0x3ffu;
+  float f;
+  if (e == 0) {
+    f = std::ldexp((float)m, -24);
+  } else {
+    const uint32_t u = ((e + 112) << 23) | (m << 13);
+    std::memcpy(&f, &u, 4);
+  }
+  return sign ? -f : f;
+}
+// k with max |v| * 2^k in [2^13, 2^14) (what the kernels' bound_exp / F16_TOP produce for dynamic operands)
+static int f16_scale_exp(const float *v, size_t n) {
+  float m = 0.f;
+  for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(v[i]));
+  if (!(m > 0.f) || !std::isfinite(m)) return 0;
+  int e;
+  (void)std::frexp(m, &e);  // m = f 2^e, f in [0.5, 1)
+  return std::max(-100, std::min(100, 14 - e));
+}
+
+int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols, int mode, const MlpHidden *tail,
+                     void **dev_out, int32_t (&exps)[3]) {
+  // mode 1 / 2 / 3: that many bf16 terms per value; mode 4 ("f16x3"): two fp16 terms of the value scaled by a power
+  // of two per matrix (exps[0..2] = the exponents applied to W2, W1, W0; the kernels divide them out again)
+  const bool f16 = mode == 4;
+  const int nt = f16 ? 2 : mode;
+  exps[0] = exps[1] = exps[2] = 0;
+  if (f16) {
+    exps[0] = f16_scale_exp(w2, (size_t)H * wn);
+    if (tail) {
+      exps[1] = f16_scale_exp(tail->w1, (size_t)H * H);
+      exps[2] = f16_scale_exp(tail->w0, (size_t)tail->nb * H);
+    }
+  }
   const int lps = 8 * nt;  // 1-KB lines per sub-step
   const size_t tail_lines = tail ? (size_t)FUSED_TAIL_FRAGS * nt : 0;
   std::vector<uint16_t> out(((size_t)n_sub * lps + tail_lines) * 64 * 8, 0);
+  int cur_exp = exps[0];
   auto put = [&](size_t line, int lane, int slot, float v, int term) {
     uint16_t sp[3];
-    split3(v, sp);
+    if (f16) {
+      const float x = std::ldexp(v, cur_exp);
+      sp[0] = f16_rne(x);
+      sp[1] = f16_rne(x - f16_f(sp[0]));
+    } else {
+      split3(v, sp);
+    }
     out[((line + term) * 64 + lane) * 8 + slot] = sp[term];
   };
   for (int s = 0; s < n_sub; ++s) {
@@ -863,7 +923,9 @@ int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols
           for (int m = 0; m < 4; ++m) {
             // z1^T[16 m + i][edge] = sum_k W0'[k][16 m + i] emb[edge][k], k = 8 gg + t
             const int k = 8 * gg + t;
+            cur_exp = exps[2];
             put(base + (size_t)(0 + m) * nt, lane, t, k < nb ? w0[(size_t)k * H + 16 * m + i] : 0.f, term);
+            cur_exp = exps[1];
             for (int s = 0; s < 2; ++s) {
               const int u = unit(s, gg, t);
               // z2^T[16 m + i][edge] = sum_u W1'[u][16 m + i] a1[edge][u]
@@ -872,6 +934,7 @@ int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols
               put(base + (size_t)(12 + 2 * m + s) * nt, lane, t, w1[(size_t)(16 * m + i) * H + u], term);
             }
           }
+          cur_exp = exps[2];
           for (int s = 0; s < 2; ++s)  // g_emb^T[k0 = i][edge] = sum_u W0'[i][u] g_z1[edge][u]
             put(base + (size_t)(20 + s) * nt, lane, t, i < nb ? w0[(size_t)i * H + unit(s, gg, t)] : 0.f, term);
         }

@@ -419,6 +419,10 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   SNET_REQUIRE(m != nullptr, "snet_model_eval: null model");
   SNET_REQUIRE(NT >= N && N > 0 && E >= 0, "snet_model_eval: need n_total >= n_local > 0 and n_edges >= 0");
   SNET_REQUIRE(NT == N || (m->halo_fwd && m->halo_rev), "snet_model_eval: ghost atoms need halo callbacks");
+  // The exchange is a collective of send/recv pairs: a rank without ghost rows of its own may still own rows its
+  // peers wait for (slab / cluster systems whose only ghosts are periodic self-images), so an installed halo is
+  // called on every layer whatever NT - N is (snet_halo_* handles n_ghost == 0)
+  const bool has_halo = m->halo_fwd != nullptr && m->halo_rev != nullptr;
   const bool pairs = w_row != nullptr && E > 0;
   SNET_REQUIRE(!pairs || (pair_edge != nullptr && n_pairs > 0 && n_pairs <= E),
                "snet_model_eval: w_row needs pair_edge and 0 < n_pairs <= n_edges");
@@ -553,7 +557,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     }
     float *h = saved[t].h;
     if ((rc = run_linear(m, L.si1, x, h, t == 0 ? NT : N, false, false, st))) return rc;
-    if (t > 0 && NT > N)
+    if (t > 0 && has_halo)
       if ((rc = m->halo_fwd(m->halo_user, h, NT, N, L.dx, stream))) {
         snet::set_error("snet_model_eval: forward halo callback failed");
         return rc;
@@ -616,14 +620,21 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     if (L.fused) {  // g_w is contracted with W2^T inside the kernel; with the hidden-layer tail not even g_h2 leaves it
       const bool tail = snet_fused_plan_has_mlp_tail(L.fused) != 0;
       float *g_h2 = tail ? nullptr : A.f((size_t)E * 64);
+      float *x_max = nullptr, *g_max = nullptr;
+      if (E > 0 && SNET_FUSED_TERMS_DEFAULT == 4) {  // fp16 operands: bounds of every edge's g_w (see snet_row_absmax)
+        x_max = A.f((size_t)NT);
+        g_max = A.f((size_t)N);
+        if ((rc = snet_row_absmax(saved[t].h, NT, L.dx, x_max, st))) return rc;
+        if ((rc = snet_row_absmax(g_m, N, L.dmid, g_max, st))) return rc;
+      }
       if (E > 0 && (rc = snet_conv_bwd_fused(L.fused, saved[t].h, sh, dsh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src,
                                              tile_ptr, tile_node, n_tiles, L.conv_scale, g_m, g_xe, g_h2,
-                                             tail ? emb : nullptr, tail ? g_emb : nullptr, g_vec, st)))
+                                             tail ? emb : nullptr, tail ? g_emb : nullptr, g_vec, x_max, g_max, st)))
         return rc;
       if (t > 0) {
         float *g_h = A.f((size_t)NT * L.dx);
         if ((rc = snet_segment_sum_rows(g_xe, col_ptr, eperm, NT, L.dx, g_h, st))) return rc;
-        if (NT > N)
+        if (has_halo)
           if ((rc = m->halo_rev(m->halo_user, g_h, NT, N, L.dx, stream))) {
             snet::set_error("snet_model_eval: reverse halo callback failed");
             return rc;
@@ -657,7 +668,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     if (t == 0) break;  // layer-0 inputs depend on species only
     float *g_h = A.f((size_t)NT * L.dx);
     if ((rc = snet_segment_sum_rows(g_xe, col_ptr, eperm, NT, L.dx, g_h, st))) return rc;
-    if (NT > N)
+    if (has_halo)
       if ((rc = m->halo_rev(m->halo_user, g_h, NT, N, L.dx, stream))) {
         snet::set_error("snet_model_eval: reverse halo callback failed");
         return rc;
@@ -675,7 +686,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   A.off = mark2;
   float *F = forces ? forces : A.f((size_t)NT * 3);
   if ((rc = snet_edge_force(g_vec, edge_vec, row_ptr, col_ptr, eperm, NT, E, F, virial_atom, virial, st))) return rc;
-  if (NT > N && m->fold_forces) {
+  if (has_halo && m->fold_forces) {
     if ((rc = m->halo_rev(m->halo_user, F, NT, N, 3, stream))) return rc;
     if (virial_atom && (rc = m->halo_rev(m->halo_user, virial_atom, NT, N, 6, stream))) return rc;
   }

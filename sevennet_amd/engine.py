@@ -230,7 +230,7 @@ class HipForceEngine:
     OVERLAP_MAX_EDGES = 1_000_000
 
     def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6',
-                 linear_mode: str = 'bf16x6', fused='auto', fused_terms: int = 2, modal=None, overlap: bool = True,
+                 linear_mode: str = 'bf16x6', fused='auto', fused_terms='f16x3', modal=None, overlap: bool = True,
                  mlp_tail: bool = True):
         """mlp_mode / linear_mode: 'bf16x6' (split-precision MFMA, fp32-class accuracy, default) or
         'fp32' (exact fp32 MFMA) for the fused radial MLP / the node-level equivariant linears.
@@ -238,10 +238,13 @@ class HipForceEngine:
         tensor-product kernels (snet_conv_fwd_fused / snet_conv_bwd_fused): neither w[E,wn] nor g_w[E,wn] is
         materialised; what is kept per layer is h2[pairs,64].  Needs mlp_mode 'bf16x6' and a shape whose channel
         multiplicities are multiples of 16 ('auto': used where available; True: required).
-        fused_terms: bf16 terms per operand of the in-kernel products w = h2 @ W2 and g_h2 = g_w @ W2^T:
-        2 (default) = bf16x3 (a0b0 + a0b1 + a1b0, ~2^-16 relative per product: measured max force error vs the
-        fp64 oracle 6e-7 eV/A where the fp32-class paths give 2e-7, tools/gpu/terms_accuracy.py), 3 = bf16x6
-        (fp32-rounding class, twice the matrix-core work), 1 = plain bf16 (3e-4 .. 5e-4 eV/A: outside the 1e-4 bar).
+        fused_terms: precision mode of the in-kernel products w = h2 @ W2 and g_h2 = g_w @ W2^T (name or C-ABI code):
+        'f16x3' / 4 (default) = two fp16 terms per operand, three products hi*hi + hi*lo + lo*hi on
+        v_mfma_f32_16x16x32_f16 with power-of-two operand scaling: fp32-rounding class (22 significand bits per
+        operand) at the matrix-core cost of bf16x3; 'bf16x6' / 3 = three bf16 terms, six products (fp32-rounding
+        class, twice the matrix-core work); 'bf16x3' / 2 = two bf16 terms (~2^-17 per product: at MD-scale forces,
+        max|F| = 8 eV/A, 7e-5 .. 3.5e-4 eV/A vs the fp64 oracle where the fp32-class modes give 1e-5 .. 4e-5:
+        profiles/r03_terms_accuracy.txt -- NOT inside the 1e-4 eV/A bar); 'bf16' / 1 = plain bf16 (1e-2 relative).
         overlap: run the radial MLPs on a second HIP stream -- forward: all layers' weights are produced
         from the edge embedding while the node-level work of earlier layers runs; reverse: the MLP reverse of
         layer t (which only feeds the final radial gradient) runs beside the rest of the reverse pass.
@@ -260,7 +263,11 @@ class HipForceEngine:
             raise ValueError("fused must be 'auto', True, False, 'fwd' or 'bwd'")
         self.mlp_mode = mlp_mode
         self.linear_mode = linear_mode
-        self.fused_terms = int(fused_terms)
+        codes = {'bf16': 1, 'bf16x3': 2, 'bf16x6': 3, 'f16x3': 4}
+        if fused_terms not in codes and fused_terms not in codes.values():
+            raise ValueError(f"fused_terms must be one of {sorted(codes)} (or the C-ABI code 1..4)")
+        self.fused_terms = int(codes.get(fused_terms, fused_terms))
+        self.fused_mode = {v: k for k, v in codes.items()}[self.fused_terms]
         self.overlap = bool(overlap)
         self._side = None  # second stream, created on first use
         self.events = None  # set to [] to collect (name, start, end) HIP events per kernel class
@@ -324,6 +331,9 @@ class HipForceEngine:
                                'snet_radial_mlp_plan_create')
                     L.mlp_plan = mp
                 L.scale = 1.0 / float(sd[f'{ls.t}_convolution.denominator'][0])
+                if ls.conv.tag not in _lib.compiled_conv_tags():   # a model outside sevennet_amd/shapes.py: compile its shape now
+                    from .jit import ensure_conv_shape
+                    ensure_conv_shape(ls.conv)
                 plan = C.c_void_p()
                 _lib.check(self.lib.snet_conv_plan_create(ls.conv.tag.encode(), C.byref(plan)), 'snet_conv_plan_create')
                 L.plan = plan
@@ -616,13 +626,21 @@ class HipForceEngine:
                 g_w = g_h2 = None
                 if L.fused_bwd:
                     g_h2 = None if L.mlp_tail else self._new(E, 64)
+                    x_max = g_max = None
+                    if self.fused_terms == 4 and E > 0:
+                        # fp16 operands: row maxima of the source rows and of the incoming gradient bound every edge's
+                        # g_w, from which the kernel derives that edge's power-of-two scale (no overflow possible)
+                        x_max, g_max = self._new(NT), self._new(N)
+                        with _Span(self, 'row_absmax'):
+                            _lib.check(lib.snet_row_absmax(_ptr(h), NT, ls.si1.dim_out, _ptr(x_max), st), 'snet_row_absmax')
+                            _lib.check(lib.snet_row_absmax(_ptr(g_m), N, ls.conv.irreps_out.dim, _ptr(g_max), st), 'snet_row_absmax')
                     with _Span(self, f'conv_bwd_fused[{ls.conv.tag}]'):
                         if E > 0:
                             _lib.check(lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(w_row),
                                                                _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale,
                                                                _ptr(g_m), _ptr(g_xe), _ptr(g_h2),
                                                                _ptr(emb) if L.mlp_tail else None, _ptr(g_emb) if L.mlp_tail else None,
-                                                               _ptr(g_vec), st),
+                                                               _ptr(g_vec), _ptr(x_max), _ptr(g_max), st),
                                        'snet_conv_bwd_fused')
                 else:
                     if side is not None:  # double-buffered: the MLP reverse of layer t+2 may still be reading this one
@@ -669,13 +687,15 @@ class HipForceEngine:
                 del g_w, g_h2
                 if t == 0:
                     break
+                # g_x = sc^T g_y + SI1^T g_h: the self-connection's share does not need the ghost gradients, so it runs
+                # while they travel (reverse_start above put the exchange on the halo's stream)
+                with _Span(self, 'node_linear_bwd'):
+                    g_x = self._linear_T(L.sc, g_y, N, g) if L.sc is not None else None
                 if pending is not None:
                     with _Span(self, 'halo_rev'):
                         halo.reverse_finish(pending, g_h)
                 with _Span(self, 'node_linear_bwd'):
-                    g_x = self._linear_T(L.si1, g_h, N, g)
-                    if L.sc is not None:
-                        self._linear_T(L.sc, g_y, N, g, out=g_x, accumulate=True)
+                    g_x = self._linear_T(L.si1, g_h, N, g, out=g_x, accumulate=g_x is not None)
                 saved[t] = None
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
@@ -687,10 +707,14 @@ class HipForceEngine:
             _lib.check(lib.snet_edge_force(_ptr(g_vec), _ptr(g.edge_vec), _ptr(g.row_ptr), _ptr(g.col_ptr),
                                            _ptr(g.eperm), NT, E, _ptr(forces), _ptr(vir_atom), _ptr(virial), st),
                        'snet_edge_force')
-            if halo is not None:
-                halo.reverse(forces, N)  # fold ghost-atom force contributions into their owners
-                if vir_atom is not None:
-                    halo.reverse(vir_atom, N)
+            if halo is not None:  # fold ghost-atom force (and atomic virial) contributions into their owners: ONE exchange
+                with _Span(self, 'halo_rev'):
+                    if vir_atom is None:
+                        halo.reverse(forces, N)
+                    else:
+                        fv = torch.cat([forces, vir_atom], 1).contiguous()
+                        halo.reverse(fv, N)
+                        forces, vir_atom = fv[:, :3].contiguous(), fv[:, 3:].contiguous()
             if g.order is not None:  # report dE/dr in the caller's edge order
                 tmp = torch.empty_like(g_vec)
                 tmp[g.order] = g_vec

@@ -376,6 +376,30 @@ class NativeHalo:
         if handle is not None:
             torch.cuda.current_stream(handle[1].device).wait_event(handle[0])
 
+    def reverse_start(self, gx: torch.Tensor, n_local: int):
+        """Begin the reverse exchange (ghost-row gradients to their owners, accumulated into gx[:n_local]) on the
+        halo's second stream; the caller's stream may run anything that does not touch gx until reverse_finish
+        (HipForceEngine: the self-connection's transposed linear).  Reference: the reverse_comm inside the layer loop,
+        pair_e3gnn_parallel.cpp:430-440."""
+        if not self.overlap:
+            self.reverse(gx, n_local)
+            return None
+        from . import _lib
+        assert gx.is_contiguous() and gx.dtype == torch.float32
+        cur = torch.cuda.current_stream(gx.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=gx.device)
+        self._side.wait_stream(cur)          # the ghost rows' gradients are complete
+        _lib.check(self.lib.snet_halo_reverse(self.handle, C.c_void_p(gx.data_ptr()), gx.shape[0], n_local, gx.shape[1],
+                                              C.c_void_p(self._side.cuda_stream)), 'snet_halo_reverse')
+        done = torch.cuda.Event()
+        done.record(self._side)
+        return done, gx
+
+    def reverse_finish(self, handle, gx: torch.Tensor = None):
+        if handle is not None:
+            torch.cuda.current_stream(handle[1].device).wait_event(handle[0])
+
     def __del__(self):
         try:
             if getattr(self, 'handle', None):

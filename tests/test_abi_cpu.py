@@ -1,5 +1,6 @@
 """CPU: the C-ABI library builds for gfx950, loads without a GPU and exports every symbol that
 include/snet_hip.h declares; host-side model description logic."""
+import ctypes as C
 import os
 import re
 
@@ -139,3 +140,30 @@ def test_md_nodes_numbering_host_only():
     assert n.value == 7 and out[4:7].tolist() == [4, 7, 10]
     with pytest.raises(RuntimeError):
         _lib.check(lib.snet_md_nodes(0, P(ilist), len(tag), P(tag), 4, 1, P(out), C.byref(n)))
+
+
+def test_unlisted_shape_is_compiled_on_demand(tmp_path, monkeypatch):
+    """b1: the reference's hook builds `convolution_cls(**kwargs)` for any irreps (convolution.py:237-247).  A shape that
+    is not in sevennet_amd/shapes.py is generated, cross-compiled by hipcc into a shape library under $SNET_JIT_CACHE
+    and registered with the running libsnet_hip.so (snet_conv_register_library); the second request is a cache hit."""
+    from sevennet_amd import _lib, jit
+    from sevennet_amd.model_spec import build_model_spec
+    from sevennet_amd.shapes import aot_conv_specs, unit_test_config
+    monkeypatch.setenv('SNET_JIT_CACHE', str(tmp_path))
+    spec = build_model_spec(unit_test_config(channel=16, lmax=1)).layers[1].conv
+    assert spec.tag not in aot_conv_specs()
+    lib = _lib.load()
+    if spec.tag not in _lib.compiled_conv_tags():
+        plan = C.c_void_p()
+        assert lib.snet_conv_plan_create(spec.tag.encode(), C.byref(plan)) != 0
+    assert jit.ensure_conv_shape(spec) == spec.tag
+    assert spec.tag in _lib.compiled_conv_tags()
+    plan = C.c_void_p()
+    _lib.check(lib.snet_conv_plan_create(spec.tag.encode(), C.byref(plan)), 'snet_conv_plan_create')
+    assert lib.snet_conv_fused_available(plan) == 1      # channel multiplicities % 16 == 0: fused kernels too
+    lib.snet_conv_plan_destroy(plan)
+    files = [f for f in os.listdir(tmp_path) if f.endswith('.so')]
+    assert len(files) == 1 and files[0].startswith(spec.tag)
+    assert jit.compile_shape(spec) == os.path.join(str(tmp_path), files[0])   # cache hit: same file
+    with pytest.raises(RuntimeError, match='dlopen'):
+        _lib.check(lib.snet_conv_register_library(str(tmp_path / 'missing.so').encode()), 'snet_conv_register_library')

@@ -38,20 +38,23 @@ def _close(a, b, rel, floor, what):
     assert err <= tol, f'{what}: max err {err:.3e} > tol {tol:.3e} (scale {np.abs(b).max() if b.size else 0:.3e})'
 
 
-def _compare(eng, out, ref, n, rel=3e-5, check_inter=True):
+def _compare(eng, out, ref, n, rel=3e-5, check_inter=True, e_unit=1.0):
     """fp32 engine vs fp64 oracle: errors relative to each quantity's scale, never looser than
-    the north-star 1e-4 eV/A on forces."""
-    _close(out['energy'], ref['energy'].reshape(1), 1e-6, 1e-6 * n, 'energy')
-    _close(out['atomic_energy'], ref['atomic_energy'], rel, 5e-6, 'atomic_energy')
+    the north-star 1e-4 eV/A on forces.  e_unit: the rescale factor the energies carry (SURVEY.md 8d's energy bar,
+    1e-6 eV per atom, is stated at rescale scale 1: a per-atom readout of O(1e-2) is a difference of O(1) features,
+    so its fp32 error is absolute in the UNSCALED unit -- measured 4e-7, identical for every engine mode)."""
+    _close(out['energy'], ref['energy'].reshape(1), 1e-6, 1e-6 * n * e_unit, 'energy')
+    _close(out['atomic_energy'], ref['atomic_energy'], rel, 5e-6 * e_unit, 'atomic_energy')
     _close(out['dE_dr'], ref['dE_dr'], rel, 1e-8, 'dE_dr')
     _close(out['forces'], ref['forces'], rel, 1e-8, 'forces')
     assert np.abs(out['forces'].cpu().numpy() - ref['forces'].numpy()).max() < f_tol(ref['forces'].abs().max().item())
     _close(out['virial'], ref['virial'], rel, 1e-7, 'virial')
     _close(out['atomic_virial'], ref['atomic_virial'], rel, 1e-8, 'atomic_virial')
     if check_inter and 'inter' in out:
-        # module-by-module features: 1e-5 of each tensor's scale for the fp32-class kernels; layers whose radial
-        # weights are formed inside the tensor-product kernel from bf16x3 products (engine default, ~2^-16 per
-        # product, tools/gpu/terms_accuracy.py: forces 6e-7 eV/A) get 4e-5 from their convolution on
+        # module-by-module features: 1e-5 of each tensor's scale for the fp32-class kernels (the engine default
+        # f16x3 included: tests/unit_tests/test_flash.py:96-125 is the reference's own bar for an accelerated
+        # convolution); only an engine explicitly built with bf16x3 / bf16 in-kernel products gets 4e-5 from its
+        # first fused convolution on
         loose = [t for t, L in enumerate(eng.layers) if getattr(L, 'fused_fwd', False) and eng.fused_terms < 3]
         first = loose[0] if loose else len(eng.layers)
         for t, L in enumerate(eng.layers):
@@ -132,7 +135,7 @@ def test_sevennet_0_shape_vs_oracle_small_cell():
     eng, out = _run(cfg, sd, types, ei, ev, keep=True)
     ref = oracle_model(cfg, sd).forward(types, ei, ev, keep=True)
     # synthetic N(0,1) weights give O(1e2..1e4) energies/forces: compare relative to the force scale
-    _compare(eng, out, ref, len(types), rel=5e-5)
+    _compare(eng, out, ref, len(types), rel=2e-5)
 
 
 @pytest.mark.parametrize('world', [2, 8])
@@ -315,7 +318,7 @@ def test_sevennet_l3i5_shape_vs_oracle_small_cell():
     types, pos, cell, ei, ev = synthetic_system((1, 1, 2), sigma=0.3, seed=3, cutoff=5.0)
     eng, out = _run(cfg, sd, types, ei, ev, keep=True)
     ref = oracle_model(cfg, sd).forward(types, ei, ev, keep=True)
-    _compare(eng, out, ref, len(types), rel=1e-4)
+    _compare(eng, out, ref, len(types), rel=2e-5)
 
 
 @pytest.mark.parametrize('case', ['bulk', 'tiny_cell', 'brick'])
@@ -411,7 +414,7 @@ def test_sevennet_mf_ompa_shape_vs_oracle_small_cell():
     out = eng.compute(g, want_atomic_virial=True, keep=True)
     torch.cuda.synchronize()
     ref = OracleModel(cfg, sd, dtype=torch.float64, modal='omat24').forward(types, ei, ev, keep=True)
-    _compare(eng, out, ref, len(types), rel=5e-5)
+    _compare(eng, out, ref, len(types), rel=2e-5)
 
 
 def test_bench_multi_rank_path_dry_run():
@@ -442,6 +445,52 @@ def test_bench_multi_rank_path_dry_run():
         assert abs(many['config']['energy'] - one['config']['energy']) <= 1e-9 * abs(one['config']['energy'])
 
 
+MD_FMAX = 8.0  # eV/A: largest force component of the MD-scale parity systems
+
+
+def _md_scale_state(cfg, sd, types, ei, ev, modal=None):
+    """seeded synthetic weights give max|F| ~ 0.03 eV/A at rescale scale = 1, where the north-star bar of 1e-4 eV/A
+    absolute is a 0.3 % relative bar.  Returns (state dict, fp64 oracle result) with `rescale_atomic_energy.scale`
+    chosen so that the oracle's largest force component is MD_FMAX."""
+    from oracle.model import OracleModel
+    r0 = OracleModel(cfg, sd, dtype=torch.float64, modal=modal).forward(types, ei, ev)
+    k = MD_FMAX / float(r0['forces'].abs().max())
+    sd = dict(sd)
+    sd['rescale_atomic_energy.scale'] = (np.asarray(sd['rescale_atomic_energy.scale'], np.float64) * k).astype(np.float32)
+    ref = OracleModel(cfg, sd, dtype=torch.float64, modal=modal).forward(types, ei, ev, keep=True)
+    assert abs(float(ref['forces'].abs().max()) - MD_FMAX) < 1e-3 * MD_FMAX
+    ref['e_unit'] = k
+    return sd, ref
+
+
+@pytest.mark.parametrize('model', ['sevennet_0', 'sevennet_l3i5', 'sevennet_mf_ompa'])
+def test_md_scale_forces_within_1e4_absolute_small_cell(model):
+    """North-star tolerance where it means something: 64-atom cells of the three released shapes with forces of
+    MD magnitude (max|F| = 8 eV/A).  Engine default (fused kernels, f16x3 in-kernel products) vs the fp64 oracle:
+    |dF| <= 1e-4 eV/A ABSOLUTE and <= 1e-5 of max|F|; every intermediate feature tensor within 1e-5 of its scale
+    (reference bar for an accelerated convolution: tests/unit_tests/test_flash.py:96-125)."""
+    from bench import model_config
+    from sevennet_amd.engine import HipForceEngine, build_graph
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = model_config(model)
+    multi = bool(cfg.get('use_modality'))
+    modal = 'mpa' if multi else None
+    sd = random_state_dict(cfg, seed=0)
+    types, pos, cell, ei, ev = synthetic_system((2, 2, 2), sigma=0.05 if model == 'sevennet_0' else 0.1, seed=0,
+                                                cutoff=cfg['cutoff'])
+    if multi:
+        types = np.random.default_rng(4).choice(np.array([3, 8, 14, 22]), size=len(types))
+    sd, ref = _md_scale_state(cfg, sd, types, ei, ev, modal)
+    eng = HipForceEngine(cfg, sd, device='cuda:0', modal=modal)
+    assert eng.fused_mode == 'f16x3' and all(L.fused_fwd and L.fused_bwd for L in eng.layers)
+    g = build_graph(types, ei, ev, device='cuda:0', num_species=eng.spec.num_species)
+    out = eng.compute(g, want_atomic_virial=True, keep=True)
+    torch.cuda.synchronize()
+    dF = np.abs(out['forces'].cpu().numpy() - ref['forces'].numpy()).max()
+    assert dF < 1e-4 and dF < 1e-5 * MD_FMAX, dF
+    _compare(eng, out, ref, len(types), rel=1e-5, e_unit=ref['e_unit'])
+
+
 @pytest.mark.parametrize('n_tile', [11, 23])
 def test_sevennet_0_full_size_equals_tiled_small_cell(n_tile):
     """BASELINE config 2 / 3 sizes (SevenNet-0 shape, 11^3 x 8 = 10 648 and 23^3 x 8 = 97 336 atoms, GPU
@@ -467,7 +516,7 @@ def test_sevennet_0_full_size_equals_tiled_small_cell(n_tile):
 
     pos_s, cell_s = tile(2)
     ei, ev, _ = neighbor_list(pos_s, cell_s, [True] * 3, cfg['cutoff'])
-    ref = oracle_model(cfg, sd).forward(np.zeros(len(pos_s), np.int64), ei, ev)
+    sd, ref = _md_scale_state(cfg, sd, np.zeros(len(pos_s), np.int64), ei, ev)   # max|F| = 8 eV/A
     f_unit = ref['forces'].numpy()[:8]          # replica (0,0,0) of the 2^3 tiling
     e_unit = ref['atomic_energy'].numpy()[:8]
     pos, cell = tile(n_tile)
@@ -481,9 +530,9 @@ def test_sevennet_0_full_size_equals_tiled_small_cell(n_tile):
     F = out['forces'].cpu().numpy().reshape(-1, 8, 3)
     Ea = out['atomic_energy'].cpu().numpy().reshape(-1, 8)
     scale = max(1.0, np.abs(f_unit).max())
-    assert np.abs(F - f_unit[None]).max() < f_tol(scale)
-    assert np.abs(Ea - e_unit[None]).max() < 1e-5 * max(1.0, np.abs(e_unit).max())
-    assert abs(float(out['energy'].cpu()) / n_big - float(ref['energy']) / 64) < 1e-6
+    assert np.abs(F - f_unit[None]).max() < 1e-4, np.abs(F - f_unit[None]).max()   # absolute, at MD-scale forces
+    assert np.abs(Ea - e_unit[None]).max() < 1e-5 * max(ref['e_unit'], np.abs(e_unit).max())
+    assert abs(float(out['energy'].cpu()) / n_big - float(ref['energy']) / 64) < 2e-6 * ref['e_unit']
     assert np.abs(out['forces'].cpu().numpy().astype(np.float64).sum(0)).max() < 1e-3 * scale
 
 
@@ -711,6 +760,52 @@ def test_bricks_through_the_native_halo_equal_single_graph(world, host):
     assert np.abs(F - fr).max() <= max(1e-8, 2e-5 * np.abs(fr).max())
 
 
+@pytest.mark.parametrize('host', ['native', 'python'])
+def test_rank_without_ghosts_still_serves_its_peers(host):
+    """A rank whose own graph has NO ghost rows (n_total == n_local) but whose rows a peer needs must still join every
+    exchange: the halo is a group of send/recv pairs, and a rank that skips it leaves its peer's receive pending
+    forever (round-2 advisor finding on csrc/snet_model.cpp: the hooks ran only when n_total > n_local).  Two bricks
+    of one cell with every edge (center on rank 1, source on rank 0) removed: rank 1 then has recv = 0, send > 0.
+    Must equal the un-split evaluation of the same directed edge list."""
+    from sevennet_amd.engine import HipForceEngine, build_graph
+    from sevennet_amd.native_model import NativeModel
+    from sevennet_amd.parallel import LoopbackHub, NativeHalo, assign_owners, build_brick_graph, processor_grid
+    from sevennet_amd.shapes import mini_sevennet_0_config
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = mini_sevennet_0_config()
+    sd = random_state_dict(cfg, seed=10)
+    types, pos, cell, ei, ev = synthetic_system((4, 3, 3), sigma=0.06, seed=5, cutoff=5.0, n_species=2)
+    owner = assign_owners(pos, cell, processor_grid(2))
+    keep = ~((owner[ei[0]] == 1) & (owner[ei[1]] == 0))
+    ei, ev = ei[:, keep], ev[keep]
+    ref = HipForceEngine(cfg, sd, device='cuda:0').compute(build_graph(types, ei, ev, device='cuda:0'))
+    torch.cuda.synchronize()
+    bricks = [build_brick_graph(pos, cell, types, 5.0, 2, r, neighbors=(ei, ev)) for r in range(2)]
+    assert sum(bricks[1].recv_counts) == 0 and len(bricks[1].send_lists[0]) > 0 and sum(bricks[0].recv_counts) > 0
+    hub = LoopbackHub(2)
+    halos = [NativeHalo(hub.comm(r), bricks[r].send_lists, bricks[r].recv_counts) for r in range(2)]
+    models = [NativeModel(cfg, sd) if host == 'native' else HipForceEngine(cfg, sd, device='cuda:0') for _ in range(2)]
+
+    def fn(r):
+        b = bricks[r]
+        g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, device='cuda:0')
+        assert (g.n_total == g.n_local) == (r == 1)
+        if host == 'native':
+            models[r].set_halo(halos[r])
+            out = models[r].compute(g)
+        else:
+            out = models[r].compute(g, halo=halos[r])
+        return float(out['energy'].cpu()), out['forces'].cpu().numpy()
+    res = _run_ranks(2, fn, hub)
+    F = np.zeros((len(types), 3), np.float32)
+    for b, (_, f) in zip(bricks, res):
+        F[b.global_ids[:b.n_local]] = f[:b.n_local]
+    e_ref = float(ref['energy'].cpu())
+    assert abs(sum(e for e, _ in res) - e_ref) < 2e-6 * abs(e_ref)
+    fr = ref['forces'].cpu().numpy()
+    assert np.abs(F - fr).max() <= max(1e-8, 2e-5 * np.abs(fr).max())
+
+
 @pytest.mark.parametrize('model,n_tile', [('sevennet_l3i5', 19), ('sevennet_mf_ompa', 15)])
 def test_lmax3_shapes_full_size_equal_tiled_small_cell(model, n_tile):
     """BASELINE config 4 / 5 sizes through the size-independent tiling property: SevenNet-l3i5 shape at
@@ -740,7 +835,7 @@ def test_lmax3_shapes_full_size_equal_tiled_small_cell(model, n_tile):
 
     pos_s, cell_s, ty_s = tile(2)
     ei, ev, _ = neighbor_list(pos_s, cell_s, [True] * 3, cfg['cutoff'])
-    ref = OracleModel(cfg, sd, dtype=torch.float64, modal=modal).forward(ty_s, ei, ev)
+    sd, ref = _md_scale_state(cfg, sd, ty_s, ei, ev, modal)   # max|F| = 8 eV/A
     f_unit, e_unit = ref['forces'].numpy()[:8], ref['atomic_energy'].numpy()[:8]
     pos, cell, ty = tile(n_tile)
     n_big = len(pos)
@@ -754,7 +849,7 @@ def test_lmax3_shapes_full_size_equal_tiled_small_cell(model, n_tile):
     F = out['forces'].cpu().numpy().reshape(-1, 8, 3)
     Ea = out['atomic_energy'].cpu().numpy().reshape(-1, 8)
     scale = max(1.0, np.abs(f_unit).max())
-    assert np.abs(F - f_unit[None]).max() < f_tol(scale), (np.abs(F - f_unit[None]).max(), scale)
-    assert np.abs(Ea - e_unit[None]).max() < 2e-5 * max(1.0, np.abs(e_unit).max())
-    assert abs(float(out['energy'].cpu()) / n_big - float(ref['energy']) / 64) < 2e-6
+    assert np.abs(F - f_unit[None]).max() < 1e-4, (np.abs(F - f_unit[None]).max(), scale)   # absolute, at MD-scale forces
+    assert np.abs(Ea - e_unit[None]).max() < 2e-5 * max(ref['e_unit'], np.abs(e_unit).max())
+    assert abs(float(out['energy'].cpu()) / n_big - float(ref['energy']) / 64) < 2e-6 * ref['e_unit']
     assert np.abs(out['forces'].cpu().numpy().astype(np.float64).sum(0)).max() < 2e-3 * scale

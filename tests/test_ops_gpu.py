@@ -210,10 +210,12 @@ def _conv_case(cfg_name):
         return build_model_spec(unit_test_config(lmax=3)).layers[1].conv
     if cfg_name == 'unit_l2':
         return build_model_spec(unit_test_config()).layers[1].conv
+    if cfg_name == 'jit_c32_l2':   # NOT in sevennet_amd/shapes.py: compiled on demand by the plug-in (sevennet_amd/jit.py)
+        return build_model_spec(unit_test_config(channel=32)).layers[1].conv
     return build_model_spec(sevennet_0_config()).layers[1].conv
 
 
-@pytest.mark.parametrize('cfg_name', ['unit_l2', 'unit_l3', '7net0_mid'])
+@pytest.mark.parametrize('cfg_name', ['unit_l2', 'unit_l3', '7net0_mid', 'jit_c32_l2'])
 def test_conv_plugin_vs_oracle_autograd(cfg_name):
     """b1 boundary: HipUvuConvolution (mul_ir in/out, unsorted int32 edges, ghost rows) against the
     oracle's e3nn-style tensor product + scatter, forward and all three gradients."""
@@ -250,8 +252,8 @@ def test_conv_plugin_vs_oracle_autograd(cfg_name):
 def _fused_case(model, layer, seed, pairs):
     """random inputs for one convolution shape: ragged degrees (0, 1, 15, 16, 17, 31, 32, 33, 70 ...),
     ghost source rows, optional pair-shared radial rows (w_row)"""
-    from sevennet_amd.model_spec import build_model_spec, sevennet_0_config, sevennet_l3i5_config
-    cfg = {'sevennet_0': sevennet_0_config, 'sevennet_l3i5': sevennet_l3i5_config}[model]()
+    from sevennet_amd.model_spec import build_model_spec, sevennet_0_config, sevennet_l3i5_config, sevennet_mf_ompa_config
+    cfg = {'sevennet_0': sevennet_0_config, 'sevennet_l3i5': sevennet_l3i5_config, 'sevennet_mf_ompa': sevennet_mf_ompa_config}[model]()
     ms = build_model_spec(cfg)
     spec = ms.layers[layer].conv
     nb, wn, dx, dout, nsh = 8, spec.weight_numel, spec.irreps_x.dim, spec.irreps_out.dim, spec.irreps_sh.dim
@@ -277,15 +279,20 @@ def _fused_case(model, layer, seed, pairs):
                 W2=(torch.randn(64, wn, generator=g) / 8).contiguous())
 
 
-@pytest.mark.parametrize('model,layer,pairs,terms', [('sevennet_0', 0, False, 3), ('sevennet_0', 1, True, 3),
-                                                     ('sevennet_0', 4, True, 3), ('sevennet_0', 1, False, 2),
-                                                     ('sevennet_0', 1, True, 1), ('sevennet_l3i5', 1, True, 3),
-                                                     ('sevennet_l3i5', 0, False, 3)])
-def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms):
+@pytest.mark.parametrize('model,layer,pairs,terms,gscale', [
+    ('sevennet_0', 0, False, 3, 1.0), ('sevennet_0', 1, True, 3, 1.0), ('sevennet_0', 4, True, 3, 1.0),
+    ('sevennet_0', 1, False, 2, 1.0), ('sevennet_0', 1, True, 1, 1.0), ('sevennet_l3i5', 1, True, 3, 1.0),
+    ('sevennet_l3i5', 0, False, 3, 1.0),
+    # f16x3 (engine default): fp32-rounding class, also with gradients 7 orders of magnitude below / 5 above unity
+    # (the kernels scale their fp16 operands per tile; fp16 itself spans 2^-24 .. 2^16)
+    ('sevennet_0', 0, False, 4, 1.0), ('sevennet_0', 1, True, 4, 1.0), ('sevennet_0', 4, True, 4, 3e5),
+    ('sevennet_0', 1, False, 4, 1e-7), ('sevennet_l3i5', 1, True, 4, 1.0), ('sevennet_mf_ompa', 2, True, 4, 40.0)])
+def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms, gscale):
     """Radial-MLP last layer inside the tensor-product kernels (w and g_w never in memory) ==
     snet_radial_mlp_fwd + snet_conv_fwd and snet_conv_bwd_edge_vec + snet_radial_mlp_bwd:
     forward rows, per-edge source-row gradients, dE/d(edge_vec) and the radial-embedding gradient.
-    terms = 3 (bf16x6) must agree to fp32 rounding; 2 and 1 to their stated precision."""
+    terms = 3 (bf16x6) and 4 (f16x3) must agree to fp32 rounding; 2 and 1 to their stated precision.
+    gscale multiplies the incoming gradient g_out (every reverse output is linear in it)."""
     L, lib = _lib()
     dev = 'cuda:0'
     c = _fused_case(model, layer, 40 + layer, pairs)
@@ -300,6 +307,7 @@ def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms):
     rp, sr = c['row_ptr'].to(dev), c['src'].to(dev)
     wr = None if c['w_row'] is None else c['w_row'].to(dev)
     x, sh, dsh, emb, g_out = (c[k].to(dev) for k in ('x', 'sh', 'dsh', 'emb', 'g_out'))
+    g_out = (g_out * gscale).contiguous()
     scale = 0.25
     # ---- separate kernels (reference)
     w_ref = torch.empty(R, wn, device=dev)
@@ -308,11 +316,11 @@ def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms):
     L.check(lib.snet_conv_fwd(plan, _p(x), _p(sh), _p(w_ref), _p(wr), _p(rp), _p(sr), N, scale, _p(out_ref), None))
     g_w = torch.empty(E, wn, device=dev)
     g_xe_ref = torch.empty(E, dx, device=dev)
-    g_vec_ref = torch.ones(E, 3, device=dev)   # accumulated into
+    g_vec_ref = torch.full((E, 3), gscale, device=dev)   # accumulated into
     L.check(lib.snet_conv_bwd_edge_vec(plan, _p(x), _p(sh), _p(dsh), _p(w_ref), _p(wr), _p(rp), _p(sr), N, scale,
                                        _p(g_out), _p(g_w), _p(g_xe_ref), _p(g_vec_ref), None))
     emb_e = emb if wr is None else emb[wr.long()].contiguous()   # per directed edge
-    g_emb_ref = torch.ones(E, nb, device=dev)
+    g_emb_ref = torch.full((E, nb), gscale, device=dev)
     L.check(lib.snet_radial_mlp_bwd(mlp, _p(emb_e), _p(g_w), E, _p(g_emb_ref), None))
     # ---- fused kernels
     h2 = torch.empty(R, 64, device=dev)
@@ -330,21 +338,31 @@ def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms):
     assert torch.equal(tile_node.cpu()[:n_tiles.value].long(), torch.repeat_interleave(torch.arange(N), (deg + 15) // 16))
     g_xe = torch.full((E, dx), float('nan'), device=dev)
     g_h2 = torch.full((E, 64), float('nan'), device=dev)
-    g_vec = torch.ones(E, 3, device=dev)
+    # row maxima the fp16-operand mode (terms = 4) bounds each edge's g_w with; other modes ignore them
+    x_max, g_max = torch.empty(c['NT'], device=dev), torch.empty(N, device=dev)
+    L.check(lib.snet_row_absmax(_p(x), c['NT'], dx, _p(x_max), None))
+    L.check(lib.snet_row_absmax(_p(g_out), N, dout, _p(g_max), None))
+    torch.cuda.synchronize()
+    assert torch.equal(x_max, x.abs().amax(1)) and torch.equal(g_max, g_out.abs().amax(1))
+    if terms == 4:
+        with pytest.raises(RuntimeError, match='x_rowmax'):
+            L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), _p(tile_node),
+                                            n_tiles.value, scale, _p(g_out), _p(g_xe), _p(g_h2), None, None, _p(g_xe), None, None, None))
+    g_vec = torch.full((E, 3), gscale, device=dev)
     L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), _p(tile_node),
-                                    n_tiles.value, scale, _p(g_out), _p(g_xe), _p(g_h2), None, None, _p(g_vec), None))
-    g_emb = torch.ones(E, nb, device=dev)
+                                    n_tiles.value, scale, _p(g_out), _p(g_xe), _p(g_h2), None, None, _p(g_vec), _p(x_max), _p(g_max), None))
+    g_emb = torch.full((E, nb), gscale, device=dev)
     L.check(lib.snet_radial_mlp_hidden_bwd(mlp, _p(emb_e), _p(g_h2), E, _p(g_emb), None))
     # ... and with the MLP's hidden layers reversed inside the same kernel (g_h2 never written)
     assert lib.snet_fused_plan_has_mlp_tail(fplan) == 1
-    g_emb_t = torch.ones(E, nb, device=dev)
+    g_emb_t = torch.full((E, nb), gscale, device=dev)
     g_xe_t = torch.full((E, dx), float('nan'), device=dev)
-    g_vec_t = torch.ones(E, 3, device=dev)
+    g_vec_t = torch.full((E, 3), gscale, device=dev)
     L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), _p(tile_node),
-                                    n_tiles.value, scale, _p(g_out), _p(g_xe_t), None, _p(emb_e), _p(g_emb_t), _p(g_vec_t), None))
+                                    n_tiles.value, scale, _p(g_out), _p(g_xe_t), None, _p(emb_e), _p(g_emb_t), _p(g_vec_t), _p(x_max), _p(g_max), None))
     with pytest.raises(RuntimeError):  # exactly one of g_h2 / g_emb
         L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), _p(tile_node),
-                                        n_tiles.value, scale, _p(g_out), _p(g_xe_t), _p(g_h2), _p(emb_e), _p(g_emb_t), _p(g_vec_t), None))
+                                        n_tiles.value, scale, _p(g_out), _p(g_xe_t), _p(g_h2), _p(emb_e), _p(g_emb_t), _p(g_vec_t), _p(x_max), _p(g_max), None))
     torch.cuda.synchronize()
     a1 = torch.nn.functional.silu(c['emb'].double() @ c['W0'].double()) * cst
     a2 = torch.nn.functional.silu(a1 @ c['W1'].double()) * cst
@@ -353,20 +371,21 @@ def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms):
         assert not torch.isnan(t).any()
     assert torch.equal(g_xe_t, g_xe) and torch.equal(g_vec_t, g_vec)
     # the tail multiplies in the kernel's own precision class (`terms`), the separate hidden-layer kernel in bf16x6
-    assert (g_emb_t - g_emb).abs().max().item() <= {3: 2e-6, 2: 1e-4, 1: 4e-2}[terms] * max(1.0, g_emb.abs().max().item())
-    tol = {3: 2e-5, 2: 1e-4, 1: 4e-2}[terms]
+    assert (g_emb_t - g_emb).abs().max().item() <= {4: 2e-6, 3: 2e-6, 2: 1e-4, 1: 4e-2}[terms] * max(gscale, g_emb.abs().max().item())
+    tol = {4: 2e-5, 3: 2e-5, 2: 1e-4, 1: 4e-2}[terms]
     # g_h2 against the fp64 contraction of the separate kernel's g_w with W2^T
     g_h2_ref = g_w.double().cpu() @ c['W2'].double().T
     for name, a, b in (('out', out, out_ref), ('g_xe', g_xe, g_xe_ref), ('g_vec', g_vec, g_vec_ref),
                        ('g_h2', g_h2.cpu().double(), g_h2_ref), ('g_emb', g_emb, g_emb_ref)):
         err = (a.double().cpu() - b.double().cpu()).abs().max().item()
-        assert err <= tol * max(1.0, b.abs().max().item()), (name, err, b.abs().max().item())
+        floor = 1.0 if name == 'out' else gscale
+        assert err <= tol * max(floor, b.abs().max().item()), (name, err, b.abs().max().item())
     assert out[0].abs().max() == 0 and out[9].abs().max() == 0 and out[N - 1].abs().max() == 0   # nodes without edges
     # g_xe is optional (first layer: inputs depend on species only)
     g_h2b = torch.empty_like(g_h2)
-    g_vecb = torch.ones(E, 3, device=dev)
+    g_vecb = torch.full((E, 3), gscale, device=dev)
     L.check(lib.snet_conv_bwd_fused(fplan, _p(x), _p(sh), _p(dsh), _p(h2), _p(wr), _p(rp), _p(sr), _p(tile_ptr), _p(tile_node),
-                                    n_tiles.value, scale, _p(g_out), None, _p(g_h2b), None, None, _p(g_vecb), None))
+                                    n_tiles.value, scale, _p(g_out), None, _p(g_h2b), None, None, _p(g_vecb), _p(x_max), _p(g_max), None))
     torch.cuda.synchronize()
     assert torch.equal(g_h2, g_h2b) and torch.equal(g_vec, g_vecb)
     lib.snet_fused_plan_destroy(fplan)

@@ -5,7 +5,7 @@ OUT=$ROOT/gpurun_out/sq
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_[A-Z_0-9]*" | sort -u > $OUT/sq_counters.txt
-CMD="python $ROOT/tools/microbench.py --terms 2 --iters 2 --only fused ${MB_ARGS:-}"   # e.g. MB_ARGS="--model sevennet_l3i5 --reps 19"
+CMD="python $ROOT/tools/microbench.py --terms ${TERMS:-4} --iters 2 --only fused ${MB_ARGS:-}"   # e.g. MB_ARGS="--model sevennet_l3i5 --reps 19"
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \

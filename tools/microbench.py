@@ -27,7 +27,7 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--model', default='sevennet_0')
     ap.add_argument('--mlp-mode', default='bf16x6')
-    ap.add_argument('--terms', type=int, default=3)
+    ap.add_argument('--terms', type=int, default=4)
     ap.add_argument('--fv', default='', help='kernel-tuning builds (SNET_CODEGEN_OPTS=fexp=<tag>): semicolon-separated '
                     '"nwv,glds,occ[,diag]" variants of the fused kernels to time, e.g. "4,0,2;4,1,2;4,1,1;4,1,2,1"')
     ap.add_argument('--only', default='', help='substring filter on kernel names')
@@ -88,11 +88,12 @@ def main():
     h2 = rnd(E, 64)
     g_h2 = rnd(E, 64)
     tile_ptr, tile_node, n_tiles = g.tiles()
+    x_max, g_max = h.abs().amax(1).contiguous(), g_m.abs().amax(1).contiguous()   # bounds of the fp16-operand mode
     ops = {
         'radial_mlp_hidden_fwd': lambda: lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb), E, _ptr(h2), st),
         f'conv_fwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_fwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
-        f'conv_bwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), _ptr(g_xe), _ptr(g_h2), None, None, _ptr(g_vec), st),
-        f'conv_bwd_fused_no_gxe[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), None, _ptr(g_h2), None, None, _ptr(g_vec), st),
+        f'conv_bwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), _ptr(g_xe), _ptr(g_h2), None, None, _ptr(g_vec), _ptr(x_max), _ptr(g_max), st),
+        f'conv_bwd_fused_no_gxe[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), None, _ptr(g_h2), None, None, _ptr(g_vec), _ptr(x_max), _ptr(g_max), st),
         'radial_mlp_hidden_bwd': lambda: lib.snet_radial_mlp_hidden_bwd(L.mlp_plan, _ptr(emb), _ptr(g_h2), E, _ptr(g_emb), st),
         f'radial_mlp_fwd[wn={wn}]': lambda: eng._mlp_fwd(L, emb, E),
         f'conv_fwd[{ls.conv.tag}]': lambda: lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), None, _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
