@@ -80,7 +80,13 @@ def parse():
                          "nccl backend) or by torch.distributed.all_to_all_single ('torch'; the only choice over gloo)")
     ap.add_argument('--no-halo-overlap', action='store_true', help='N > 1, native halo: run the forward ghost exchange on the '
                     'compute stream instead of a second stream beside the self-connection / hidden radial layers')
-    ap.add_argument('--no-h2d', action='store_true', help='keep the edge vectors resident (no per-step host -> device copy)')
+    ap.add_argument('--dist-path', action='store_true', help='take the N > 1 code path (process group, RCCL unique-id broadcast, '
+                    'brick graph, native halo with its communicators) even at world size 1: what tools/gpu/rccl_world1_soak.sh runs')
+    ap.add_argument('--h2d', default='positions', choices=['positions', 'edges', 'none'],
+                    help="per-step input copied host -> device inside every timed step: 'positions' (default: fp64 positions "
+                         "[n,3], edge vectors formed on the GPU from the resident topology + image offsets -- what an MD host "
+                         "hands over), 'edges' (the fp32 edge vectors [E,3], round-2 behaviour), 'none' (inputs resident)")
+    ap.add_argument('--no-h2d', action='store_true', help="same as --h2d none")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-reps', type=int, default=6, help='CPU-baseline sample: cells per axis (6 -> 1728 atoms, 11 -> 10 648)')
     return ap.parse_args()
@@ -208,8 +214,13 @@ def main():
     torch.cuda.set_device(dev_id)
     dev = f'cuda:{dev_id}'
     import torch.distributed as dist
-    if world > 1:
+    dist_mode = world > 1 or a.dist_path
+    if dist_mode:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device(dev))
         else:
@@ -241,7 +252,7 @@ def main():
     n_atoms = len(pos)
     t0 = time.perf_counter()
     halo = None
-    if world == 1:
+    if not dist_mode:
         ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
         types = species_of(cfg, n_atoms)
         graph = build_graph(types, ei, ev, device=dev, num_species=eng.spec.num_species)
@@ -273,18 +284,40 @@ def main():
 
     # per-step input: the edge vectors (what an MD host derives from the new positions) come from pinned host
     # memory every step, on the compute stream, inside the timed region
-    ev_host = None
-    if not a.no_h2d:
+    ev_host = pos_host = None
+    if a.no_h2d:
+        a.h2d = 'none'
+    if a.h2d == 'edges':
         ev_host = graph.edge_vec.cpu().pin_memory()
+    elif a.h2d == 'positions':
+        # resident: topology (center, src) and the periodic-image offset of every edge; per step: the positions of this
+        # rank's local + ghost atoms (fp64, as ASE / LAMMPS hold them)
+        import ctypes as C
+        from sevennet_amd import _lib
+        pos_rank = np.ascontiguousarray(pos if not dist_mode else pos[bg.global_ids], np.float64)
+        pos_host = torch.from_numpy(pos_rank).pin_memory()
+        pos_dev = pos_host.to(dev)
+        ev64 = torch.from_numpy(np.ascontiguousarray(ev if not dist_mode else bg.edge_vec, np.float64)).to(dev)
+        if graph.order is not None:
+            ev64 = ev64[graph.order]
+        shift_dev = (ev64 - (pos_dev[graph.src.long()] - pos_dev[graph.center.long()])).contiguous()
+        del ev64
+        lib_ = _lib.load()
 
     def step():
         if ev_host is not None:
             graph.edge_vec.copy_(ev_host, non_blocking=True)
+        elif pos_host is not None:
+            pos_dev.copy_(pos_host, non_blocking=True)
+            _lib.check(lib_.snet_edge_vectors(C.c_void_p(pos_dev.data_ptr()), C.c_void_p(graph.center.data_ptr()),
+                                              C.c_void_p(graph.src.data_ptr()), C.c_void_p(shift_dev.data_ptr()), graph.n_edges,
+                                              C.c_void_p(graph.edge_vec.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'snet_edge_vectors')
         return nat.compute(graph) if nat is not None else eng.compute(graph, halo=halo)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_mode:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -312,7 +345,7 @@ def main():
     t_enq = time.perf_counter() - t0  # host time to enqueue K steps (kernels run asynchronously)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_mode:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -381,7 +414,7 @@ def main():
                         "avg_ms of the dominant kernel is measured with that concurrent work present")
     step_ms = dt / a.steps * 1e3
     e_total = out['energy'].clone()
-    if world > 1:  # ranks hold partial energies of their bricks
+    if dist_mode:  # ranks hold partial energies of their bricks
         dist.all_reduce(e_total)
     roof['kernel_ms_per_step'] = {k: round(v / n_break, 4) for k, v in sorted(totals.items(), key=lambda kv: -kv[1])}
     roof['avg_ms_source'] = 'HIP events inside the timed steps' if len(timed_dom) else 'HIP events of an untimed pass of the same kernels (native host)'
@@ -395,6 +428,16 @@ def main():
                                  'credit, radial weights not materialised); fractions of 8 TB/s and of the 157.3 TFLOP/s fp32 '
                                  'matrix peak over the measured step time')
 
+    # ghost exchange of this rank per step: L-1 forward (width dx_t) + L-1 reverse exchanges + one force fold; bytes = rows
+    # sent + received; time = HIP-event brackets around the exchange calls (with the split exchange the brackets cover
+    # only the enqueue + the final wait, i.e. the part that is NOT hidden behind compute)
+    halo_ms, halo_n, halo_bytes = 0.0, 0, 0
+    if dist_mode:
+        halo_ms = sum(v for k, v in totals.items() if k.startswith('halo')) / n_break
+        rows = int(sum(len(s_) for s_ in bg.send_lists)) + int(graph.n_total - graph.n_local)
+        dims = [ls.si1.dim_out for ls in eng.spec.layers[1:]]
+        halo_n = 2 * len(dims) + 1
+        halo_bytes = rows * 4 * (2 * sum(dims) + 3)
     if rank == 0:
         res = {
             'metric': 'atom-steps/sec (energy+forces), SevenNet-0 100k-atom cell, 1/2/4/8 MI355X' if a.model == 'sevennet_0'
@@ -406,17 +449,23 @@ def main():
                                    f'cell (a=5.431 A x {a.reps}^3, {wl_note}), cutoff {cfg["cutoff"]} A, '
                                    f'{n_edges_total} directed edges, seeded synthetic weights',
                        'atoms': n_atoms, 'edges': n_edges_total,
-                       'parallelism': 'single GPU' if world == 1 else f'spatial decomposition x{world}, RCCL halo',
+                       'parallelism': 'single GPU' if not dist_mode else f'spatial decomposition x{world}, RCCL halo',
                        'graph_build_s': round(t_graph, 3),
                        'host': a.host, 'host_enqueue_ms_per_step': round(t_enq / a.steps * 1e3, 3),
-                       'h2d_in_step': (None if ev_host is None else
-                                       f'edge_vec [E,3] fp32 = {ev_host.numel() * 4 / 1e6:.1f} MB from pinned host memory every step'),
+                       'h2d_in_step': (f'edge_vec [E,3] fp32 = {ev_host.numel() * 4 / 1e6:.1f} MB from pinned host memory every step'
+                                       if ev_host is not None else
+                                       f'positions [n,3] fp64 = {pos_host.numel() * 8 / 1e6:.2f} MB from pinned host memory every step; '
+                                       'edge vectors formed on the GPU (snet_edge_vectors) from the resident topology'
+                                       if pos_host is not None else None),
                        'fused': a.fused, 'terms': a.terms,
-                       'halo': (None if world == 1 else ('libsnet_hip RCCL send/recv groups' if type(halo).__name__ == 'NativeHalo'
+                       'halo': (None if not dist_mode else ('libsnet_hip RCCL send/recv groups' if type(halo).__name__ == 'NativeHalo'
                                                           else f'torch.distributed all_to_all_single ({backend})')),
-                       'halo_overlap': (None if world == 1 else bool(getattr(halo, 'overlap', True))),
-                       'ghost_rows_rank0': (None if world == 1 else int(graph.n_total - graph.n_local)),
-                       'halo_ms_per_step_rank0': (None if world == 1 else round(sum(v for k, v in totals.items() if k.startswith('halo')) / n_break, 4)),
+                       'halo_overlap': (None if not dist_mode else bool(getattr(halo, 'overlap', True))),
+                       'ghost_rows_rank0': (None if not dist_mode else int(graph.n_total - graph.n_local)),
+                       'halo_ms_per_step_rank0': (None if not dist_mode else round(halo_ms, 4)),
+                       'halo_exchanges_per_step': (None if not dist_mode else halo_n),
+                       'halo_bytes_per_step_rank0': (None if not dist_mode else halo_bytes),
+                       'halo_gbs_rank0': (None if not dist_mode or halo_ms <= 0 else round(halo_bytes / (halo_ms * 1e-3) / 1e9, 2)),
                        'kernel_ms_per_step_rank0': round(sum(v for k, v in totals.items() if not k.startswith('halo')) / n_break, 3),
                        'energy': float(e_total.cpu())},
             'roofline': roof,
@@ -431,7 +480,7 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_mode:
         dist.destroy_process_group()
 
 

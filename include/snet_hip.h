@@ -51,6 +51,12 @@ typedef struct snet_edge_params {
   int32_t normalize;   /* SH on unit vector (1) or raw vector (0, <0.10 checkpoints) */
 } snet_edge_params;
 
+/* Per-step input of an MD host: positions, not edge vectors.  edge_vec[e] = pos[src[e]] - pos[center[e]] + shift[e]
+ * (fp64 positions [n_total,3] and per-edge periodic-image offsets shift[E,3] = S.cell, nullable = no images; the
+ * subtraction runs in fp64, as in the reference's hosts: pair_e3gnn.cpp:160-175, train/dataload.py:62-70).  With the
+ * topology resident, a step uploads 24 bytes per atom instead of 12 bytes per edge. */
+int snet_edge_vectors(const double *pos, const int32_t *center, const int32_t *src, const double *shift, int64_t n_edges,
+                      float *edge_vec, void *stream);
 /* edge_vec[E,3] -> emb[E,n_basis], sh[E,nsh], nsh = (lmax+1)^2; coeffs_host[n_basis] = Bessel c_n
  * (HOST).  dsh (nullable) receives the Jacobian d sh[e,i] / d edge_vec[e,a] as [E,nsh,3]; the
  * tensor-product reverse kernel contracts with it so only 3 values per edge are reduced. */
@@ -170,7 +176,8 @@ int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, c
  *   g_emb[E,nb] ACCUMULATED: the kernel also reverses the MLP's two hidden layers per 16-edge tile (it reads
  *               emb[E,nb], the radial basis values per DIRECTED edge), so g_h2 never reaches memory either.
  *               Needs snet_fused_plan_has_mlp_tail(plan) != 0 (n_basis <= 16 and a multiple of 4).
- * x_rowmax[n_rows of x] / g_rowmax[n_dst]: snet_row_absmax of x and g_out; required for terms = 4, ignored (NULL) otherwise.
+ * x_rowmax[n_rows of x] / g_rowmax[n_dst]: upper bounds of max|x[row]| and max|g_out[node]| (snet_row_absmax, or
+ *   snet_row_norm2 of the linear map's input that produced g_out); required for terms = 4, ignored (NULL) otherwise.
  * snet_conv_fused_available() != 0 iff the shape has these kernels (channel multiplicities % 16 == 0). */
 #define SNET_FUSED_TERMS_DEFAULT 4
 typedef struct snet_fused_plan snet_fused_plan;
@@ -195,6 +202,10 @@ int snet_fused_plan_has_mlp_tail(const snet_fused_plan *plan);
  * power of two derived from a BOUND of |g_w| -- (sum |C|) max|g_out[node]| max|x[src]| max|Y_e| -- so that no entry can
  * overflow fp16 whatever the model's feature magnitudes are; the two row maxima come from this kernel. */
 int snet_row_absmax(const float *x, int64_t n_rows, int32_t dim, float *out, void *stream);
+/* out[r] = mult * ||x[r,:]||_2.  With mult = the largest row norm of a linear map's matrix this bounds every entry of
+ * the map's output row (Cauchy-Schwarz): both hosts bound g_out = SI2^T g_y this way from the 5x narrower g_y instead
+ * of reading g_out[N, dmid] once more (g_rowmax of snet_conv_bwd_fused may be ANY upper bound of max|g_out[node]|). */
+int snet_row_norm2(const float *x, int64_t n_rows, int32_t dim, float mult, float *out, void *stream);
 /* per-edge gradients given g_out[n_dst,dout]: g_w[E,wn] (overwritten), g_sh[E,nsh] (ACCUMULATED,
  * so one buffer collects all layers) and, if g_xe != NULL, this edge's contribution to the gradient
  * of its source row, g_xe[E,dx] (overwritten; sum it per source node with snet_segment_sum_rows --

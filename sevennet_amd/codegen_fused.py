@@ -1018,7 +1018,15 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         # win its stand-alone timing (3.21 vs 3.46 ms) but lose inside the step with the hidden-layer tail (4.04 vs 3.53)
         if len(cats) == 1 and bwd_lds(nt, 8) <= 80 * 1024:
             return (8, 0, 2)
-        if bwd_lds(nt, 4) <= 53 * 1024:
+        # three waves per SIMD only where the kernel's live state fits 168 VGPRs: source rows, their prefetch and their
+        # gradient (3 x 4 d1), h2^T split and g_h2 accumulators (32), Y gradient, g_out prefetch, slab staging, one
+        # path's g_out entries, addresses / scales.  The SevenNet-0 middle layer needs ~200: at 168 the compiler spilled
+        # 38 registers and the spill traffic queues with the prefetch loads (round 3, same box: 6.80 ms at three waves
+        # with spills, 6.43 at two waves without)
+        maxd1 = max(2 * c.l1 + 1 for c in cats)
+        maxd3 = max(2 * p.l3 + 1 for p in spec.paths)
+        live = 12 * maxd1 + 32 + NSH + 4 * NK + 16 + 4 * maxd3 + 35
+        if bwd_lds(nt, 4) <= 53 * 1024 and live <= 168:
             return (4, 0, 3)
         if bwd_lds(nt, 4) <= 80 * 1024:
             return (4, 0, 2)

@@ -174,7 +174,29 @@ int prepare(const snet_edge_params *p, const float *coeffs_host, EdgeP &P) {
   return 0;
 }
 
+// edge_vec[e] = pos[src[e]] - pos[center[e]] + shift[e], differences in fp64 (positions of a 100-A cell carry an fp32
+// ulp of 8e-6 A; the reference's hosts -- ASE, LAMMPS -- also subtract in double and only then go to fp32)
+__global__ void edge_vectors_kernel(const double *__restrict__ pos, const int32_t *__restrict__ center,
+                                    const int32_t *__restrict__ src, const double *__restrict__ shift, int64_t E,
+                                    float *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const double *pj = pos + 3 * (int64_t)src[e], *pi = pos + 3 * (int64_t)center[e];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) out[3 * e + k] = (float)(pj[k] - pi[k] + (shift ? shift[3 * e + k] : 0.0));
+}
+
 }  // namespace
+
+extern "C" int snet_edge_vectors(const double *pos, const int32_t *center, const int32_t *src, const double *shift,
+                                 int64_t E, float *edge_vec, void *stream) {
+  if (E <= 0) return 0;
+  SNET_REQUIRE(pos && center && src && edge_vec, "snet_edge_vectors: null argument");
+  edge_vectors_kernel<<<(unsigned)((E + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(pos, center, src, shift, E,
+                                                                                              edge_vec);
+  SNET_CHECK_LAUNCH("snet_edge_vectors");
+  return 0;
+}
 
 extern "C" int snet_edge_embed_fwd(const snet_edge_params *p, const float *coeffs, const float *edge_vec,
                                    int64_t E, float *emb, float *sh, float *dsh, void *stream) {

@@ -4,10 +4,13 @@
 // calls instead of `model.forward` + `torch::autograd::grad`.  Same op sequence as the Python host
 // (sevennet_amd/engine.py), no torch, no Python.  Ghost-feature exchange is left to the host through
 // two callbacks invoked at the reference's exchange points (pair_e3gnn_parallel.cpp:369,435).
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -62,6 +65,7 @@ struct Linear {
   };
   std::vector<Group> fwd, rev;  // launch plans: per-irrep GEMMs with distinct targets share a launch
   float *bias = nullptr;        // device [dim_out]: constant row bias of a multi-modal linear, or null
+  float t_norm = 0.f;           // largest row norm of the transposed map: |(L^T g)[k]| <= t_norm ||g||_2
   bool present() const { return dim_out > 0; }
 };
 
@@ -152,6 +156,7 @@ bool read_linear(Reader &r, Linear &L) {
     const int off = r.i32(), len = r.i32();
     L.zero_in.push_back({off, len});
   }
+  std::map<std::pair<int, int>, std::vector<double>> row_sq;
   for (auto &b : L.blocks) {
     std::vector<float> w = r.farr((size_t)b.mul_in * b.mul_out);
     if (!r.ok) return false;
@@ -159,7 +164,14 @@ bool read_linear(Reader &r, Linear &L) {
     for (int k = 0; k < b.mul_in; ++k)
       for (int n = 0; n < b.mul_out; ++n) wt[(size_t)n * b.mul_in + k] = w[(size_t)k * b.mul_out + n];
     if (!upload_split(w, b.mul_in, b.mul_out, &b.W) || !upload_split(wt, b.mul_out, b.mul_in, &b.WT)) return false;
+    // squared norms of the rows of w (one per input channel), summed over the blocks that feed the same input block
+    auto &sq = row_sq[{b.in_off, b.species}];
+    sq.resize((size_t)b.mul_in, 0.0);
+    for (int k = 0; k < b.mul_in; ++k)
+      for (int n = 0; n < b.mul_out; ++n) sq[k] += (double)w[(size_t)k * b.mul_out + n] * w[(size_t)k * b.mul_out + n];
   }
+  for (auto &kv : row_sq)
+    for (double v : kv.second) L.t_norm = std::max(L.t_norm, (float)std::sqrt(v));
   const int has_bias = r.i32();
   if (!r.ok || (has_bias != 0 && has_bias != 1)) return false;
   if (has_bias) {
@@ -625,7 +637,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
         x_max = A.f((size_t)NT);
         g_max = A.f((size_t)N);
         if ((rc = snet_row_absmax(saved[t].h, NT, L.dx, x_max, st))) return rc;
-        if ((rc = snet_row_absmax(g_m, N, L.dmid, g_max, st))) return rc;
+        if ((rc = snet_row_norm2(g_y, N, L.gin, L.si2.t_norm, g_max, st))) return rc;  // g_m = SI2^T g_y (Cauchy-Schwarz)
       }
       if (E > 0 && (rc = snet_conv_bwd_fused(L.fused, saved[t].h, sh, dsh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src,
                                              tile_ptr, tile_node, n_tiles, L.conv_scale, g_m, g_xe, g_h2,

@@ -165,6 +165,25 @@ __global__ void row_absmax_kernel(const float *__restrict__ x, int64_t n_rows, i
   if (lane == 0) out[r] = m;
 }
 
+// out[r] = mult * ||x[r, :]||_2 (fp32 sum of squares: a bound needs no more)
+__global__ void row_norm2_kernel(const float *__restrict__ x, int64_t n_rows, int dim, float mult, float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const float *row = x + r * dim;
+  float m = 0.f;
+  if ((dim & 3) == 0) {
+    for (int k = 4 * lane; k < dim; k += 256) {
+      const float4 v = *reinterpret_cast<const float4 *>(row + k);
+      m = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, m))));
+    }
+  } else {
+    for (int k = lane; k < dim; k += 64) m = fmaf(row[k], row[k], m);
+  }
+  for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
+  if (lane == 0) out[r] = mult * sqrtf(m) * 1.0001f;
+}
+
 // out[s, c] = sum over the segment's rows; lanes over columns (coalesced row reads), 4 rows in flight
 __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__restrict__ x, const int32_t *__restrict__ seg,
                                                                const int32_t *__restrict__ perm, int dim,
@@ -326,6 +345,14 @@ extern "C" int snet_row_absmax(const float *x, int64_t n_rows, int32_t dim, floa
   SNET_REQUIRE(x != nullptr && out != nullptr, "snet_row_absmax: null argument");
   row_absmax_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(x, n_rows, dim, out);
   SNET_CHECK_LAUNCH("snet_row_absmax");
+  return 0;
+}
+extern "C" int snet_row_norm2(const float *x, int64_t n_rows, int32_t dim, float mult, float *out, void *stream) {
+  SNET_REQUIRE(dim >= 1 && n_rows < (1ll << 33), "snet_row_norm2: bad shape");
+  if (n_rows <= 0) return 0;
+  SNET_REQUIRE(x != nullptr && out != nullptr, "snet_row_norm2: null argument");
+  row_norm2_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(x, n_rows, dim, mult, out);
+  SNET_CHECK_LAUNCH("snet_row_norm2");
   return 0;
 }
 extern "C" int snet_segment_sum_rows(const float *x, const int32_t *seg_ptr, const int32_t *perm, int64_t n_seg,

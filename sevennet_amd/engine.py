@@ -176,6 +176,12 @@ class _Linear:
             self.wt = [torch.from_numpy(np.ascontiguousarray(m.T)).to(dev) for m in mats]
         self.groups_fwd = self._plan(transpose=False)
         self.groups_T = self._plan(transpose=True)
+        # largest row norm of the TRANSPOSED map: |(Linear^T g)[k]| <= t_norm * ||g||_2 for every input entry k
+        # (Cauchy-Schwarz over all blocks that feed the same input block; per species for the FCTP self-connection)
+        acc = {}
+        for b, m in zip(spec.blocks, mats):
+            acc[(b.in_off, b.species)] = acc.get((b.in_off, b.species), 0.0) + (np.asarray(m, np.float32).astype(np.float64) ** 2).sum(1)   # fp32 weights, as the native host reads them
+        self.t_norm = float(max(np.sqrt(v).max() for v in acc.values())) if acc else 0.0
 
     def _plan(self, transpose: bool):
         """-> list of (species, GemmDesc array, n, first_use_accumulates[list of target offsets])"""
@@ -630,10 +636,12 @@ class HipForceEngine:
                     if self.fused_terms == 4 and E > 0:
                         # fp16 operands: row maxima of the source rows and of the incoming gradient bound every edge's
                         # g_w, from which the kernel derives that edge's power-of-two scale (no overflow possible)
+                        # (g_m = SI2^T g_y: bounded through the 5x narrower g_y and SI2's largest row norm)
                         x_max, g_max = self._new(NT), self._new(N)
-                        with _Span(self, 'row_absmax'):
+                        with _Span(self, 'row_bounds'):
                             _lib.check(lib.snet_row_absmax(_ptr(h), NT, ls.si1.dim_out, _ptr(x_max), st), 'snet_row_absmax')
-                            _lib.check(lib.snet_row_absmax(_ptr(g_m), N, ls.conv.irreps_out.dim, _ptr(g_max), st), 'snet_row_absmax')
+                            _lib.check(lib.snet_row_norm2(_ptr(g_y), N, ls.gate.irreps_in.dim, L.si2.t_norm, _ptr(g_max), st),
+                                       'snet_row_norm2')
                     with _Span(self, f'conv_bwd_fused[{ls.conv.tag}]'):
                         if E > 0:
                             _lib.check(lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(w_row),

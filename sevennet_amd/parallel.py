@@ -245,14 +245,14 @@ class RcclComm:
         if rank == 0:
             _lib.check(self.lib.snet_rccl_unique_id(C.cast(ident, C.c_void_p)), 'snet_rccl_unique_id')
         raw = bytes(ident.raw)
-        if world > 1:
-            if bcast is None:
-                import torch.distributed as dist
+        if bcast is not None:
+            raw = bcast(raw)
+        else:
+            import torch.distributed as dist
+            if world > 1 or (dist.is_available() and dist.is_initialized()):   # world 1 inside a process group: same path
                 box = [raw]
                 dist.broadcast_object_list(box, src=0)
                 raw = box[0]
-            else:
-                raw = bcast(raw)
         buf = (C.c_char * 128).from_buffer_copy(raw)
         self.handle = C.c_void_p()
         _lib.check(self.lib.snet_rccl_comm_create(C.cast(buf, C.c_void_p), world, rank, C.byref(self.handle)),

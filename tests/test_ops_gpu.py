@@ -707,3 +707,27 @@ def test_rescale_reduce_vs_reference_modules():
                                   ('sm', d['rs_species_shift'], cm[modal])):
             ea, _ = run(scale, shift)
             assert np.abs(ea - d[f'rs_modal_{tag}_{modal}'][:, 0]).max() <= 1e-6, (tag, modal)
+
+
+def test_edge_vectors_from_positions():
+    """snet_edge_vectors: r_j - r_i + image offset, subtracted in fp64 (positions near 125 A have an fp32 ulp of 8e-6 A:
+    an fp32 subtraction would miss the reference hosts' edge vectors by 1e-5 A)"""
+    L, lib = _lib()
+    dev = 'cuda:0'
+    from sevennet_amd.neighbor import diamond_cubic, neighbor_list
+    pos, cell = diamond_cubic(5.431, (3, 3, 3), 0.05, 1)
+    pos = pos + 110.0          # far from the origin
+    ei, ev, S = neighbor_list(pos, cell, [True] * 3, 5.0)
+    shift = S.astype(np.float64) @ cell
+    assert np.abs(pos[ei[1]] - pos[ei[0]] + shift - ev).max() < 1e-9
+    pd = torch.from_numpy(pos).to(dev)
+    c, s_ = (torch.from_numpy(ei[k]).to(dev, torch.int32) for k in (0, 1))
+    sd = torch.from_numpy(np.ascontiguousarray(shift)).to(dev)
+    out = torch.empty(ei.shape[1], 3, device=dev)
+    L.check(lib.snet_edge_vectors(_p(pd), _p(c), _p(s_), _p(sd), ei.shape[1], _p(out), None))
+    torch.cuda.synchronize()
+    want = torch.from_numpy(ev).to(torch.float32)
+    assert (out.cpu() - want).abs().max() <= 2.4e-7 * 5.0        # one fp32 ulp of a cutoff-length vector
+    assert (out.cpu() == want).float().mean() > 0.99
+    naive = (pd.float()[s_.long()] - pd.float()[c.long()] + sd.float()).cpu()
+    assert (naive - want).abs().max() > 3e-6                      # what the fp64 subtraction avoids
