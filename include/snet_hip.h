@@ -170,7 +170,8 @@ int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, c
  *   tile_ptr   int32[n_dst+1], exclusive scan of ceil(degree/16), and tile_node int32[n_tiles] (tile -> node), both
  *              from snet_edge_tiles: the reverse kernel gives each 16-edge tile of a node's CSR segment to one
  *              wavefront (tile_node capacity: n_dst + n_edges / 16 entries always suffice)
- * reverse outputs: g_xe[E,dx] (nullable; sum per source with snet_segment_sum_rows), g_vec[E,3] ACCUMULATED (as
+ * reverse outputs: g_xe[E,dx] (nullable; chunk order of snet_fused_plan_gxe_chunks; sum per source with
+ * snet_segment_sum_rows_chunked), g_vec[E,3] ACCUMULATED (as
  * snet_conv_bwd_edge_vec), and exactly ONE of
  *   g_h2[E,64]  overwritten; feed to snet_radial_mlp_hidden_bwd, or
  *   g_emb[E,nb] ACCUMULATED: the kernel also reverses the MLP's two hidden layers per 16-edge tile (it reads
@@ -198,6 +199,13 @@ int snet_conv_bwd_fused(const snet_fused_plan *plan, const float *x, const float
                         const float *g_out, float *g_xe, float *g_h2, const float *emb, float *g_emb, float *g_vec,
                         const float *x_rowmax, const float *g_rowmax, void *stream);
 int snet_fused_plan_has_mlp_tail(const snet_fused_plan *plan);
+/* g_xe[E,dx] of snet_conv_bwd_fused is an intermediate with its own row layout: the 16-channel chunks of a row are stored in
+ * the order the kernel produces them ([x block][channel tile][component]: each (block, tile) writes one contiguous run per
+ * edge instead of half cache lines).  chunk_pos[s] (dx / 16 entries, host) = position of standard chunk s in the row;
+ * snet_segment_sum_rows_chunked (chunk_pos on the DEVICE) sums such rows per source atom and returns standard order. */
+int snet_fused_plan_gxe_chunks(const snet_fused_plan *plan, int32_t *chunk_pos, int32_t capacity);
+int snet_segment_sum_rows_chunked(const float *x, const int32_t *seg_ptr, const int32_t *perm, int64_t n_seg, int32_t dim,
+                                  const int32_t *chunk_pos, float *out, void *stream);
 /* out[r] = max_k |x[r,k]| for r < n_rows.  The f16x3 reverse kernel (terms = 4) scales its fp16 operand g_w per edge by a
  * power of two derived from a BOUND of |g_w| -- (sum |C|) max|g_out[node]| max|x[src]| max|Y_e| -- so that no entry can
  * overflow fp16 whatever the model's feature magnitudes are; the two row maxima come from this kernel. */
@@ -440,6 +448,33 @@ int snet_md_compute(snet_md_host *host, int32_t inum, const int32_t *ilist, cons
                     int32_t eflag_atom, int32_t vflag, int32_t vflag_atom, double *f, double *eng, double *virial,
                     double *eatom, double *vatom, int32_t *node_to_atom_out, int64_t *n_nodes_out,
                     int64_t *n_edges_out, void *stream);
+
+/* ---- DFT-D3 dispersion -----------------------------------------------------------------------------
+ * What the reference's CUDA library behind sevenn.calculator.D3Calculator computes (pair_d3_for_ase.cu), as own HIP
+ * kernels (csrc/snet_d3.hip: one workgroup per atom over its (neighbour, lattice translation) row, fp64, deterministic
+ * reductions), behind the same call sequence as the reference's C-ABI (pair_d3_for_ase.cu:2034-2082):
+ *   pair_init          -> snet_d3_create            pair_run_coeff     -> snet_d3_set_tables (published tables, from the
+ *   pair_set_atom      -> snet_d3_set_atoms                               blob sevennet_amd/data/d3_params.npz) + set_atoms
+ *   pair_set_domain    -> snet_d3_set_cell          pair_run_compute   -> snet_d3_compute
+ *   pair_run_settings  -> snet_d3_settings          pair_get_energy / _force / _stress -> snet_d3_energy / _forces / _stress
+ *   pair_fin           -> snet_d3_destroy
+ * Units at the boundary: A, eV, eV/A, eV/A^3; cutoffs in bohr^2 like the reference (vdw 9000, cn 1600).
+ *   snet_d3_set_tables  r0ab[94*94] (A), c6ab[n_c6*5] (C6, Z_i + 100 ref_i, Z_j + 100 ref_j, CN_i, CN_j), r2r4[94], rcov[94]
+ *   snet_d3_settings    damping 0 = damp_zero, 1 = damp_bj; func5 = (s6, rs6, s18, rs18, alp) of the functional
+ *   snet_d3_set_cell    cell[9]: lattice vectors as rows (any orientation: no LAMMPS-style rotation needed), pbc[3]
+ *   snet_d3_stress      [9] = dE/d(strain) / volume, row-major symmetric (ASE sign convention)                          */
+typedef struct snet_d3 snet_d3;
+int snet_d3_create(snet_d3 **out);
+void snet_d3_destroy(snet_d3 *d3);
+int snet_d3_set_tables(snet_d3 *d3, const double *r0ab, const double *c6ab, int64_t n_c6, const double *r2r4, const double *rcov);
+int snet_d3_settings(snet_d3 *d3, double vdw_cutoff_au2, double cn_cutoff_au2, int32_t damping, const double *func5);
+int snet_d3_set_atoms(snet_d3 *d3, int32_t n, const int32_t *atomic_numbers, const double *positions);
+int snet_d3_set_cell(snet_d3 *d3, const double *cell9, const int32_t *pbc3);
+int snet_d3_compute(snet_d3 *d3, void *stream);
+double snet_d3_energy(const snet_d3 *d3);
+const double *snet_d3_forces(const snet_d3 *d3);
+const double *snet_d3_stress(const snet_d3 *d3);
+const double *snet_d3_coordination_numbers(const snet_d3 *d3);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,8 @@ SIGNATURES = {
                                       c_i32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                       c_stream]),
     'snet_fused_plan_has_mlp_tail': (C.c_int, [C.c_void_p]),
+    'snet_fused_plan_gxe_chunks': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]),
+    'snet_segment_sum_rows_chunked': (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, c_i32p, c_f32p, c_stream]),
     'snet_edge_vectors': (C.c_int, [c_f64p, c_i32p, c_i32p, c_f64p, C.c_int64, c_f32p, c_stream]),
     'snet_row_absmax': (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, c_stream]),
     'snet_row_norm2': (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_float, c_f32p, c_stream]),
@@ -134,6 +136,17 @@ SIGNATURES = {
     'snet_model_set_rccl_halo': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'snet_edge_pairs': (C.c_int, [c_i32p, c_i32p, c_f32p, C.c_int64, C.c_int64, c_i32p, c_i32p, C.POINTER(C.c_int64),
                                   c_stream]),
+    'snet_d3_create': (C.c_int, [C.POINTER(C.c_void_p)]),
+    'snet_d3_destroy': (None, [C.c_void_p]),
+    'snet_d3_set_tables': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'snet_d3_settings': (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_void_p]),
+    'snet_d3_set_atoms': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    'snet_d3_set_cell': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'snet_d3_compute': (C.c_int, [C.c_void_p, c_stream]),
+    'snet_d3_energy': (C.c_double, [C.c_void_p]),
+    'snet_d3_forces': (C.POINTER(C.c_double), [C.c_void_p]),
+    'snet_d3_stress': (C.POINTER(C.c_double), [C.c_void_p]),
+    'snet_d3_coordination_numbers': (C.POINTER(C.c_double), [C.c_void_p]),
     'snet_md_create': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     'snet_md_destroy': (None, [C.c_void_p]),
     'snet_md_nodes': (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]),

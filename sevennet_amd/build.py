@@ -30,7 +30,7 @@ _sfx = ('_' + os.path.basename(LIB).replace('.so', '')) if os.environ.get('SNET_
 GEN = os.path.join(CSRC, 'generated' + _sfx)
 OBJ = os.path.join(CSRC, 'build' + _sfx)
 ARCH = 'gfx950'
-STATIC_SOURCES = ['snet_api.cpp', 'snet_model.cpp', 'snet_halo.cpp', 'snet_gemm.hip', 'snet_mlp.hip', 'snet_edge.hip', 'snet_node.hip', 'snet_force.hip', 'snet_neighbor.hip', 'snet_md.hip']
+STATIC_SOURCES = ['snet_api.cpp', 'snet_model.cpp', 'snet_halo.cpp', 'snet_gemm.hip', 'snet_mlp.hip', 'snet_edge.hip', 'snet_node.hip', 'snet_force.hip', 'snet_neighbor.hip', 'snet_md.hip', 'snet_d3.hip']
 
 
 def _hipcc() -> str:

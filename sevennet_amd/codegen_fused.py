@@ -209,6 +209,19 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     NSHP = NSH + 1 if (4 * NSH) % 32 == 0 else NSH
     A(f'constexpr int DX = {DX}, DOUT = {DOUT}, NSH = {NSH}, NSHP = {NSHP}, WN = {WN}, NS = {NS};')
     A('const int32_t SUB_COLS[NS * 2] = {' + ', '.join(f'{a}, {b}' for a, b in cols) + '};')
+    # g_xe[E, DX] is a private intermediate (reverse kernel -> segment sum): inside a row its 16-channel chunks are kept in
+    # the order the kernel produces them, [x block][channel tile][component], so that the 2 l + 1 stores of one
+    # (block, tile) write one contiguous run per edge (whole 128-byte lines) instead of 64-byte halves of lines whose other
+    # half arrives one channel tile later.  GXE_CHUNK[standard chunk] = chunk position inside the g_xe row.
+    gxe_chunk = list(range(DX // 16))
+    gxe_std = bool(OPTS.get('gxestd'))   # kernel-tuning builds: standard row order (round-2 layout) for A/B runs
+    for cat in ([] if gxe_std else cats):
+        d1c = 2 * cat.l1 + 1
+        for ct in range(cat.mul // 16):
+            for m in range(d1c):
+                gxe_chunk[(cat.x_off + m * cat.mul) // 16 + ct] = cat.x_off // 16 + ct * d1c + m
+    assert sorted(gxe_chunk) == list(range(DX // 16))
+    A(f'const int32_t GXE_CHUNK[{DX // 16}] = {{' + ', '.join(str(v) for v in gxe_chunk) + '};')
     A('')
 
     def out_index(p, m3):
@@ -492,11 +505,14 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A('      ++sidx;')
             A('    }')
         A('    if (g_xe && valid' + (' && !(diag & 16)' if exp else '') + ') {')
-        A(f'      float *o = g_xe + (size_t)e * DX + {cat.x_off} + 16 * ct + 4 * g;')
+        if gxe_std:
+            A(f'      float *o = g_xe + (size_t)e * DX + {cat.x_off} + 16 * ct + 4 * g;')
+        else:
+            A(f'      float *o = g_xe + (size_t)e * DX + {cat.x_off} + {16 * d1} * ct + 4 * g;   // chunk order [tile][component]: GXE_CHUNK')
         for m in range(d1):
-            # streaming stores: a row's two 64-byte halves are written one channel tile apart; kept in L2 the first
-            # half is usually evicted alone before its partner arrives (PMC: 8.9 GB written for 5.9 GB of output)
-            A(f'      __builtin_nontemporal_store(gx[{m}], reinterpret_cast<f32x4 *>(o + {m * cat.mul}));')
+            # streaming stores (kept in L2, partially written lines were evicted before their other half arrived:
+            # 8.9 GB written for 5.9 GB of output in round 2)
+            A(f'      __builtin_nontemporal_store(gx[{m}], reinterpret_cast<f32x4 *>(o + {m * cat.mul if gxe_std else 16 * m}));')
         A('    }')
         # park the prefetched entries of the next block in the other buffer (last read one block ago)
         if nct > 1:
@@ -1071,7 +1087,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         if len(cats) == 1 and fwd_lds(nt, 8) <= 80 * 1024:   # first layer (scalar inputs only): 0.87 vs 1.03 ms
             return (8, 1, 2)
         if nt <= 2 and fwd_lds(nt, 12) <= 160 * 1024:
-            return (12, 1, 3)
+            return (12, 0 if OPTS.get('f12reg') else 1, 3)
         for w in (8, 4, 2, 1):
             if fwd_lds(nt, w) <= 160 * 1024:
                 return (w, 1, 2)
@@ -1083,7 +1099,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         cond = f' (nt == {nt_})' if kw != 'else' else ''
         A(f'  {kw}{cond} launch_fwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
     A('}')
-    A(f'const snet::FusedKernels kernels = {{"{tag}", DX, DOUT, NSH, WN, NS, SUB_COLS, launch_bwd, launch_fwd}};')
+    A(f'const snet::FusedKernels kernels = {{"{tag}", DX, DOUT, NSH, WN, NS, SUB_COLS, GXE_CHUNK, launch_bwd, launch_fwd}};')
     A('const snet::FusedRegistrar registrar(&kernels);')
     A('}  // namespace')
     return '\n'.join(L) + '\n'

@@ -164,6 +164,13 @@ int snet_conv_fwd_fused(const snet_fused_plan *fp, const float *x, const float *
   SNET_CHECK_LAUNCH("snet_conv_fwd_fused");
   return 0;
 }
+int snet_fused_plan_gxe_chunks(const snet_fused_plan *fp, int32_t *chunk_pos, int32_t capacity) {
+  SNET_REQUIRE(fp != nullptr && chunk_pos != nullptr, "snet_fused_plan_gxe_chunks: null argument");
+  const int n = fp->k->dx / 16;
+  SNET_REQUIRE(capacity >= n, "snet_fused_plan_gxe_chunks: capacity below dx / 16");
+  for (int i = 0; i < n; ++i) chunk_pos[i] = fp->k->gxe_chunk[i];
+  return 0;
+}
 int snet_fused_plan_has_mlp_tail(const snet_fused_plan *fp) { return fp != nullptr && fp->hidden.w0 != nullptr; }
 
 int snet_conv_bwd_fused(const snet_fused_plan *fp, const float *x, const float *sh, const float *dsh, const float *h2,

@@ -75,6 +75,9 @@ struct FusedKernels {
   int dx, dout, nsh, wn;
   int n_sub;
   const int32_t *sub_cols;
+  // g_xe rows are written in the kernel's own chunk order: gxe_chunk[standard 16-channel chunk] = its position in the row
+  // (dx / 16 entries); snet_segment_sum_rows_chunked undoes it while it sums
+  const int32_t *gxe_chunk;
   // reverse pass of one tile list (snet_edge_tiles): g_xe[E,dx] (nullable), g_vec[E,3] +=, and either g_h2[E,64]
   // or (tail.g_emb set) the radial MLP's hidden layers reversed in the same kernel: g_emb[E,nb] +=
   // nt = precision mode of the in-kernel products: 1 / 2 / 3 bf16 terms per operand, 4 = two fp16 terms ("f16x3")

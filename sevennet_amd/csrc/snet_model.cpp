@@ -114,6 +114,7 @@ struct Layer {
   snet_conv_plan *conv = nullptr;
   snet_mlp_plan *mlp_plan = nullptr;
   snet_fused_plan *fused = nullptr;  // radial-MLP last layer inside the tensor-product kernels (where the shape has them)
+  int32_t *gxe_chunks = nullptr;     // device: chunk order of the fused reverse kernel's g_xe rows (dx / 16 entries)
   Linear sc, si1, si2;
   std::vector<snet_gate_seg> segs;
 };
@@ -305,6 +306,12 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
     if (good && getenv("SNET_NO_FUSED") == nullptr && snet_conv_fused_available(L.conv) &&
         snet_fused_plan_create(L.conv, L.mlp_plan, SNET_FUSED_TERMS_DEFAULT, &L.fused))
       good = false;
+    if (good && L.fused) {
+      std::vector<int32_t> cp((size_t)L.dx / 16);
+      good = snet_fused_plan_gxe_chunks(L.fused, cp.data(), (int32_t)cp.size()) == 0 &&
+             hipMalloc((void **)&L.gxe_chunks, cp.size() * 4) == hipSuccess &&
+             hipMemcpy(L.gxe_chunks, cp.data(), cp.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
     good = good && read_linear(r, L.sc) && read_linear(r, L.si1) && read_linear(r, L.si2);
     if (good) {
       const int ns = r.i32();
@@ -368,6 +375,7 @@ extern "C" void snet_model_destroy(snet_model *m) {
   };
   for (auto &L : m->layers) {
     snet_fused_plan_destroy(L.fused);
+    if (L.gxe_chunks) (void)hipFree(L.gxe_chunks);
     snet_conv_plan_destroy(L.conv);
     snet_radial_mlp_plan_destroy(L.mlp_plan);
     free_lin(L.sc); free_lin(L.si1); free_lin(L.si2);
@@ -645,7 +653,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
         return rc;
       if (t > 0) {
         float *g_h = A.f((size_t)NT * L.dx);
-        if ((rc = snet_segment_sum_rows(g_xe, col_ptr, eperm, NT, L.dx, g_h, st))) return rc;
+        if ((rc = snet_segment_sum_rows_chunked(g_xe, col_ptr, eperm, NT, L.dx, L.gxe_chunks, g_h, st))) return rc;
         if (has_halo)
           if ((rc = m->halo_rev(m->halo_user, g_h, NT, N, L.dx, stream))) {
             snet::set_error("snet_model_eval: reverse halo callback failed");

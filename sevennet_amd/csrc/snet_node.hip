@@ -184,22 +184,26 @@ __global__ void row_norm2_kernel(const float *__restrict__ x, int64_t n_rows, in
   if (lane == 0) out[r] = mult * sqrtf(m) * 1.0001f;
 }
 
-// out[s, c] = sum over the segment's rows; lanes over columns (coalesced row reads), 4 rows in flight
+// out[s, c] = sum over the segment's rows; lanes over columns (coalesced row reads), 4 rows in flight.
+// chunk_pos (nullable): the rows of x keep their 16-column chunks in another order (chunk c / 16 sits at position
+// chunk_pos[c / 16]: the fused reverse kernel's g_xe); out is in standard order
 __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const float *__restrict__ x, const int32_t *__restrict__ seg,
                                                                const int32_t *__restrict__ perm, int dim,
+                                                               const int32_t *__restrict__ chunk_pos,
                                                                float *__restrict__ out) {
   const int s = blockIdx.x;
   const int k0 = seg[s], k1 = seg[s + 1];
   for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+    const int cx = chunk_pos ? chunk_pos[c >> 4] * 16 + (c & 15) : c;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int k = k0;
     for (; k + 3 < k1; k += 4) {
-      a0 += x[(size_t)perm[k] * dim + c];
-      a1 += x[(size_t)perm[k + 1] * dim + c];
-      a2 += x[(size_t)perm[k + 2] * dim + c];
-      a3 += x[(size_t)perm[k + 3] * dim + c];
+      a0 += x[(size_t)perm[k] * dim + cx];
+      a1 += x[(size_t)perm[k + 1] * dim + cx];
+      a2 += x[(size_t)perm[k + 2] * dim + cx];
+      a3 += x[(size_t)perm[k + 3] * dim + cx];
     }
-    for (; k < k1; ++k) a0 += x[(size_t)perm[k] * dim + c];
+    for (; k < k1; ++k) a0 += x[(size_t)perm[k] * dim + cx];
     out[(size_t)s * dim + c] = (a0 + a1) + (a2 + a3);
   }
 }
@@ -347,6 +351,17 @@ extern "C" int snet_row_absmax(const float *x, int64_t n_rows, int32_t dim, floa
   SNET_CHECK_LAUNCH("snet_row_absmax");
   return 0;
 }
+extern "C" int snet_segment_sum_rows_chunked(const float *x, const int32_t *seg_ptr, const int32_t *perm, int64_t n_seg,
+                                             int32_t dim, const int32_t *chunk_pos, float *out, void *stream) {
+  SNET_REQUIRE(dim >= 16 && dim % 16 == 0 && n_seg < (1ll << 31), "snet_segment_sum_rows_chunked: dim must be a multiple of 16");
+  SNET_REQUIRE(chunk_pos != nullptr, "snet_segment_sum_rows_chunked: null chunk table");
+  if (n_seg <= 0) return 0;
+  const int threads = dim >= 256 ? 256 : (dim > 128 ? 256 : (dim > 64 ? 128 : 64));
+  segment_sum_rows_kernel<<<(unsigned)n_seg, threads, 0, static_cast<hipStream_t>(stream)>>>(x, seg_ptr, perm, dim, chunk_pos,
+                                                                                           out);
+  SNET_CHECK_LAUNCH("snet_segment_sum_rows_chunked");
+  return 0;
+}
 extern "C" int snet_row_norm2(const float *x, int64_t n_rows, int32_t dim, float mult, float *out, void *stream) {
   SNET_REQUIRE(dim >= 1 && n_rows < (1ll << 33), "snet_row_norm2: bad shape");
   if (n_rows <= 0) return 0;
@@ -360,7 +375,7 @@ extern "C" int snet_segment_sum_rows(const float *x, const int32_t *seg_ptr, con
   SNET_REQUIRE(dim >= 1 && n_seg < (1ll << 31), "snet_segment_sum_rows: bad shape");
   if (n_seg <= 0) return 0;
   const int threads = dim >= 256 ? 256 : (dim > 128 ? 256 : (dim > 64 ? 128 : 64));
-  segment_sum_rows_kernel<<<(unsigned)n_seg, threads, 0, static_cast<hipStream_t>(stream)>>>(x, seg_ptr, perm, dim, out);
+  segment_sum_rows_kernel<<<(unsigned)n_seg, threads, 0, static_cast<hipStream_t>(stream)>>>(x, seg_ptr, perm, dim, nullptr, out);
   SNET_CHECK_LAUNCH("snet_segment_sum_rows");
   return 0;
 }

@@ -355,6 +355,10 @@ class HipForceEngine:
                     L.fplan = fpl
                     # the reverse kernel also reverses the MLP's hidden layers (g_h2 never reaches memory)
                     L.mlp_tail = bool(self.lib.snet_fused_plan_has_mlp_tail(fpl)) and mlp_tail
+                    nch = ls.si1.dim_out // 16   # chunk order of the fused reverse kernel's g_xe rows
+                    cp = (C.c_int32 * nch)()
+                    _lib.check(self.lib.snet_fused_plan_gxe_chunks(fpl, cp, nch), 'snet_fused_plan_gxe_chunks')
+                    L.gxe_chunks = torch.tensor(list(cp), dtype=torch.int32, device=self.dev)
                 L.fused_fwd = L.fplan is not None and fused in ('auto', True, 'fwd')
                 L.fused_bwd = L.fplan is not None and fused in ('auto', True, 'bwd')
                 segs = (_lib.GateSeg * len(ls.gate.segs))()
@@ -667,8 +671,13 @@ class HipForceEngine:
                 if t > 0:
                     g_h = self._new(NT, ls.si1.dim_out)
                     with _Span(self, 'conv_bwd_node[segment_sum]'):
-                        _lib.check(lib.snet_segment_sum_rows(_ptr(g_xe), _ptr(g.col_ptr), _ptr(g.eperm), NT,
-                                                             ls.si1.dim_out, _ptr(g_h), st), 'snet_segment_sum_rows')
+                        if L.fused_bwd:   # the fused kernel's g_xe rows: chunk order undone while summing
+                            _lib.check(lib.snet_segment_sum_rows_chunked(_ptr(g_xe), _ptr(g.col_ptr), _ptr(g.eperm), NT,
+                                                                         ls.si1.dim_out, _ptr(L.gxe_chunks), _ptr(g_h), st),
+                                       'snet_segment_sum_rows_chunked')
+                        else:
+                            _lib.check(lib.snet_segment_sum_rows(_ptr(g_xe), _ptr(g.col_ptr), _ptr(g.eperm), NT,
+                                                                 ls.si1.dim_out, _ptr(g_h), st), 'snet_segment_sum_rows')
                     del g_xe
                     if halo is not None:
                         with _Span(self, 'halo_rev'):

@@ -806,11 +806,11 @@ def test_rank_without_ghosts_still_serves_its_peers(host):
     assert np.abs(F - fr).max() <= max(1e-8, 2e-5 * np.abs(fr).max())
 
 
-@pytest.mark.parametrize('model,n_tile', [('sevennet_l3i5', 19), ('sevennet_mf_ompa', 15)])
+@pytest.mark.parametrize('model,n_tile', [('sevennet_l3i5', 19), ('sevennet_mf_ompa', 15), ('sevennet_mf_ompa', 29)])
 def test_lmax3_shapes_full_size_equal_tiled_small_cell(model, n_tile):
     """BASELINE config 4 / 5 sizes through the size-independent tiling property: SevenNet-l3i5 shape at
     19^3 x 8 = 54 872 atoms and the SevenNet-MF-ompa shape (119 species, two fidelity channels, cutoff 6) at
-    15^3 x 8 = 27 000 atoms.  The big cell is an exact n^3 tiling of a rattled, 4-species-decorated 8-atom cell, so
+    15^3 x 8 = 27 000 atoms and -- config 5's full workload on ONE GPU -- at 29^3 x 8 = 195 112 atoms (9.0 M edges).  The big cell is an exact n^3 tiling of a rattled, 4-species-decorated 8-atom cell, so
     every replica must carry the forces / atomic energies of the 2^3 tiling, which the fp64 oracle evaluates;
     the fused tensor-product kernels (engine default) run every layer of both shapes."""
     from bench import model_config
@@ -853,3 +853,40 @@ def test_lmax3_shapes_full_size_equal_tiled_small_cell(model, n_tile):
     assert np.abs(Ea - e_unit[None]).max() < 2e-5 * max(ref['e_unit'], np.abs(e_unit).max())
     assert abs(float(out['energy'].cpu()) / n_big - float(ref['energy']) / 64) < 2e-6 * ref['e_unit']
     assert np.abs(out['forces'].cpu().numpy().astype(np.float64).sum(0)).max() < 2e-3 * scale
+
+
+def test_amorphous_supercell_at_config4_size():
+    """BASELINE config 4 as written -- SevenNet-l3i5 shape on an AMORPHOUS cell of > 50 000 atoms (ragged degrees at size):
+    a 512-atom amorphous cell (sigma = 0.35 A, 1.8 A minimum distance; degrees 21 .. 32) tiled 5 x 5 x 5 = 64 000 atoms.
+    Every replica must carry the forces / atomic energies the fp64 oracle finds for the periodic 512-atom cell; forces at
+    MD scale (max|F| = 8 eV/A), absolute 1e-4 eV/A bar."""
+    from bench import model_config
+    from sevennet_amd.engine import HipForceEngine
+    from sevennet_amd.neighbor import amorphous_cell, neighbor_list
+    from sevennet_amd.neighbor_gpu import build_graph_gpu
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = model_config('sevennet_l3i5')
+    sd = random_state_dict(cfg, seed=0)
+    unit, cell_u = amorphous_cell(5.431, (4, 4, 4), 0.35, 3, 1.8)
+    n_u = len(unit)
+    ei, ev, _ = neighbor_list(unit, cell_u, [True] * 3, cfg['cutoff'])
+    deg = np.bincount(ei[0], minlength=n_u)
+    assert deg.max() - deg.min() >= 10            # not the uniform degree of a rattled crystal
+    sd, ref = _md_scale_state(cfg, sd, np.zeros(n_u, np.int64), ei, ev)
+    n_t = 5
+    L = float(cell_u[0, 0])
+    shifts = np.stack(np.meshgrid(*[np.arange(n_t)] * 3, indexing='ij'), -1).reshape(-1, 3) * L
+    pos = (shifts[:, None, :] + np.mod(unit, L)[None, :, :]).reshape(-1, 3)
+    n_big = len(pos)
+    assert n_big == 64000
+    eng = HipForceEngine(cfg, sd, device='cuda:0')
+    g = build_graph_gpu(np.zeros(n_big, np.int64), pos, cell_u * n_t, cfg['cutoff'], device='cuda:0')
+    assert g.n_edges == ei.shape[1] * n_t ** 3
+    out = eng.compute(g)
+    torch.cuda.synchronize()
+    F = out['forces'].cpu().numpy().reshape(-1, n_u, 3)
+    Ea = out['atomic_energy'].cpu().numpy().reshape(-1, n_u)
+    f_ref, e_ref = ref['forces'].numpy(), ref['atomic_energy'].numpy()
+    assert np.abs(F - f_ref[None]).max() < 1e-4, np.abs(F - f_ref[None]).max()
+    assert np.abs(Ea - e_ref[None]).max() < 2e-5 * max(ref['e_unit'], np.abs(e_ref).max())
+    assert abs(float(out['energy'].cpu()) / n_big - float(ref['energy']) / n_u) < 2e-6 * ref['e_unit']

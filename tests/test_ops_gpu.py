@@ -369,6 +369,24 @@ def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms, gscale)
     assert (h2.cpu().double() - a2).abs().max() < 5e-6 * a2.abs().max()
     for t in (out, g_xe, g_h2, g_vec, g_emb, g_emb_t):
         assert not torch.isnan(t).any()
+    # the fused kernel keeps the 16-channel chunks of a g_xe row in its own order (snet_fused_plan_gxe_chunks): undo it,
+    # and check that snet_segment_sum_rows_chunked returns the standard-order sums bit for bit
+    cp = (C.c_int32 * (dx // 16))()
+    L.check(lib.snet_fused_plan_gxe_chunks(fplan, cp, dx // 16))
+    cpos = torch.tensor(list(cp), dtype=torch.long)
+    assert sorted(cpos.tolist()) == list(range(dx // 16))
+    col = (cpos[:, None] * 16 + torch.arange(16)[None, :]).reshape(-1).to(dev)
+    g_xe_raw, g_xe = g_xe, g_xe[:, col].contiguous()
+    order = torch.argsort(sr.long(), stable=True).to(torch.int32)
+    col_ptr = torch.zeros(c['NT'] + 1, dtype=torch.int32, device=dev)
+    col_ptr[1:] = torch.cumsum(torch.bincount(sr.long(), minlength=c['NT']), 0).to(torch.int32)
+    s_std, s_chk = torch.empty(c['NT'], dx, device=dev), torch.empty(c['NT'], dx, device=dev)
+    L.check(lib.snet_segment_sum_rows(_p(g_xe), _p(col_ptr), _p(order), c['NT'], dx, _p(s_std), None))
+    L.check(lib.snet_segment_sum_rows_chunked(_p(g_xe_raw), _p(col_ptr), _p(order), c['NT'], dx,
+                                              _p(torch.tensor(list(cp), dtype=torch.int32, device=dev)), _p(s_chk), None))
+    torch.cuda.synchronize()
+    assert torch.equal(s_std, s_chk)
+    g_xe_t = g_xe_t[:, col].contiguous()
     assert torch.equal(g_xe_t, g_xe) and torch.equal(g_vec_t, g_vec)
     # the tail multiplies in the kernel's own precision class (`terms`), the separate hidden-layer kernel in bf16x6
     assert (g_emb_t - g_emb).abs().max().item() <= {4: 2e-6, 3: 2e-6, 2: 1e-4, 1: 4e-2}[terms] * max(gscale, g_emb.abs().max().item())
