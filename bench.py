@@ -451,6 +451,7 @@ def main():
                        'atoms': n_atoms, 'edges': n_edges_total,
                        'parallelism': 'single GPU' if not dist_mode else f'spatial decomposition x{world}, RCCL halo',
                        'graph_build_s': round(t_graph, 3),
+                       'peak_device_memory_gb': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
                        'host': a.host, 'host_enqueue_ms_per_step': round(t_enq / a.steps * 1e3, 3),
                        'h2d_in_step': (f'edge_vec [E,3] fp32 = {ev_host.numel() * 4 / 1e6:.1f} MB from pinned host memory every step'
                                        if ev_host is not None else

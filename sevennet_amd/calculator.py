@@ -89,7 +89,7 @@ def patch_old_config(cfg: dict) -> dict:
 W3J_KEY = '{t}_convolution.convolution._compiled_main_left_right._w3j_{l1}_{l2}_{l3}'
 
 
-def fix_old_convolution_signs(cfg: dict, sd: dict) -> dict:
+def fix_old_convolution_signs(cfg: dict, sd: dict, strict_reference: bool = False) -> dict:
     """Second half of the reference's `sort_old_convolution` (scripts/backward_compatibility.py:119-137).
 
     Checkpoints with the pre-0.11 convolution (version < 0.11.0 or 0.11.0.dev0) carry the real Wigner-3j
@@ -108,6 +108,9 @@ def fix_old_convolution_signs(cfg: dict, sd: dict) -> dict:
     so later paths of the same key keep their weights while their tensor has changed sign.  Here every
     path that reads a flipped buffer is fixed, which preserves the function the checkpoint was trained as.
     All released checkpoints (SO(3)-only, one path per key) are unaffected by the difference.
+    When a flipped buffer IS shared by several paths a warning says so, and `strict_reference=True`
+    (or SNET_STRICT_REFERENCE_W3J=1) reproduces the upstream behaviour instead: only the first path of a key is
+    negated, so that this engine's numbers equal upstream's for such a checkpoint.
     Returns a state dict without the `_w3j_*` buffers."""
     from .irreps import real_wigner_3j
     from .model_spec import build_model_spec, old_convolution_order
@@ -115,7 +118,9 @@ def fix_old_convolution_signs(cfg: dict, sd: dict) -> dict:
     if not old_convolution_order(cfg.get('version', '0.0.0')) or len(out) == len(sd):
         return out   # current instruction order, or a checkpoint stripped of its buffers: nothing to compare
     spec = build_model_spec(cfg)   # paths in the checkpoint's own (unsorted) instruction order
+    strict_reference = strict_reference or os.environ.get('SNET_STRICT_REFERENCE_W3J') == '1'
     for ls in spec.layers:
+        flipped = {}
         ww_key = f'{ls.t}_convolution.weight_nn.layer{len(ls.mlp_dims) - 2}.weight'
         ww = None
         for p in ls.conv.paths:
@@ -133,15 +138,25 @@ def fix_old_convolution_signs(cfg: dict, sd: dict) -> dict:
             if not np.allclose(old, -now, rtol=1e-5, atol=1e-6):
                 raise ValueError(f'{key} is neither +wigner_3j nor -wigner_3j: the checkpoint was written with an '
                                  'incompatible Clebsch-Gordan convention (e3nn < 0.4?)')
+            flipped[key] = flipped.get(key, 0) + 1
+            if strict_reference and flipped[key] > 1:
+                continue   # upstream flipped the shared buffer in place after the first path: later paths keep their weights
             if ww is None:
                 ww = np.array(out[ww_key], copy=True)
             ww[:, p.w_off:p.w_off + p.mul] *= -1.0
         if ww is not None:
             out[ww_key] = ww
+        shared = sorted(k for k, c in flipped.items() if c > 1)
+        if shared:
+            warnings.warn(f'{shared}: a sign-flipped Wigner-3j buffer is shared by several tensor-product paths; '
+                          + ('only the first path of each was negated, as sevenn/scripts/backward_compatibility.py does '
+                             '(strict_reference)' if strict_reference else
+                             'every such path was negated (the function the checkpoint was trained as); upstream negates only '
+                             'the first -- pass strict_reference=True / SNET_STRICT_REFERENCE_W3J=1 to reproduce its numbers'))
     return out
 
 
-def load_reference_checkpoint(path: str):
+def load_reference_checkpoint(path: str, strict_reference: bool = False):
     """(config, state_dict) from a reference checkpoint file (sevenn/checkpoint.py:286-308:
     a torch pickle holding 'config' and 'model_state_dict'), with the reference's own
     backward-compatibility steps (patch_state_dict_if_old, scripts/backward_compatibility.py:165-184):
@@ -154,7 +169,7 @@ def load_reference_checkpoint(path: str):
     cfg = patch_old_config(dict(cp['config']))
     sd = {k: v.detach().cpu().numpy() for k, v in map_old_state_dict(cp['model_state_dict']).items()
           if hasattr(v, 'detach')}
-    return cfg, fix_old_convolution_signs(cfg, sd)
+    return cfg, fix_old_convolution_signs(cfg, sd, strict_reference)
 
 
 class SevenNetCalculator(Calculator):

@@ -53,9 +53,8 @@ struct Rccl {
 
 Rccl *rccl() {
   static Rccl r;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;   // several host threads may create communicators / halos at the same time
+  std::call_once(once, [] {
     const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names)  // a copy some other component (PyTorch-ROCm) already loaded wins
       if ((r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
@@ -78,7 +77,7 @@ Rccl *rccl() {
             r.AllReduce))
         r.h = nullptr;
     }
-  }
+  });
   return r.h ? &r : nullptr;
 }
 
@@ -249,6 +248,7 @@ struct snet_halo {
   std::vector<int64_t> send_cnt, recv_cnt, send_off, recv_off;  // rows per peer and their prefix sums
   int64_t n_send = 0, n_ghost = 0, n_seg = 0;
   Dev<int32_t> send_idx, red_rows, red_perm, red_ptr;
+  int64_t max_send_row = -1;  // send_idx entries are local rows: max_send_row < n_local must hold on every call
   Dev<int32_t> ghost_perm, ghost_inv;      // optional: k-th received row (peer order) <-> ghost row (host's node order)
   bool permuted = false;
   Dev<float> send_buf, recv_buf, seg_buf, ghost_buf;  // grown to the widest row seen
@@ -361,6 +361,14 @@ int snet_halo_create(void *comm, int32_t world, int32_t rank, const int32_t *sen
   if (h->n_send > 0) {
     SNET_REQUIRE(send_idx_host != nullptr, "snet_halo_create: send_idx missing");
     std::vector<int32_t> idx(send_idx_host, send_idx_host + h->n_send);
+    for (int32_t v : idx) {  // the largest row a peer asks for: checked against n_local on every exchange
+      if (v < 0) {
+        delete h;
+        snet::set_error("snet_halo_create: negative send index");
+        return 1;
+      }
+      h->max_send_row = std::max(h->max_send_row, (int64_t)v);
+    }
     ok = h->send_idx.upload(idx);
     // reverse unpack plan: received rows grouped by the local row they add into; a stable sort keeps the
     // contributions of one row in peer order, so the floating-point sum order is fixed
@@ -412,6 +420,7 @@ int snet_halo_forward(void *user, float *x, int64_t n_total, int64_t n_local, in
   auto *h = static_cast<snet_halo *>(user);
   SNET_REQUIRE(h != nullptr && x != nullptr && dim > 0, "snet_halo_forward: bad argument");
   SNET_REQUIRE(n_total - n_local == h->n_ghost, "snet_halo_forward: ghost row count does not match the exchange plan");
+  SNET_REQUIRE(h->max_send_row < n_local, "snet_halo_forward: the exchange plan sends a row beyond n_local");
   SNET_REQUIRE(h->comm->kind != 0 || rccl() != nullptr, "snet_halo_forward: RCCL not loaded");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (h->n_send > 0) {
@@ -442,6 +451,7 @@ int snet_halo_reverse(void *user, float *gx, int64_t n_total, int64_t n_local, i
   auto *h = static_cast<snet_halo *>(user);
   SNET_REQUIRE(h != nullptr && gx != nullptr && dim > 0, "snet_halo_reverse: bad argument");
   SNET_REQUIRE(n_total - n_local == h->n_ghost, "snet_halo_reverse: ghost row count does not match the exchange plan");
+  SNET_REQUIRE(h->max_send_row < n_local, "snet_halo_reverse: the exchange plan sends a row beyond n_local");
   SNET_REQUIRE(h->comm->kind != 0 || rccl() != nullptr, "snet_halo_reverse: RCCL not loaded");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (h->n_send > 0)

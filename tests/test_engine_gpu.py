@@ -852,7 +852,9 @@ def test_lmax3_shapes_full_size_equal_tiled_small_cell(model, n_tile):
     assert np.abs(F - f_unit[None]).max() < 1e-4, (np.abs(F - f_unit[None]).max(), scale)   # absolute, at MD-scale forces
     assert np.abs(Ea - e_unit[None]).max() < 2e-5 * max(ref['e_unit'], np.abs(e_unit).max())
     assert abs(float(out['energy'].cpu()) / n_big - float(ref['energy']) / 64) < 2e-6 * ref['e_unit']
-    assert np.abs(out['forces'].cpu().numpy().astype(np.float64).sum(0)).max() < 2e-3 * scale
+    # net force: every replica repeats the same rounding, so the total grows with the number of replicas -- per replica
+    # (8 atoms, max|F| = 8 eV/A) it must stay at the fp32 rounding of the forces
+    assert np.abs(out['forces'].cpu().numpy().astype(np.float64).sum(0)).max() / (n_big / 8) < 4e-5
 
 
 def test_amorphous_supercell_at_config4_size():
