@@ -59,6 +59,43 @@ def schedule(spec: ConvSpec):
     return cats, pairs_of, cols
 
 
+def schedule_bwd(spec: ConvSpec):
+    """Blocks of the reverse kernel -> (per x block: dict(cat, U, ncb, steps), flat (col_a, col_b) table of its weight stream).
+    A block covers U channel tiles of one x block; `steps` lists its sub-steps as pairs of (path, member tile u) -- or None
+    for an empty second tile.  U = 2 where the x block has an odd number of paths and an even number of channel tiles: the
+    partnerless path's tiles of the block's two channel tiles then share a sub-step (and the g_out entries of both tiles fit
+    the wave's 32-row LDS buffer).  Stream order: for x block: for
+    block: for sub-step.  SNET_CODEGEN_OPTS=nopairct=1 keeps U = 1 everywhere (the round-2 schedule)."""
+    out, cols = [], []
+    # first interaction layer (one x block, 8-wave workgroups at <= 128 VGPRs): two-tile blocks push it past 128 registers
+    # and halve its occupancy (measured 1.70 -> 2.36 ms): it keeps one channel tile per block
+    n_cats = sum(1 for i in range(len(spec.irreps_x)) if _Cat(spec, i, 0).paths)
+    for i in range(len(spec.irreps_x)):
+        cat = _Cat(spec, i, 0)
+        if not cat.paths:
+            continue
+        ps = [pi for pi, _ in cat.paths]
+        nct = cat.mul // 16
+        # (a two-tile block parks the g_out entries of both tiles: only where they fit 32 rows of the wave's LDS buffer --
+        # the lmax-3 middle layers would otherwise lose a workgroup per CU to LDS)
+        entries = sum(2 * p.l3 + 1 for _, p in cat.paths)
+        if len(ps) % 2 == 1 and nct % 2 == 0 and 2 * entries <= 32 and n_cats > 1 and not OPTS.get('nopairct'):
+            full = [(ps[k], ps[k + 1]) for k in range(0, len(ps) - 1, 2)]
+            steps = [((a, 0), (b, 0)) for a, b in full] + [((a, 1), (b, 1)) for a, b in full] + [((ps[-1], 0), (ps[-1], 1))]
+            U = 2
+        else:
+            steps = [((ps[k], 0), (ps[k + 1], 0) if k + 1 < len(ps) else None) for k in range(0, len(ps), 2)]
+            U = 1
+        ncb = nct // U
+        out.append(dict(cat=cat, U=U, ncb=ncb, steps=steps))
+        for cb in range(ncb):
+            for ta, tb in steps:
+                ca = spec.paths[ta[0]].w_off + 16 * (U * cb + ta[1])
+                cb_ = spec.paths[tb[0]].w_off + 16 * (U * cb + tb[1]) if tb is not None else -1
+                cols.append((ca, cb_))
+    return out, cols
+
+
 def _emit_staging(A, lines: str):
     """stage_load(s, b) / stage_store(b): the next sub-step's `lines` fragment lines (1 KB each) travel
     global -> LDS either through registers (load early, ds_write late) or (GLDS) by gfx950's direct
@@ -209,6 +246,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     NSHP = NSH + 1 if (4 * NSH) % 32 == 0 else NSH
     A(f'constexpr int DX = {DX}, DOUT = {DOUT}, NSH = {NSH}, NSHP = {NSHP}, WN = {WN}, NS = {NS};')
     A('const int32_t SUB_COLS[NS * 2] = {' + ', '.join(f'{a}, {b}' for a, b in cols) + '};')
+    _, cols_rev = schedule_bwd(spec)   # the reverse kernel's own sub-step order (see schedule_bwd)
+    A(f'const int32_t SUB_COLS_B[{2 * len(cols_rev)}] = {{' + ', '.join(f'{a}, {b}' for a, b in cols_rev) + '};')
     # g_xe[E, DX] is a private intermediate (reverse kernel -> segment sum): inside a row its 16-channel chunks are kept in
     # the order the kernel produces them, [x block][channel tile][component], so that the 2 l + 1 stores of one
     # (block, tile) write one contiguous run per edge (whole 128-byte lines) instead of 64-byte halves of lines whose other
@@ -289,33 +328,40 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     # are fetched ONCE per wave, one block ahead, by one or two 16-byte loads per lane (lane L: channels 4 (L & 3)
     # .. +3 of entry 16 k + (L >> 2); vector-memory instructions, not bytes, are what this kernel runs out of),
     # parked in a wave-private LDS buffer and read back as group-broadcast 16-byte reads.
-    glists = [[(pi, m3) for pi, p in cat.paths for m3 in range(2 * p.l3 + 1)] for cat in cats]
+    # The reverse kernel walks the weight columns in BLOCKS: one x block (cat) and U = 1 or 2 of its 16-channel tiles.  An x
+    # block with an odd number of paths leaves one path without a partner for the second 16-column tile of a sub-step;
+    # with U = 2 that path's tiles of two consecutive channel tiles share a sub-step instead (schedule_bwd): the
+    # SevenNet-0 middle layer needs 30 sub-steps instead of 34, its last layer (three one-path x blocks) 7 instead of 14.
+    bsched, cols_b = schedule_bwd(spec)
+    NSB = len(cols_b)
+    glists = [[(pi, m3, u) for u in range(bs['U']) for pi, p in bs['cat'].paths for m3 in range(2 * p.l3 + 1)] for bs in bsched]
     NGP = max((len(gl) + 15) // 16 * 16 for gl in glists)   # rows of the LDS buffer (padded to 16 entries per load)
     NK = NGP // 16
-    A(f'  constexpr int NGP = {NGP}, NK = {NK};')
+    A(f'  constexpr int NGP = {NGP}, NK = {NK}, NSUB = {NSB};   // NSUB: sub-steps of the reverse kernel\'s weight stream')
     A('  __shared__ __attribute__((aligned(16))) float s_g[NWV][2][NGP * 16];')
     A('  f32x4 gpre[NK];')
     A('  const float *gnode = g_out + (size_t)((diag & 256) ? (node & 63) : node) * DOUT + 4 * (lane & 3);')
     for ci, gl in enumerate(glists):   # per-lane offsets of the entries this lane fetches (-1: none)
         for k in range((len(gl) + 15) // 16):
-            offs = [out_index(spec.paths[gl[q][0]], gl[q][1]) if q < len(gl) else -1 for q in range(16 * k, 16 * k + 16)]
+            offs = [out_index(spec.paths[gl[q][0]], gl[q][1]) + 16 * gl[q][2] if q < len(gl) else -1 for q in range(16 * k, 16 * k + 16)]
             A(f'  static const int32_t GOFF{ci}_{k}[16] = {{' + ', '.join(str(o) for o in offs) + '};')
             A(f'  const int goff{ci}_{k} = GOFF{ci}_{k}[lane >> 2];')
 
-    def emit_g_loads(ind, ci, ct_expr):
+    def emit_g_loads(ind, ci, cb_expr):
         gl = glists[ci]
+        U_ = bsched[ci]['U']
         for k in range((len(gl) + 15) // 16):
             dg = '(diag & 8) ? f32x4{scale, scale, scale, scale} : ' if exp else ''
             A(f'{ind}gpre[{k}] = {dg}(goff{ci}_{k} < 0) ? f32x4{{0.f, 0.f, 0.f, 0.f}} : '
-              f'*reinterpret_cast<const f32x4 *>(gnode + goff{ci}_{k} + 16 * ({ct_expr})) * scale;')
+              f'*reinterpret_cast<const f32x4 *>(gnode + goff{ci}_{k} + {16 * U_} * ({cb_expr})) * scale;')
 
     def emit_g_park(ind, ci, buf_expr):
         gl = glists[ci]
         for k in range((len(gl) + 15) // 16):
             A(f'{ind}*reinterpret_cast<f32x4 *>(&s_g[wave][{buf_expr}][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]) = gpre[{k}];')
 
-    def g_row(ci, pi, m3):
-        return glists[ci].index((pi, m3))
+    def g_row(ci, pi, m3, u):
+        return glists[ci].index((pi, m3, u))
 
     emit_g_loads('  ', 0, '0')
     A('  const int e0 = row_ptr[node] + 16 * (t - tile_ptr[node]);')
@@ -326,11 +372,14 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  const int wr = w_row ? w_row[e] : e;')
     A('  float x_bound = 0.f;')
     A('  if constexpr (F16) x_bound = tail.x_max[s_src] * tail.g_max[node];')
-    _c0 = cats[0]
+    _c0, _U0 = cats[0], bsched[0]['U']
+    _d0 = 2 * _c0.l1 + 1
     A(f'  const float *xs0 = x + (size_t)s_src * DX + {_c0.x_off} + 4 * g;')
-    A(f'  f32x4 xr0[{2 * _c0.l1 + 1}], xn0[{2 * _c0.l1 + 1}];')
-    for m in range(2 * _c0.l1 + 1):
-        A(f'  xr0[{m}] = *reinterpret_cast<const f32x4 *>(xs0 + {m * _c0.mul});')
+    A(f'  f32x4 xr0[{_U0}][{_d0}], xn0[{_U0}][{_d0}];')
+    for u in range(_U0):
+        for m in range(_d0):
+            A(f'  xr0[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs0 + {16 * u + m * _c0.mul});')
+
     A('  // the edge\'s spherical harmonics wait in wave-private LDS ([component][edge]: conflict-free, the four channel')
     A('  // groups of an edge read the same word) and are re-read per path: 9 .. 16 fewer live registers per lane')
     A('  __shared__ float s_y[NWV][NSH * 16];')
@@ -385,40 +434,43 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    g_unsc = snet::pow2f(-(kg + tail.w2_exp));')
     A('  }')
     A('  int sidx = 0, buf = 0, gbuf = 0;')
-    for ci, cat in enumerate(cats):
+    for ci, bs in enumerate(bsched):
+        cat, U, ncb = bs['cat'], bs['U'], bs['ncb']
         d1 = 2 * cat.l1 + 1
-        A(f'  // ---- x block {cat.i_x}: {cat.mul}x l={cat.l1}, {len(cat.paths)} paths')
-        nct = cat.mul // 16
-        # source rows: the next channel tile's slice is requested one block ahead (gather latency ~1-2 us)
+        A(f'  // ---- x block {cat.i_x}: {cat.mul}x l={cat.l1}, {len(cat.paths)} paths, {U} channel tile(s) per block, {len(bs["steps"])} sub-steps per block')
+        # source rows: the next block's slices are requested one block ahead (gather latency ~1-2 us)
         if ci > 0:   # (the first x block's rows were requested in the prologue)
             A(f'  const float *xs{ci} = x + (size_t)s_src * DX + {cat.x_off} + 4 * g;')
-            A(f'  f32x4 xr{ci}[{d1}], xn{ci}[{d1}];')
+            A(f'  f32x4 xr{ci}[{U}][{d1}], xn{ci}[{U}][{d1}];')
+            for u in range(U):
+                for m in range(d1):
+                    A(f'  xr{ci}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {16 * u + m * cat.mul});')
+        A(f'  for (int cb = 0; cb < {ncb}; ++cb) {{')
+        A(f'    f32x4 (&xr)[{U}][{d1}] = xr{ci};')
+        A(f'    f32x4 gx[{U}][{d1}];')
+        for u in range(U):
             for m in range(d1):
-                A(f'  xr{ci}[{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {m * cat.mul});')
-        A(f'  for (int ct = 0; ct < {nct}; ++ct) {{')
-        A(f'    f32x4 (&xr)[{d1}] = xr{ci};')
-        A(f'    f32x4 gx[{d1}];')
-        for m in range(d1):
-            A(f'    gx[{m}] = f32x4{{0.f, 0.f, 0.f, 0.f}};')
-        if nct > 1:
-            A(f'    if (ct + 1 < {nct}' + (' && !(diag & 64)' if exp else '') + ') {')
-            for m in range(d1):
-                A(f'      xn{ci}[{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + 16 * (ct + 1) + {m * cat.mul});')
+                A(f'    gx[{u}][{m}] = f32x4{{0.f, 0.f, 0.f, 0.f}};')
+        if ncb > 1:
+            A(f'    if (cb + 1 < {ncb}' + (' && !(diag & 64)' if exp else '') + ') {')
+            for u in range(U):
+                for m in range(d1):
+                    A(f'      xn{ci}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {16 * U} * (cb + 1) + {16 * u + m * cat.mul});')
             A('    }')
         A('    const float *gl_ = &s_g[wave][gbuf][4 * g];')
-        # next block's g_out entries: this x block's next channel tile, or the first tile of the next x block
-        if nct > 1:
-            A(f'    if (ct + 1 < {nct}) {{')
-            emit_g_loads('      ', ci, 'ct + 1')
-            A('    }' + (' else {' if ci + 1 < len(cats) else ''))
-            if ci + 1 < len(cats):
+        # next block's g_out entries: this x block's next block, or the first block of the next x block
+        if ncb > 1:
+            A(f'    if (cb + 1 < {ncb}) {{')
+            emit_g_loads('      ', ci, 'cb + 1')
+            A('    }' + (' else {' if ci + 1 < len(bsched) else ''))
+            if ci + 1 < len(bsched):
                 emit_g_loads('      ', ci + 1, '0')
                 A('    }')
-        elif ci + 1 < len(cats):
+        elif ci + 1 < len(bsched):
             emit_g_loads('    ', ci + 1, '0')
-        for (pa, pb) in pairs_of[ci]:
+        for (ta, tb) in bs['steps']:
             A('    {')
-            A('      if (sidx + 1 < NS' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, buf ^ 1);')
+            A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, buf ^ 1);')
             # hipcc's machine scheduler, left alone, sinks the prefetch loads next to their use (zero overlap) and
             # interleaves the phases until ~200 VGPRs spill: pin the prefetch at the top and fence the phases
             A('      __builtin_amdgcn_sched_barrier(0);')
@@ -429,8 +481,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             # before the tensor-product bodies (+30 VGPRs: only fits two waves per SIMD, 6.72 vs 6.73 ms at three)
             wfirst, gpf = bool(OPTS.get('wfirst')), bool(OPTS.get('gpf'))
             if wfirst:
-                for tp, pi in enumerate((pa, pb)):
-                    if pi is None:
+                for tp, tl_ in enumerate((ta, tb)):
+                    if tl_ is None:
                         continue
                     A(f'      f32x4 wv{tp} = f32x4{{0.f, 0.f, 0.f, 0.f}};')
                     A('#pragma unroll')
@@ -449,12 +501,13 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A('        for (int tm = 0; tm < NT; ++tm) ag[m][tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
             if wfirst or gpf:
                 A('      __builtin_amdgcn_sched_barrier(0);')
-            for tp, pi in enumerate((pa, pb)):
-                if pi is None:
+            for tp, tl_ in enumerate((ta, tb)):
+                if tl_ is None:
                     continue
+                pi, u = tl_
                 p = spec.paths[pi]
                 d3 = 2 * p.l3 + 1
-                A(f'      {{  // tile {tp}: path {pi}')
+                A(f'      {{  // tile {tp}: path {pi}, channel tile {U} cb + {u}')
                 if wfirst:
                     A(f'        const f32x4 wv = wv{tp};')
                 else:
@@ -471,7 +524,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                     A('        if constexpr (F16) wv *= w_unscale;')
                 A(f'        f32x4 G[{d3}];')
                 for m3 in range(d3):
-                    A(f'        G[{m3}] = *reinterpret_cast<const f32x4 *>(gl_ + {g_row(ci, pi, m3)} * 16);')
+                    A(f'        G[{m3}] = *reinterpret_cast<const f32x4 *>(gl_ + {g_row(ci, pi, m3, u)} * 16);')
                 A('        float ys[NSH];')
                 for b_ in range(2 * p.l2 + 1):
                     A(f'        ys[{p.sh_off + b_}] = yl[{(p.sh_off + b_) * 16}];')
@@ -479,7 +532,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 # straight-line code hipcc's scheduler interleaves it with the surrounding matrix products and
                 # loads until ~200 VGPRs spill to scratch (measured: 692 spilled registers without the branch, 0 with)
                 A(f'        gw{tp} = f32x4{{0.f, 0.f, 0.f, 0.f}};')
-                A(f'        if (!(diag & 1)) bwdf_p{pi}(xr, ys, wv, G, gw{tp}, gy, gx);')
+                A(f'        if (!(diag & 1)) bwdf_p{pi}(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
                 A('      }')
             A('      float v[8] = {gw0[0], gw0[1], gw0[2], gw0[3], gw1[0], gw1[1], gw1[2], gw1[3]};')
             A('      if constexpr (F16) {')
@@ -499,36 +552,39 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A('        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
                 A('        ga[m] = mfma16_split<NT, F16>(a, b, ga[m]);')
             A('      }')
-            A('      if (sidx + 1 < NS' + (' && !(diag & 32)' if exp else '') + ') stage_store(buf ^ 1);')
+            A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_store(buf ^ 1);')
             A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
             A('      buf ^= 1;')
             A('      ++sidx;')
             A('    }')
         A('    if (g_xe && valid' + (' && !(diag & 16)' if exp else '') + ') {')
-        if gxe_std:
-            A(f'      float *o = g_xe + (size_t)e * DX + {cat.x_off} + 16 * ct + 4 * g;')
-        else:
-            A(f'      float *o = g_xe + (size_t)e * DX + {cat.x_off} + {16 * d1} * ct + 4 * g;   // chunk order [tile][component]: GXE_CHUNK')
-        for m in range(d1):
-            # streaming stores (kept in L2, partially written lines were evicted before their other half arrived:
-            # 8.9 GB written for 5.9 GB of output in round 2)
-            A(f'      __builtin_nontemporal_store(gx[{m}], reinterpret_cast<f32x4 *>(o + {m * cat.mul if gxe_std else 16 * m}));')
+        for u in range(U):
+            if gxe_std:
+                A(f'      {"float *" if u == 0 else ""}o = g_xe + (size_t)e * DX + {cat.x_off} + 16 * ({U} * cb + {u}) + 4 * g;')
+            else:
+                A(f'      {"float *" if u == 0 else ""}o = g_xe + (size_t)e * DX + {cat.x_off} + {16 * d1} * ({U} * cb + {u}) + 4 * g;   // chunk order [tile][component]: GXE_CHUNK')
+            for m in range(d1):
+                # streaming stores (kept in L2, partially written lines were evicted before their other half arrived:
+                # 8.9 GB written for 5.9 GB of output in round 2)
+                A(f'      __builtin_nontemporal_store(gx[{u}][{m}], reinterpret_cast<f32x4 *>(o + {m * cat.mul if gxe_std else 16 * m}));')
         A('    }')
         # park the prefetched entries of the next block in the other buffer (last read one block ago)
-        if nct > 1:
-            A(f'    if (ct + 1 < {nct}) {{')
+        if ncb > 1:
+            A(f'    if (cb + 1 < {ncb}) {{')
             emit_g_park('      ', ci, 'gbuf ^ 1')
-            A('    }' + (' else {' if ci + 1 < len(cats) else ''))
-            if ci + 1 < len(cats):
+            A('    }' + (' else {' if ci + 1 < len(bsched) else ''))
+            if ci + 1 < len(bsched):
                 emit_g_park('      ', ci + 1, 'gbuf ^ 1')
                 A('    }')
-        elif ci + 1 < len(cats):
+        elif ci + 1 < len(bsched):
             emit_g_park('    ', ci + 1, 'gbuf ^ 1')
         A('    gbuf ^= 1;')
         A('    __builtin_amdgcn_wave_barrier();')
-        if nct > 1:
+        if ncb > 1:
             A('#pragma unroll')
-            A(f'    for (int m = 0; m < {d1}; ++m) xr{ci}[m] = xn{ci}[m];')
+            A(f'    for (int u = 0; u < {U}; ++u)')
+            A('#pragma unroll')
+            A(f'      for (int m = 0; m < {d1}; ++m) xr{ci}[u][m] = xn{ci}[u][m];')
         A('  }')
     if dead_x:
         A('  if (g_xe && valid) {  // x blocks that feed no path get a zero gradient')
@@ -557,7 +613,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    static_assert(TA <= 2 * LPS, "tail phase does not fit the slab buffers");')
     A('    constexpr int NSA = (TA * 64 + NTH - 1) / NTH, NSB = (TB * 64 + NTH - 1) / NTH;')
     A('    u32x4 *tl = &slab[0][0];')
-    A('    const u32x4 *ep = slabs + (size_t)NS * LPS * 64;')
+    A('    const u32x4 *ep = slabs + (size_t)NSUB * LPS * 64;')
     A('    u32x4 sb[NSB];')
     A('#pragma unroll')
     A('    for (int i = 0; i < NSA; ++i)')
@@ -1099,7 +1155,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         cond = f' (nt == {nt_})' if kw != 'else' else ''
         A(f'  {kw}{cond} launch_fwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
     A('}')
-    A(f'const snet::FusedKernels kernels = {{"{tag}", DX, DOUT, NSH, WN, NS, SUB_COLS, GXE_CHUNK, launch_bwd, launch_fwd}};')
+    A(f'const snet::FusedKernels kernels = {{"{tag}", DX, DOUT, NSH, WN, NS, SUB_COLS, {len(cols_rev)}, SUB_COLS_B, GXE_CHUNK, launch_bwd, launch_fwd}};')
     A('const snet::FusedRegistrar registrar(&kernels);')
     A('}  // namespace')
     return '\n'.join(L) + '\n'

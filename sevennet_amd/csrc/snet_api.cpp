@@ -57,7 +57,8 @@ struct snet_conv_plan {
 struct snet_fused_plan {
   const snet::FusedKernels *k;
   int terms;
-  void *slabs;  // device: W2 as pre-split MFMA fragments in the kernels' sub-step order, then the hidden-layer tail
+  void *slabs;    // device: W2 as pre-split MFMA fragments in the FORWARD kernel's sub-step order
+  void *slabs_b;  // the same in the REVERSE kernel's order, then the hidden-layer tail
   snet::MlpHidden hidden;  // w0 == nullptr: no tail (g_h2 is always written)
   int32_t exps[3];         // mode 4: power-of-two scales of W2 / W1 / W0 in the fragment stream
 };
@@ -138,18 +139,22 @@ int snet_fused_plan_create(const snet_conv_plan *plan, const snet_mlp_plan *mlp,
   // 16-row operand tile and its rows are whole float4s
   snet::MlpHidden hid = snet::mlp_plan_hidden(mlp);
   if (hid.w0 != nullptr && !(hid.nb <= 16 && hid.nb % 4 == 0)) hid.w0 = nullptr;
-  int32_t exps[3] = {0, 0, 0};
-  if (snet::pack_fused_slabs(snet::mlp_plan_w2_host(mlp), k->wn, k->n_sub, k->sub_cols, terms,
-                             hid.w0 ? &hid : nullptr, &dev, exps) != 0) {
+  int32_t exps[3] = {0, 0, 0}, exps_f[3];
+  void *dev_b = nullptr;
+  if (snet::pack_fused_slabs(snet::mlp_plan_w2_host(mlp), k->wn, k->n_sub, k->sub_cols, terms, nullptr, &dev, exps_f) != 0 ||
+      snet::pack_fused_slabs(snet::mlp_plan_w2_host(mlp), k->wn, k->n_sub_b, k->sub_cols_b, terms,
+                             hid.w0 ? &hid : nullptr, &dev_b, exps) != 0) {
+    if (dev) (void)hipFree(dev);
     snet::set_error("snet_fused_plan_create: device allocation / upload of the W2 fragment stream failed");
     return 1;
   }
-  *out = new snet_fused_plan{k, terms, dev, hid, {exps[0], exps[1], exps[2]}};
+  *out = new snet_fused_plan{k, terms, dev, dev_b, hid, {exps[0], exps[1], exps[2]}};
   return 0;
 }
 void snet_fused_plan_destroy(snet_fused_plan *p) {
   if (!p) return;
   if (p->slabs) (void)hipFree(p->slabs);
+  if (p->slabs_b) (void)hipFree(p->slabs_b);
   delete p;
 }
 
@@ -189,7 +194,7 @@ int snet_conv_bwd_fused(const snet_fused_plan *fp, const float *x, const float *
                "snet_conv_bwd_fused: g_emb needs emb and a plan with the hidden-layer tail (snet_fused_plan_has_mlp_tail)");
   const snet::FusedTail tail{emb, g_emb, fp->hidden.nb, fp->hidden.act, fp->hidden.cst, fp->exps[0], fp->exps[1], fp->exps[2],
                              x_rowmax, g_rowmax};
-  fp->k->bwd(fp->terms, x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node, n_tiles, fp->slabs, scale, g_out,
+  fp->k->bwd(fp->terms, x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node, n_tiles, fp->slabs_b, scale, g_out,
              g_xe, g_h2, g_vec, tail, static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_conv_bwd_fused");
   return 0;

@@ -74,7 +74,9 @@ struct FusedKernels {
   const char *tag;
   int dx, dout, nsh, wn;
   int n_sub;
-  const int32_t *sub_cols;
+  const int32_t *sub_cols;   // forward kernel's sub-step order
+  int n_sub_b;
+  const int32_t *sub_cols_b;  // reverse kernel's sub-step order (pairs a partnerless path's tiles across two channel tiles)
   // g_xe rows are written in the kernel's own chunk order: gxe_chunk[standard 16-channel chunk] = its position in the row
   // (dx / 16 entries); snet_segment_sum_rows_chunked undoes it while it sums
   const int32_t *gxe_chunk;

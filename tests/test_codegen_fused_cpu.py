@@ -68,3 +68,41 @@ def test_generated_source_is_consistent(tag):
     for line in re.findall(r'static const int32_t GOFF\d+_\d+\[16\] = \{([^}]*)\}', src):
         vals = [int(v) for v in line.split(',')]
         assert all(v == -1 or 0 <= v < dout for v in vals)
+
+
+@pytest.mark.parametrize('tag', sorted(FUSABLE))
+def test_reverse_schedule_covers_every_weight_column_once(tag):
+    """the reverse kernel's own weight stream (schedule_bwd): blocks of one or two channel tiles of an x block; an x block
+    with an odd number of paths pairs the partnerless path's tiles of two consecutive channel tiles in one sub-step, so no
+    sub-step of such a block has an empty second tile"""
+    sp = FUSABLE[tag]
+    blocks, cols = codegen_fused.schedule_bwd(sp)
+    seen = sorted(c + i for ab in cols for c in ab if c >= 0 for i in range(16))
+    assert seen == list(range(sp.weight_numel))
+    _, _, cols_f = codegen_fused.schedule(sp)
+    assert len(cols) <= len(cols_f)
+    k = 0
+    for b in blocks:
+        cat, U = b['cat'], b['U']
+        assert b['ncb'] * U == cat.mul // 16
+        paths = {pi for pi, _ in cat.paths}
+        if U == 2:
+            assert len(paths) % 2 == 1 and all(tb is not None for _, tb in b['steps'])
+            assert b['steps'][-1][0][0] == b['steps'][-1][1][0] and (b['steps'][-1][0][1], b['steps'][-1][1][1]) == (0, 1)
+        for cb in range(b['ncb']):
+            for ta, tb in b['steps']:
+                assert ta[0] in paths and cols[k][0] == sp.paths[ta[0]].w_off + 16 * (U * cb + ta[1])
+                assert cols[k][1] == (-1 if tb is None else sp.paths[tb[0]].w_off + 16 * (U * cb + tb[1]))
+                k += 1
+    assert k == len(cols)
+    src = codegen_fused.gen_conv_fused(sp)
+    tab = re.search(r'SUB_COLS_B\[\d+\] = \{([^}]*)\}', src).group(1)
+    assert [int(v) for v in tab.split(',')] == [c for ab in cols for c in ab]
+    assert f'NSUB = {len(cols)};' in src and '(size_t)NSUB * LPS * 64' in src
+
+
+def test_reverse_schedule_sub_step_counts_of_sevennet_0():
+    """SevenNet-0: middle layers 30 sub-steps (34 with one channel tile per block), last layer 7 (14); the first layer
+    (a single x block) keeps 16"""
+    counts = {tag: len(codegen_fused.schedule_bwd(FUSABLE[tag])[1]) for tag in ('22d6a77ad5ac', '005c575f8ec2', 'ecc5d202727d')}
+    assert counts == {'22d6a77ad5ac': 30, '005c575f8ec2': 7, 'ecc5d202727d': 16}
