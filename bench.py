@@ -75,6 +75,8 @@ def parse():
                          'fp32-rounding class; engine default), 3 = bf16x6 (fp32-rounding class, six products), 2 = bf16x3 '
                          '(outside the 1e-4 eV/A bar at MD-scale forces), 1 = plain bf16')
     ap.add_argument('--no-overlap', action='store_true', help='radial MLPs on the main stream (no second stream)')
+    ap.add_argument('--no-transposed', action='store_true', help='last layer: per-edge g_xe rows + segment sum instead of the '
+                    'transposed scalar convolution (A/B switch, Python host)')
     ap.add_argument('--halo', default='auto', choices=['auto', 'native', 'torch'],
                     help="N > 1: ghost exchange by libsnet_hip.so's own RCCL send/recv groups ('native', default with the "
                          "nccl backend) or by torch.distributed.all_to_all_single ('torch'; the only choice over gloo)")
@@ -233,7 +235,8 @@ def main():
     cfg = model_config(a.model)
     sd = random_state_dict(cfg, seed=0)
     modal = 'mpa' if cfg.get('use_modality') else None
-    eng = HipForceEngine(cfg, sd, device=dev, mlp_mode=a.mlp_mode, fused=(False if a.fused == 'off' else a.fused), fused_terms=a.terms, modal=modal, overlap=not a.no_overlap)
+    eng = HipForceEngine(cfg, sd, device=dev, mlp_mode=a.mlp_mode, fused=(False if a.fused == 'off' else a.fused), fused_terms=a.terms, modal=modal, overlap=not a.no_overlap,
+                         transposed_conv=not a.no_transposed)
 
     # workloads of SURVEY.md section 8(d): config 3 (SevenNet-0: sigma 0.05 A, seed 2), config 4 (l3i5: "amorphous",
     # sigma 0.35 A with a 1.8 A minimum-distance reject, seed 3), config 5's per-GPU share (MF-ompa: 4-species

@@ -190,6 +190,21 @@ int snet_fused_plan_create(const snet_conv_plan *plan, const snet_mlp_plan *mlp,
 void snet_fused_plan_destroy(snet_fused_plan *plan);
 int snet_edge_tiles(const int32_t *row_ptr, int64_t n_dst, int32_t *tile_ptr, int32_t *tile_node, int64_t tile_capacity,
                     int64_t *n_tiles, void *stream);
+/* Scalar-output shapes (every path (l, l -> 0): the last interaction layer): the source-row gradient
+ *   g_x[j] = sum over the edges e that have j as their source of  w_e * T * Y(e) * g_out[center(e)]
+ * is itself a uvu convolution -- shape `tag` (x = the g_out row, out = g_x), radial weights W2 with column c scaled by
+ * col_scale[c], run with snet_conv_fwd_fused over the edges grouped by SOURCE (row_ptr = col_ptr, src = center_t, w_row =
+ * w_row_t, sh rows gathered by eperm; n_dst = n_total).  It gathers dout floats per edge where the per-edge path
+ * (g_xe of snet_conv_bwd_fused + snet_segment_sum_rows_chunked) writes and re-reads dx floats.  Replaces nothing in the
+ * reference (e3nn's autograd scatters g_x rows with index_add, sevenn/nn/convolution.py:130-136); exists because the
+ * reverse kernel's g_xe stores are half of the last layer's time.
+ * snet_conv_plan_transposed: tag[13] ("" when the shape has a non-scalar output), col_scale[wn] (nullable), dead[2 k] =
+ * (offset, length) ranges of g_x the transposed product leaves unwritten (zero them).
+ * snet_edges_by_source: center_t[e'] / w_row_t[e'] of the edge eperm[e'] (w_row NULL: w_row_t = eperm). */
+int snet_conv_plan_transposed(const snet_conv_plan *plan, char *tag, float *col_scale, int32_t *dead, int32_t dead_capacity,
+                              int32_t *n_dead);
+int snet_edges_by_source(const int32_t *row_ptr, int64_t n_dst, const int32_t *eperm, const int32_t *w_row, int64_t n_edges,
+                         int32_t *center_t, int32_t *w_row_t, void *stream);
 int snet_conv_fwd_fused(const snet_fused_plan *plan, const float *x, const float *sh, const float *h2,
                         const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale,
                         float *out, void *stream);

@@ -70,6 +70,8 @@ SIGNATURES = {
     'snet_radial_mlp_hidden_fwd': (C.c_int, [C.c_void_p, c_f32p, C.c_int64, c_f32p, c_stream]),
     'snet_radial_mlp_hidden_bwd': (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int64, c_f32p, c_stream]),
     'snet_conv_fused_available': (C.c_int, [C.c_void_p]),
+    'snet_conv_plan_transposed': (C.c_int, [C.c_void_p, C.c_char_p, c_f32p, c_i32p, C.c_int32, C.POINTER(C.c_int32)]),
+    'snet_edges_by_source': (C.c_int, [c_i32p, C.c_int64, c_i32p, c_i32p, C.c_int64, c_i32p, c_i32p, c_stream]),
     'snet_fused_plan_create': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     'snet_fused_plan_destroy': (None, [C.c_void_p]),
     'snet_edge_tiles': (C.c_int, [c_i32p, C.c_int64, c_i32p, c_i32p, C.c_int64, C.POINTER(C.c_int64), c_stream]),

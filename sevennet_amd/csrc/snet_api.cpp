@@ -1,4 +1,6 @@
 // C-ABI glue of libsnet_hip.so: error state, compiled-shape registry, conv plans, scratch.
+#include <cstdio>
+#include <cstring>
 #include <map>
 #include <vector>
 
@@ -121,6 +123,21 @@ int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, c
   SNET_CHECK_LAUNCH("snet_conv_fwd");
   return 0;
 }
+int snet_conv_plan_transposed(const snet_conv_plan *plan, char *tag, float *col_scale, int32_t *dead, int32_t dead_capacity,
+                              int32_t *n_dead) {
+  SNET_REQUIRE(plan != nullptr && tag != nullptr, "snet_conv_plan_transposed: null argument");
+  const snet::ConvKernels *k = plan->k;
+  tag[0] = 0;
+  if (n_dead) *n_dead = 0;
+  if (k->t_tag == nullptr) return 0;  // a non-scalar output: no transposed form
+  SNET_REQUIRE(dead == nullptr || dead_capacity >= 2 * k->t_ndead, "snet_conv_plan_transposed: dead[] too small");
+  snprintf(tag, 13, "%s", k->t_tag);
+  if (col_scale) memcpy(col_scale, k->t_col_scale, (size_t)k->wn * 4);
+  if (dead) memcpy(dead, k->t_dead, (size_t)k->t_ndead * 8);
+  if (n_dead) *n_dead = k->t_ndead;
+  return 0;
+}
+
 int snet_conv_fused_available(const snet_conv_plan *plan) {
   return plan != nullptr && snet::find_fused(plan->k->tag) != nullptr;
 }

@@ -44,6 +44,13 @@ struct ConvKernels {
   void (*bwd_node)(const float *sh, const float *w, const int32_t *w_row, const int32_t *col_ptr, const int32_t *eperm,
                    const int32_t *dst, int64_t n_src, float scale, const float *g_out, float *g_x,
                    hipStream_t st);
+  // scalar-output shapes (every path (l, l -> 0)): the source-row gradient is a forward convolution of the TRANSPOSED
+  // product (shape t_tag: x = the g_out row, out = g_x) with W2's column c scaled by t_col_scale[c]; t_dead = (offset,
+  // length) ranges of g_x no path writes.  t_tag == nullptr: the shape has a non-scalar output.
+  const char *t_tag;
+  const float *t_col_scale;
+  int t_ndead;
+  const int *t_dead;
 };
 void register_conv(const ConvKernels *k);
 

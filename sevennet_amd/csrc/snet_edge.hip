@@ -186,7 +186,34 @@ __global__ void edge_vectors_kernel(const double *__restrict__ pos, const int32_
   for (int k = 0; k < 3; ++k) out[3 * e + k] = (float)(pj[k] - pi[k] + (shift ? shift[3 * e + k] : 0.0));
 }
 
+// edges in source-grouped order e' (edge eperm[e']): destination atom (upper bound of the edge index in row_ptr) and
+// radial row
+__global__ void edges_by_source_kernel(const int32_t *__restrict__ row_ptr, int32_t n_dst, const int32_t *__restrict__ eperm,
+                                       const int32_t *__restrict__ w_row, int64_t E, int32_t *__restrict__ center_t,
+                                       int32_t *__restrict__ w_row_t) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= E) return;
+  const int32_t e = eperm[i];
+  int32_t lo = 0, hi = n_dst;  // largest node with row_ptr[node] <= e
+  while (hi - lo > 1) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (row_ptr[mid] <= e) lo = mid; else hi = mid;
+  }
+  center_t[i] = lo;
+  w_row_t[i] = w_row ? w_row[e] : e;
+}
+
 }  // namespace
+
+extern "C" int snet_edges_by_source(const int32_t *row_ptr, int64_t n_dst, const int32_t *eperm, const int32_t *w_row,
+                                    int64_t E, int32_t *center_t, int32_t *w_row_t, void *stream) {
+  if (E <= 0) return 0;
+  SNET_REQUIRE(row_ptr && eperm && center_t && w_row_t && n_dst > 0, "snet_edges_by_source: null argument");
+  edges_by_source_kernel<<<(unsigned)((E + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      row_ptr, (int32_t)n_dst, eperm, w_row, E, center_t, w_row_t);
+  SNET_CHECK_LAUNCH("snet_edges_by_source");
+  return 0;
+}
 
 extern "C" int snet_edge_vectors(const double *pos, const int32_t *center, const int32_t *src, const double *shift,
                                  int64_t E, float *edge_vec, void *stream) {

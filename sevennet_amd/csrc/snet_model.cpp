@@ -115,6 +115,11 @@ struct Layer {
   snet_mlp_plan *mlp_plan = nullptr;
   snet_fused_plan *fused = nullptr;  // radial-MLP last layer inside the tensor-product kernels (where the shape has them)
   int32_t *gxe_chunks = nullptr;     // device: chunk order of the fused reverse kernel's g_xe rows (dx / 16 entries)
+  // scalar-output layer (t > 0): source-row gradient as a forward convolution of the transposed product (snet_hip.h)
+  snet_conv_plan *tconv = nullptr;
+  snet_mlp_plan *tmlp = nullptr;
+  snet_fused_plan *tfused = nullptr;
+  std::vector<int32_t> t_dead;       // (offset, length) column ranges of g_h it leaves unwritten
   Linear sc, si1, si2;
   std::vector<snet_gate_seg> segs;
 };
@@ -312,6 +317,24 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
              hipMalloc((void **)&L.gxe_chunks, cp.size() * 4) == hipSuccess &&
              hipMemcpy(L.gxe_chunks, cp.data(), cp.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     }
+    if (good && L.fused && t > 0 && L.dmid < L.dx && getenv("SNET_NO_TRANSPOSED") == nullptr) {
+      char ttag[13];
+      std::vector<float> cs((size_t)L.wn);
+      int32_t dead[32], nd = 0;
+      if (snet_conv_plan_transposed(L.conv, ttag, cs.data(), dead, 32, &nd) == 0 && ttag[0] != 0 &&
+          snet_conv_plan_create(ttag, &L.tconv) == 0 && snet_conv_fused_available(L.tconv)) {
+        std::vector<float> w2t(w2);
+        for (int k = 0; k < L.mlp[2]; ++k)
+          for (int c = 0; c < L.wn; ++c) w2t[(size_t)k * L.wn + c] *= cs[c];
+        good = snet_radial_mlp_plan_create(L.mlp[0], L.mlp[1], L.mlp[2], L.mlp[3], w0.data(), w1.data(), w2t.data(),
+                                           m->act_radial, m->act_cst, 1, &L.tmlp) == 0 &&
+               snet_fused_plan_create(L.tconv, L.tmlp, SNET_FUSED_TERMS_DEFAULT, &L.tfused) == 0;
+        L.t_dead.assign(dead, dead + 2 * nd);
+      } else if (L.tconv) {  // the transposed shape is not in this build: per-edge rows + segment sum
+        snet_conv_plan_destroy(L.tconv);
+        L.tconv = nullptr;
+      }
+    }
     good = good && read_linear(r, L.sc) && read_linear(r, L.si1) && read_linear(r, L.si2);
     if (good) {
       const int ns = r.i32();
@@ -375,6 +398,9 @@ extern "C" void snet_model_destroy(snet_model *m) {
   };
   for (auto &L : m->layers) {
     snet_fused_plan_destroy(L.fused);
+    snet_fused_plan_destroy(L.tfused);
+    snet_radial_mlp_plan_destroy(L.tmlp);
+    snet_conv_plan_destroy(L.tconv);
     if (L.gxe_chunks) (void)hipFree(L.gxe_chunks);
     snet_conv_plan_destroy(L.conv);
     snet_radial_mlp_plan_destroy(L.mlp_plan);
@@ -447,8 +473,11 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   SNET_REQUIRE(!pairs || (pair_edge != nullptr && n_pairs > 0 && n_pairs <= E),
                "snet_model_eval: w_row needs pair_edge and 0 < n_pairs <= n_edges");
   const int64_t WR = pairs ? n_pairs : E;  // rows of each layer's radial-weight matrix
-  bool any_fused = false;
-  for (auto &L : m->layers) any_fused |= L.fused != nullptr;
+  bool any_fused = false, any_transposed = false;
+  for (auto &L : m->layers) {
+    any_fused |= L.fused != nullptr;
+    any_transposed |= L.tfused != nullptr;
+  }
   // the second stream only carries the separate radial-MLP kernels (same policy as engine.py)
   bool ov = m->overlap && E > 0 && E <= OVERLAP_MAX_EDGES && !any_fused;
   if (ov && m->side == nullptr) {  // created on first use; any failure just keeps everything on one stream
@@ -511,6 +540,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   for (auto &L : m->layers) wn_max = wn_max > (size_t)L.wn ? wn_max : (size_t)L.wn;
   if (ov) { add((size_t)E * wn_max); add((size_t)E * wn_max); }  // g_w double buffer (its reader runs on the side stream)
   if (any_fused) { add((size_t)N + 64); add((size_t)N + (size_t)E / 16 + 64); }  // tile_ptr, tile_node
+  if (any_transposed) { add((size_t)E + 64); add((size_t)E + 64); add((size_t)E * nsh + 64); }  // center_t, w_row_t, sh_t
   add((size_t)NT * dmax * 2 + 256); add((size_t)N * (m->ro1.dim_out + 8) * 2); add(trans + 64 * 1024);
   need += 1 << 20;
   if (m->arena.cap < need) {
@@ -550,6 +580,15 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     tile_ptr = reinterpret_cast<int32_t *>(A.f((size_t)N + 64));
     tile_node = reinterpret_cast<int32_t *>(A.f((size_t)N + (size_t)E / 16 + 64));
     if ((rc = snet_edge_tiles(row_ptr, N, tile_ptr, tile_node, N + E / 16 + 1, &n_tiles, st))) return rc;
+  }
+  int32_t *center_t = nullptr, *w_row_t = nullptr;  // edges grouped by source (transposed scalar convolution)
+  float *sh_t = nullptr;
+  if (any_transposed && E > 0) {
+    center_t = reinterpret_cast<int32_t *>(A.f((size_t)E + 64));
+    w_row_t = reinterpret_cast<int32_t *>(A.f((size_t)E + 64));
+    sh_t = A.f((size_t)E * nsh + 64);
+    if ((rc = snet_edges_by_source(row_ptr, N, eperm, pairs ? w_row : nullptr, E, center_t, w_row_t, st))) return rc;
+    if ((rc = snet_gather_rows(sh, eperm, sh_t, E, nsh, st))) return rc;
   }
   float *gw_buf[2] = {nullptr, nullptr};
   bool gw_busy[2] = {false, false};
@@ -636,7 +675,8 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     if ((rc = snet_gate_bwd(saved[t].y, g_x, g_y, N, L.gin, L.dout, L.segs.data(), (int)L.segs.size(), st))) return rc;
     float *g_m = A.f((size_t)N * L.dmid);
     if ((rc = run_linear(m, L.si2, g_y, g_m, N, true, false, st))) return rc;
-    float *g_xe = t > 0 ? A.f((size_t)E * L.dx) : nullptr;
+    const bool transposed = t > 0 && L.tfused != nullptr && E > 0;
+    float *g_xe = t > 0 && !transposed ? A.f((size_t)E * L.dx) : nullptr;
     if (L.fused) {  // g_w is contracted with W2^T inside the kernel; with the hidden-layer tail not even g_h2 leaves it
       const bool tail = snet_fused_plan_has_mlp_tail(L.fused) != 0;
       float *g_h2 = tail ? nullptr : A.f((size_t)E * 64);
@@ -653,7 +693,15 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
         return rc;
       if (t > 0) {
         float *g_h = A.f((size_t)NT * L.dx);
-        if ((rc = snet_segment_sum_rows_chunked(g_xe, col_ptr, eperm, NT, L.dx, L.gxe_chunks, g_h, st))) return rc;
+        if (transposed) {
+          for (size_t i = 0; i + 1 < L.t_dead.size(); i += 2)
+            SNET_REQUIRE(hipMemset2DAsync(g_h + L.t_dead[i], (size_t)L.dx * 4, 0, (size_t)L.t_dead[i + 1] * 4, (size_t)NT, st) ==
+                             hipSuccess, "snet_model_eval: memset failed");
+          if ((rc = snet_conv_fwd_fused(L.tfused, g_m, sh_t, saved[t].w, w_row_t, col_ptr, center_t, NT, L.conv_scale, g_h, st)))
+            return rc;
+        } else if ((rc = snet_segment_sum_rows_chunked(g_xe, col_ptr, eperm, NT, L.dx, L.gxe_chunks, g_h, st))) {
+          return rc;
+        }
         if (has_halo)
           if ((rc = m->halo_rev(m->halo_user, g_h, NT, N, L.dx, stream))) {
             snet::set_error("snet_model_eval: reverse halo callback failed");

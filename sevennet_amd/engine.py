@@ -24,7 +24,7 @@ import torch
 
 from . import _lib
 from .model_spec import (ACT_CST, ACT_ID, LinearSpec, ModelSpec, build_model_spec, linear_modal_bias,
-                         linear_weight_matrices)
+                         linear_weight_matrices, transposed_scalar_conv)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -63,6 +63,18 @@ class Graph:
     tile_ptr: Optional[torch.Tensor] = None
     tile_node: Optional[torch.Tensor] = None
     n_tiles: int = 0
+    # edges grouped by SOURCE atom (order eperm): destination row and radial row of each (transposed scalar convolution)
+    src_T: Optional[torch.Tensor] = None
+    w_row_T: Optional[torch.Tensor] = None
+
+    def by_source(self, lib, stream):
+        """(center[eperm], w_row[eperm]) as int32 arrays, built on first use (w_row None: the edge's own row, eperm)"""
+        if self.src_T is None:
+            self.src_T, self.w_row_T = torch.empty_like(self.eperm), torch.empty_like(self.eperm)
+            _lib.check(lib.snet_edges_by_source(_ptr(self.row_ptr), self.n_local, _ptr(self.eperm), _ptr(self.w_row),
+                                                self.n_edges, _ptr(self.src_T), _ptr(self.w_row_T), stream),
+                       'snet_edges_by_source')
+        return self.src_T, self.w_row_T
 
     def tiles(self):
         """(tile_ptr, tile_node, n_tiles), built on first use"""
@@ -237,7 +249,7 @@ class HipForceEngine:
 
     def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6',
                  linear_mode: str = 'bf16x6', fused='auto', fused_terms='f16x3', modal=None, overlap: bool = True,
-                 mlp_tail: bool = True):
+                 mlp_tail: bool = True, transposed_conv: bool = True):
         """mlp_mode / linear_mode: 'bf16x6' (split-precision MFMA, fp32-class accuracy, default) or
         'fp32' (exact fp32 MFMA) for the fused radial MLP / the node-level equivariant linears.
         fused: 'auto' (default) / True / False / 'fwd' / 'bwd' -- run the radial MLP's last layer INSIDE the
@@ -260,6 +272,8 @@ class HipForceEngine:
         exclusive, so large graphs stay on one stream.  Every buffer the side stream touches is allocated on the main stream and
         reused explicitly (double-buffered g_w): `record_stream`-deferred frees of 10-GB blocks made the
         caching allocator fall back to hipMalloc/hipFree, a 3x slowdown at 100k atoms.
+        transposed_conv: scalar-output layers (the last one) take their source-row gradient from a forward convolution of the
+        transposed tensor product over the edges grouped by source atom instead of per-edge g_xe rows + a segment sum.
         modal: fidelity channel (name from config['_modal_map'] or index) of a multi-modal model; the
         one-hot inputs of its linears become constant biases, shift/scale rows are selected at load.
         """
@@ -361,6 +375,32 @@ class HipForceEngine:
                     L.gxe_chunks = torch.tensor(list(cp), dtype=torch.int32, device=self.dev)
                 L.fused_fwd = L.fplan is not None and fused in ('auto', True, 'fwd')
                 L.fused_bwd = L.fplan is not None and fused in ('auto', True, 'bwd')
+                # scalar-output layer (the last one): its source-row gradient as a forward convolution of the transposed
+                # product over the edges grouped by source -- gathers dout floats per edge instead of writing and
+                # re-reading a dx-float g_xe row (model_spec.transposed_scalar_conv)
+                L.tplan = None
+                tr = transposed_scalar_conv(ls.conv) if (L.fused_bwd and transposed_conv and ls.t > 0) else None
+                if tr is not None and ls.conv.irreps_out.dim < ls.conv.irreps_x.dim:
+                    spec_t, kappa = tr
+                    if spec_t.tag not in _lib.compiled_conv_tags():
+                        from .jit import ensure_conv_shape
+                        ensure_conv_shape(spec_t)
+                    # the column factors and dead ranges come from the shape's own tables, like in the C++ sequencer
+                    ttag, col = C.create_string_buffer(13), np.empty(ls.conv.weight_numel, np.float32)
+                    dead, nd = (C.c_int32 * 32)(), C.c_int32()
+                    _lib.check(self.lib.snet_conv_plan_transposed(plan, ttag, col.ctypes.data_as(C.c_void_p), C.cast(dead, C.c_void_p),
+                                                                  32, C.byref(nd)), 'snet_conv_plan_transposed')
+                    assert ttag.value.decode() == spec_t.tag, (ttag.value, spec_t.tag)
+                    w2t = np.ascontiguousarray(np.asarray(hw[2], np.float32) * col[None, :], dtype=np.float32)
+                    tpl, tmlp, tfp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+                    _lib.check(self.lib.snet_conv_plan_create(spec_t.tag.encode(), C.byref(tpl)), 'snet_conv_plan_create')
+                    _lib.check(self.lib.snet_radial_mlp_plan_create(d[0], d[1], d[2], d[3], fp[0], fp[1],
+                                                                    w2t.ctypes.data_as(C.POINTER(C.c_float)),
+                                                                    ACT_ID[sp.act_radial], ACT_CST[sp.act_radial], 1, C.byref(tmlp)),
+                               'snet_radial_mlp_plan_create')
+                    _lib.check(self.lib.snet_fused_plan_create(tpl, tmlp, self.fused_terms, C.byref(tfp)), 'snet_fused_plan_create')
+                    L.tplan, L.tmlp, L.tconv = tfp, tmlp, tpl
+                    L.t_dead = [(dead[2 * i], dead[2 * i + 1]) for i in range(nd.value)]
                 segs = (_lib.GateSeg * len(ls.gate.segs))()
                 inv_act = {v: k for k, v in ACT_ID.items()}
                 for i, s in enumerate(ls.gate.segs):
@@ -384,6 +424,10 @@ class HipForceEngine:
             for L in getattr(self, 'layers', []):
                 if getattr(L, 'fplan', None) is not None:
                     self.lib.snet_fused_plan_destroy(L.fplan)
+                if getattr(L, 'tplan', None) is not None:
+                    self.lib.snet_fused_plan_destroy(L.tplan)
+                    self.lib.snet_conv_plan_destroy(L.tconv)
+                    self.lib.snet_radial_mlp_plan_destroy(L.tmlp)
                 self.lib.snet_conv_plan_destroy(L.plan)
                 if getattr(L, 'mlp_plan', None) is not None:
                     self.lib.snet_radial_mlp_plan_destroy(L.mlp_plan)
@@ -620,6 +664,7 @@ class HipForceEngine:
                 g_e.fill_(self.scale0)
             g_h1 = self._linear_T(self.ro2, g_e, N, g)
             g_x = self._linear_T(self.ro1, g_h1, N, g)
+            sh_T = None   # spherical harmonics in source-grouped edge order (transposed scalar convolution)
             g_vec = torch.zeros(E, 3, dtype=torch.float32, device=self.dev)  # spherical part, all layers
             g_emb = torch.zeros(E, nb, dtype=torch.float32, device=self.dev)
             for t in range(len(self.layers) - 1, -1, -1):
@@ -632,7 +677,8 @@ class HipForceEngine:
                 with _Span(self, 'node_linear_bwd'):
                     g_m = self._linear_T(L.si2, g_y, N, g)
                 # layer 0: inputs depend on species only -> no source-row gradient needed
-                g_xe = self._new(E, ls.si1.dim_out) if t > 0 else None
+                use_t = t > 0 and getattr(L, 'tplan', None) is not None and E > 0
+                g_xe = self._new(E, ls.si1.dim_out) if (t > 0 and not use_t) else None
                 g_w = g_h2 = None
                 if L.fused_bwd:
                     g_h2 = None if L.mlp_tail else self._new(E, 64)
@@ -668,7 +714,21 @@ class HipForceEngine:
                 # the source-row gradient goes first so that its ghost rows can travel to their owners while
                 # the radial MLP's reverse pass (independent of them) runs
                 pending = None
-                if t > 0:
+                if use_t:
+                    # g_h[j] = sum over the edges that have j as their source: a forward convolution of the transposed product,
+                    # "x" = the destination's g_m row (scalars), Y and the radial rows in source-grouped edge order
+                    src_t, w_row_t = g.by_source(lib, st)
+                    g_h = self._new(NT, ls.si1.dim_out)
+                    if L.t_dead:
+                        g_h.zero_()
+                    with _Span(self, f'conv_bwd_node[transposed {ls.conv.tag}]'):
+                        if sh_T is None:
+                            sh_T = self._new(E, nsh)
+                            _lib.check(lib.snet_gather_rows(_ptr(sh), _ptr(g.eperm), _ptr(sh_T), E, nsh, st), 'snet_gather_rows')
+                        _lib.check(lib.snet_conv_fwd_fused(L.tplan, _ptr(g_m), _ptr(sh_T), _ptr(h2), _ptr(w_row_t),
+                                                           _ptr(g.col_ptr), _ptr(src_t), NT, L.scale, _ptr(g_h), st),
+                                   'snet_conv_fwd_fused')
+                elif t > 0:
                     g_h = self._new(NT, ls.si1.dim_out)
                     with _Span(self, 'conv_bwd_node[segment_sum]'):
                         if L.fused_bwd:   # the fused kernel's g_xe rows: chunk order undone while summing
@@ -679,12 +739,12 @@ class HipForceEngine:
                             _lib.check(lib.snet_segment_sum_rows(_ptr(g_xe), _ptr(g.col_ptr), _ptr(g.eperm), NT,
                                                                  ls.si1.dim_out, _ptr(g_h), st), 'snet_segment_sum_rows')
                     del g_xe
-                    if halo is not None:
-                        with _Span(self, 'halo_rev'):
-                            if hasattr(halo, 'reverse_start'):
-                                pending = halo.reverse_start(g_h, N)
-                            else:
-                                halo.reverse(g_h, N)
+                if t > 0 and halo is not None:
+                    with _Span(self, 'halo_rev'):
+                        if hasattr(halo, 'reverse_start'):
+                            pending = halo.reverse_start(g_h, N)
+                        else:
+                            halo.reverse(g_h, N)
                 if L.fused_bwd and L.mlp_tail:
                     pass
                 elif L.fused_bwd:

@@ -180,6 +180,45 @@ class ConvSpec:
         return hashlib.sha1(self.key.encode()).hexdigest()[:12]
 
 
+def transposed_scalar_conv(conv: ConvSpec):
+    """Source-row gradient of a convolution whose outputs are all scalars (the last interaction layer of every NequIP-style
+    model: paths (l, l -> 0) only), as a FORWARD convolution over the edges grouped by SOURCE atom:
+
+        g_x[j][a, u] = sum_{e: src(e) = j} w_e[u] * T_{a b 0} Y_b(e) * g_out[dst(e)][u]      (T = sqrt(2 l3 + 1) * w3j)
+
+    i.e. a uvu tensor product with "x" = the destination's g_out row (scalars), the same spherical harmonics and the
+    same radial weights up to one constant per path.  Gathering the 4 * dout bytes of g_out per edge instead of writing
+    and re-reading the 4 * dx bytes of a per-edge g_xe row pays exactly when dout < dx.
+    Returns (ConvSpec of the transposed product, kappa[path] = factor on the path's weight columns), or None when the
+    convolution has a non-scalar output path."""
+    from .codegen import _path_terms
+    if not conv.paths or any(p.l3 != 0 for p in conv.paths):
+        return None
+    x_off = conv.irreps_x.offsets()
+    order = sorted(range(len(conv.paths)), key=lambda k: (conv.paths[k].out_off, conv.paths[k].out_ch))
+    if len({conv.paths[k].i_x for k in order}) != len(order):
+        return None
+    # "x" of the transposed product = g_out row: one scalar block per path, in memory order
+    irreps_g = Irreps([(conv.paths[k].mul, 0, 1) for k in order])
+    g_index = {k: i for i, k in enumerate(order)}
+    g_off = irreps_g.offsets()
+    paths, kappa = [], []
+    for k, p in enumerate(conv.paths):      # same path order -> same weight-column offsets
+        mul, l, par = conv.irreps_x[p.i_x]
+        q = ConvPath(g_index[k], p.i_sh, 0, p.l2, l, p.mul, p.w_off, g_off[g_index[k]], p.sh_off, x_off[p.i_x], mul, 0)
+        fwd = {(a, b): v for a, b, c, v in _path_terms(p)}            # out_0 = sum T[a, b, 0] x_a Y_b
+        tr = {(c, b): v for a, b, c, v in _path_terms(q)}             # out_c = sum T'[0, b, c] g Y_b
+        if set(fwd) != set(tr):
+            return None
+        r = [fwd[key] / tr[key] for key in fwd]
+        if max(r) - min(r) > 1e-12 * max(abs(v) for v in r):
+            return None
+        kappa.append(float(r[0]))
+        paths.append(q)
+    spec = ConvSpec(irreps_g, conv.irreps_sh, Irreps(conv.irreps_x), Irreps(conv.irreps_x), paths, conv.weight_numel)
+    return spec, kappa
+
+
 def make_conv(irreps_x: Irreps, irreps_sh: Irreps, irreps_target: Irreps, sort_by_out: bool) -> ConvSpec:
     """Instruction generation of sevenn/nn/convolution.py:61-82.  Weight columns
     follow the (possibly re-sorted) instruction order, `mul_x` per instruction;

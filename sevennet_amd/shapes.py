@@ -9,7 +9,7 @@ from __future__ import annotations
 from typing import Dict, List
 
 from .model_spec import (ConvSpec, build_model_spec, sevennet_0_config,
-                         sevennet_l3i5_config, sevennet_mf_ompa_config)
+                         sevennet_l3i5_config, sevennet_mf_ompa_config, transposed_scalar_conv)
 
 # the reference's deployed example model (sevenn 0.8.6), used by the golden fixtures
 TS_EXAMPLE_CONFIG = dict(
@@ -61,4 +61,8 @@ def aot_conv_specs(extra_configs: List[dict] = ()) -> Dict[str, ConvSpec]:
     for cfg in list(aot_configs().values()) + list(extra_configs):
         for ls in build_model_spec(cfg).layers:
             specs.setdefault(ls.conv.tag, ls.conv)
+            # scalar-output (last) layers: the source-row gradient runs as a forward convolution of the transposed product
+            tr = transposed_scalar_conv(ls.conv)
+            if tr is not None and all(mul % 16 == 0 for mul, _, _ in ls.conv.irreps_x):
+                specs.setdefault(tr[0].tag, tr[0])
     return specs

@@ -167,3 +167,38 @@ def test_unlisted_shape_is_compiled_on_demand(tmp_path, monkeypatch):
     assert jit.compile_shape(spec) == os.path.join(str(tmp_path), files[0])   # cache hit: same file
     with pytest.raises(RuntimeError, match='dlopen'):
         _lib.check(lib.snet_conv_register_library(str(tmp_path / 'missing.so').encode()), 'snet_conv_register_library')
+
+
+def test_scalar_output_shapes_carry_their_transposed_form():
+    """last-layer shapes (paths (l, l -> 0) only) name the transposed product + W2 column factors; others do not"""
+    from sevennet_amd.model_spec import (build_model_spec, sevennet_0_config, sevennet_l3i5_config, sevennet_mf_ompa_config,
+                                         transposed_scalar_conv)
+    from sevennet_amd import _lib
+    lib = _lib.load()
+    for cfg in (sevennet_0_config(), sevennet_l3i5_config(), sevennet_mf_ompa_config()):
+        layers = build_model_spec(cfg).layers
+        for ls in (layers[1], layers[-1]):
+            plan = C.c_void_p()
+            _lib.check(lib.snet_conv_plan_create(ls.conv.tag.encode(), C.byref(plan)), 'snet_conv_plan_create')
+            tag, col = C.create_string_buffer(13), np.zeros(ls.conv.weight_numel, np.float32)
+            dead, nd = (C.c_int32 * 32)(), C.c_int32(-1)
+            _lib.check(lib.snet_conv_plan_transposed(plan, tag, col.ctypes.data_as(C.c_void_p), C.cast(dead, C.c_void_p), 32,
+                                                     C.byref(nd)), 'snet_conv_plan_transposed')
+            tr = transposed_scalar_conv(ls.conv)
+            if ls is layers[1]:
+                assert tr is None and tag.value == b'' and nd.value == 0
+                continue
+            spec_t, kappa = tr
+            assert tag.value.decode() == spec_t.tag and spec_t.tag in _lib.compiled_conv_tags()
+            # the transposed product swaps the roles of x and out; same weight columns
+            assert spec_t.irreps_out.dim == ls.conv.irreps_x.dim and spec_t.irreps_x.dim == ls.conv.irreps_out.dim
+            assert spec_t.weight_numel == ls.conv.weight_numel
+            for p, k in zip(ls.conv.paths, kappa):
+                l = ls.conv.irreps_x[p.i_x][1]
+                assert k == pytest.approx((2 * l + 1) ** -0.5, rel=1e-12)
+                assert np.all(col[p.w_off:p.w_off + p.mul] == np.float32(k))
+            fed = {p.i_x for p in ls.conv.paths}
+            want = [(off, m * (2 * l + 1)) for i, (off, (m, l, _)) in
+                    enumerate(zip(ls.conv.irreps_x.offsets(), ls.conv.irreps_x)) if i not in fed]
+            assert [(dead[2 * i], dead[2 * i + 1]) for i in range(nd.value)] == want
+            lib.snet_conv_plan_destroy(plan)

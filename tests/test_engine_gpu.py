@@ -566,6 +566,35 @@ def test_fused_engine_equals_separate_kernels(model):
         assert (rc['forces'] - rb['forces']).abs().max().item() < 2e-5 * fs
 
 
+@pytest.mark.parametrize('model', ['sevennet_0', 'sevennet_l3i5', 'sevennet_mf_ompa'])
+def test_transposed_last_layer_equals_per_edge_rows(model):
+    """last interaction layer (scalar outputs only): source-row gradient as a forward convolution of the transposed
+    product over the source-grouped edges == per-edge g_xe rows + segment sum; with and without the undirected-pair map"""
+    from bench import model_config
+    from sevennet_amd.engine import HipForceEngine, build_graph
+    from sevennet_amd.neighbor import diamond_cubic, neighbor_list
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = model_config(model)
+    sd = random_state_dict(cfg, 4)
+    modal = 'mpa' if cfg.get('use_modality') else None
+    pos, cell = diamond_cubic(5.431, (3, 3, 2), 0.08, 6)
+    ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
+    a = HipForceEngine(cfg, sd, device='cuda:0', modal=modal)
+    b = HipForceEngine(cfg, sd, device='cuda:0', modal=modal, transposed_conv=False)
+    assert [L.tplan is not None for L in a.layers] == [False] * (len(a.layers) - 1) + [True]
+    assert all(L.tplan is None for L in b.layers)
+    for pair_map in (True, False):
+        g = build_graph(np.zeros(len(pos), np.int64), ei, ev, device='cuda:0', share_pairs=pair_map,
+                        num_species=a.spec.num_species)
+        ra, rb = a.compute(g), b.compute(g)
+        torch.cuda.synchronize()
+        assert (g.w_row is not None) == pair_map
+        assert ra['energy'].item() == rb['energy'].item()
+        fs = max(1.0, rb['forces'].abs().max().item())
+        assert (ra['forces'] - rb['forces']).abs().max().item() < 1e-5 * fs
+        assert (ra['virial'] - rb['virial']).abs().max().item() < 1e-5 * max(1.0, rb['virial'].abs().max().item())
+
+
 def test_native_rccl_halo_self_exchange():
     """csrc/snet_halo.cpp on a world-1 RCCL communicator (one GPU): the rank sends rows to itself.  forward fills
     the ghost rows with the owners' rows; reverse adds ghost rows into their owners, duplicates summed in fixed
