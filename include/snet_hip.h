@@ -276,6 +276,10 @@ int snet_gate_fwd(float *y, const float *addend, float *out, int64_t n_nodes, in
                   const snet_gate_seg *segs_host, int32_t n_segs, void *stream);
 int snet_gate_bwd(const float *y, const float *g_out, float *g_y, int64_t n_nodes, int32_t dim_in,
                   int32_t dim_out, const snet_gate_seg *segs_host, int32_t n_segs, void *stream);
+/* snet_gate_bwd that also returns row_norm[n] = norm_mult * ||g_y[n]||_2 (nullable), the bound snet_row_norm2 gives: the rows
+ * are in registers anyway, one pass over g_y less per layer. */
+int snet_gate_bwd_norm(const float *y, const float *g_out, float *g_y, int64_t n_nodes, int32_t dim_in, int32_t dim_out,
+                       const snet_gate_seg *segs, int32_t n_segs, float norm_mult, float *row_norm, void *stream);
 
 /* ---- a6: species embedding (one-hot @ W == table lookup) ------------------
  * replaces OnehotEmbedding + first IrrepsLinear, node_embedding.py:44-53,

@@ -95,6 +95,8 @@ SIGNATURES = {
                                 c_stream]),
     'snet_gate_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(GateSeg),
                                 C.c_int32, c_stream]),
+    'snet_gate_bwd_norm': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(GateSeg),
+                                     C.c_int32, C.c_float, c_f32p, c_stream]),
     'snet_embed_rows': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
     'snet_add_row_bias': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
     'snet_add_inplace': (C.c_int, [c_f32p, c_f32p, C.c_int64, c_stream]),

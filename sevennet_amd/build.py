@@ -43,8 +43,9 @@ def _hipcc() -> str:
 def _flags() -> List[str]:
     # -fno-slp-vectorize: SLP packing into v_pk_*_f32 duplicates operands into register pairs and
     # doubled the VGPR count of the tensor-product kernels (217 -> 115), halving their occupancy
+    # SNET_BUILD_DEFS="-DSNET_GEMM_OCC=3 ...": extra definitions of an experiment build (tools/gpu/ab_bench.sh)
     return [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fno-slp-vectorize',
-            f'-I{INCLUDE}', f'-I{CSRC}']
+            f'-I{INCLUDE}', f'-I{CSRC}'] + os.environ.get('SNET_BUILD_DEFS', '').split()
 
 
 def _stamp(src: str) -> str:

@@ -12,9 +12,14 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <type_traits>
+
 #include "snet_common.h"
 #include "snet_split.h"
 
+#ifndef SNET_GEMM_PIPE
+#define SNET_GEMM_PIPE 0
+#endif
 #ifndef SNET_GEMM_OCC
 #define SNET_GEMM_OCC 4
 #endif
@@ -205,6 +210,45 @@ __device__ __forceinline__ void gemm_split_body(snet::u32x4 *Bs, int bx, int by,
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[mt][t] = zero16();
 
+#if SNET_GEMM_PIPE
+  // Both operands run TWO k steps ahead of the MFMAs: the memory counter retires loads in order, so a B slab that is
+  // stored to LDS in the iteration that loaded it exposes the full L2 latency on every k step whatever the A rows do.
+  // Iteration q: issue A(q + 2), B(q + 2); multiply with A(q) (registers) and B(q) (LDS); store B(q + 1), loaded one iteration ago.
+  float ring[2][MT][8];
+  u32x4 stb[2][NST];
+  load_a(0, ring[0]);
+  load_b(0, stb[0]);
+  if (nq > 1) {
+    load_a(1, ring[1]);
+    load_b(1, stb[1]);
+  }
+  store_b(0, stb[0]);
+  __syncthreads();
+  auto step = [&](int q, auto J) {
+    constexpr int jj = decltype(J)::value;
+    Split3 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = split8(ring[jj][mt]);
+    if (q + 2 < nq) {
+      load_a(q + 2, ring[jj]);
+      load_b(q + 2, stb[jj]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int term = 0; term < 3; ++term) b[term] = as_bf16x8(Bs[jj * SLAB + (t * 3 + term) * 64 + lane]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][t] = mfma6(a[mt], b, acc[mt][t]);
+    }
+    if (q + 1 < nq) store_b(jj ^ 1, stb[jj ^ 1]);
+    __syncthreads();
+  };
+  for (int q = 0; q < nq; q += 2) {
+    step(q, std::integral_constant<int, 0>{});
+    if (q + 1 < nq) step(q + 1, std::integral_constant<int, 1>{});
+  }
+#else
   float av[MT][8], an[MT][8];
   u32x4 st[NST];
   load_a(0, av);
@@ -239,6 +283,8 @@ __device__ __forceinline__ void gemm_split_body(snet::u32x4 *Bs, int bx, int by,
     __syncthreads();
     buf ^= 1;
   }
+
+#endif
 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)

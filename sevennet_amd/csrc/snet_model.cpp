@@ -533,7 +533,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     dmax = dmax > (size_t)L.dout ? dmax : (size_t)L.dout;
     add((size_t)NT * L.dx); add(L.fused ? (size_t)WR * 64 : (size_t)WR * L.wn); add((size_t)N * L.gin);  // saved h, w | h2, y
     const size_t t = ((size_t)N * L.gin + 64) * 2 + (size_t)N * L.dmid * 2 + (size_t)E * (L.fused ? 64 : L.wn) + (size_t)E * L.dx +
-                     (size_t)NT * L.dx * 2 + (size_t)N * L.dout + 4096;
+                     (size_t)NT * L.dx * 2 + (size_t)N * L.dout + (size_t)NT + (size_t)N + 4096;  // + x_max, g_max
     trans = trans > t ? trans : t;
   }
   size_t wn_max = 0;
@@ -672,7 +672,11 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     Layer &L = m->layers[t];
     A.off = mark2;
     float *g_y = A.f((size_t)N * L.gin);
-    if ((rc = snet_gate_bwd(saved[t].y, g_x, g_y, N, L.gin, L.dout, L.segs.data(), (int)L.segs.size(), st))) return rc;
+    // fp16 operands of the fused reverse kernel: bound of every row of g_m = SI2^T g_y (Cauchy-Schwarz), taken in the same pass
+    float *g_max = (L.fused && E > 0 && SNET_FUSED_TERMS_DEFAULT == 4) ? A.f((size_t)N) : nullptr;
+    if ((rc = snet_gate_bwd_norm(saved[t].y, g_x, g_y, N, L.gin, L.dout, L.segs.data(), (int)L.segs.size(),
+                                 g_max ? L.si2.t_norm : 0.f, g_max, st)))
+      return rc;
     float *g_m = A.f((size_t)N * L.dmid);
     if ((rc = run_linear(m, L.si2, g_y, g_m, N, true, false, st))) return rc;
     const bool transposed = t > 0 && L.tfused != nullptr && E > 0;
@@ -680,12 +684,10 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     if (L.fused) {  // g_w is contracted with W2^T inside the kernel; with the hidden-layer tail not even g_h2 leaves it
       const bool tail = snet_fused_plan_has_mlp_tail(L.fused) != 0;
       float *g_h2 = tail ? nullptr : A.f((size_t)E * 64);
-      float *x_max = nullptr, *g_max = nullptr;
+      float *x_max = nullptr;
       if (E > 0 && SNET_FUSED_TERMS_DEFAULT == 4) {  // fp16 operands: bounds of every edge's g_w (see snet_row_absmax)
         x_max = A.f((size_t)NT);
-        g_max = A.f((size_t)N);
         if ((rc = snet_row_absmax(saved[t].h, NT, L.dx, x_max, st))) return rc;
-        if ((rc = snet_row_norm2(g_y, N, L.gin, L.si2.t_norm, g_max, st))) return rc;  // g_m = SI2^T g_y (Cauchy-Schwarz)
       }
       if (E > 0 && (rc = snet_conv_bwd_fused(L.fused, saved[t].h, sh, dsh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src,
                                              tile_ptr, tile_node, n_tiles, L.conv_scale, g_m, g_xe, g_h2,

@@ -672,8 +672,12 @@ class HipForceEngine:
                 ls = L.spec
                 h, w, zs, y, h2 = saved[t]
                 g_y = self._new(N, ls.gate.irreps_in.dim)
-                _lib.check(lib.snet_gate_bwd(_ptr(y), _ptr(g_x), _ptr(g_y), N, ls.gate.irreps_in.dim,
-                                             ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st), 'snet_gate_bwd')
+                # fp16 operands of the fused reverse kernel: row bound of g_m = SI2^T g_y through the narrower g_y and SI2's
+                # largest row norm (Cauchy-Schwarz), taken while the gate's reverse pass has the row in registers
+                g_max = self._new(N) if (L.fused_bwd and self.fused_terms == 4 and E > 0) else None
+                _lib.check(lib.snet_gate_bwd_norm(_ptr(y), _ptr(g_x), _ptr(g_y), N, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim,
+                                                  L.gate_segs, len(ls.gate.segs), L.si2.t_norm if g_max is not None else 0.0,
+                                                  _ptr(g_max), st), 'snet_gate_bwd_norm')
                 with _Span(self, 'node_linear_bwd'):
                     g_m = self._linear_T(L.si2, g_y, N, g)
                 # layer 0: inputs depend on species only -> no source-row gradient needed
@@ -682,16 +686,13 @@ class HipForceEngine:
                 g_w = g_h2 = None
                 if L.fused_bwd:
                     g_h2 = None if L.mlp_tail else self._new(E, 64)
-                    x_max = g_max = None
+                    x_max = None
                     if self.fused_terms == 4 and E > 0:
                         # fp16 operands: row maxima of the source rows and of the incoming gradient bound every edge's
                         # g_w, from which the kernel derives that edge's power-of-two scale (no overflow possible)
-                        # (g_m = SI2^T g_y: bounded through the 5x narrower g_y and SI2's largest row norm)
-                        x_max, g_max = self._new(NT), self._new(N)
+                        x_max = self._new(NT)
                         with _Span(self, 'row_bounds'):
                             _lib.check(lib.snet_row_absmax(_ptr(h), NT, ls.si1.dim_out, _ptr(x_max), st), 'snet_row_absmax')
-                            _lib.check(lib.snet_row_norm2(_ptr(g_y), N, ls.gate.irreps_in.dim, L.si2.t_norm, _ptr(g_max), st),
-                                       'snet_row_norm2')
                     with _Span(self, f'conv_bwd_fused[{ls.conv.tag}]'):
                         if E > 0:
                             _lib.check(lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(w_row),

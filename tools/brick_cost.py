@@ -52,12 +52,13 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         eng.compute(g, halo=halo)
+    t_host = (time.perf_counter() - t0) / a.steps * 1e3   # host time to enqueue a step (the GPU runs behind)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps * 1e3
     times = {k: round(float(np.sum(v)) / a.steps, 3) for k, v in eng.kernel_times_ms().items()}
     ghosts = g.n_total - g.n_local
     print(f'world {a.world} rank {a.rank}: {g.n_local} local atoms, {ghosts} ghost rows, {g.n_edges} edges, '
-          f'{g.n_pairs} radial-weight rows; {dt:.2f} ms/step (no exchange); '
+          f'{g.n_pairs} radial-weight rows; {dt:.2f} ms/step (no exchange), host enqueue {t_host:.2f} ms/step; '
           f'halo bytes/exchange {ghosts * 480 * 4 / 1e6:.1f} MB')
     print(dict(sorted(times.items(), key=lambda kv: -kv[1])))
 

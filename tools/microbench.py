@@ -89,6 +89,8 @@ def main():
     g_h2 = rnd(E, 64)
     tile_ptr, tile_node, n_tiles = g.tiles()
     x_max, g_max = h.abs().amax(1).contiguous(), g_m.abs().amax(1).contiguous()   # bounds of the fp16-operand mode
+    gy_r, y_r, sc_r = rnd(N, ls.si2.dim_out), rnd(N, ls.gate.irreps_in.dim), rnd(N, ls.gate.irreps_in.dim)
+    xo_r = rnd(N, ls.gate.irreps_out.dim)
     ops = {
         'radial_mlp_hidden_fwd': lambda: lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb), E, _ptr(h2), st),
         f'conv_fwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_fwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
@@ -107,7 +109,11 @@ def main():
         'si1_fwd': lambda: eng._linear(L.si1, h, N, g),
         'sc_fwd': lambda: eng._linear(L.sc, h, N, g),
         'si1_bwd': lambda: eng._linear_T(L.si1, h, N, g),
-        'si2_bwd': lambda: eng._linear_T(L.si2, rnd(N, ls.si2.dim_out), N, g),
+        'si2_bwd': lambda: eng._linear_T(L.si2, gy_r, N, g),
+        'sc_bwd': lambda: eng._linear_T(L.sc, gy_r, N, g),
+        'gate_fwd': lambda: lib.snet_gate_fwd(_ptr(y_r), _ptr(sc_r), _ptr(xo_r), N, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st),
+        'gate_bwd': lambda: lib.snet_gate_bwd_norm(_ptr(y_r), _ptr(xo_r), _ptr(gy_r), N, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), 1.0, _ptr(g_max), st),
+        'row_absmax': lambda: lib.snet_row_absmax(_ptr(h), N, dx, _ptr(x_max), st),
     }
     print(f'lib={_lib.LIB_PATH} N={N} E={E} layer={a.layer} dx={dx} dmid={dmid} wn={wn}')
     todo = []
