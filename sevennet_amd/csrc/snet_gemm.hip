@@ -12,20 +12,32 @@
 #include <cstdlib>
 #include <cstring>
 
-#include <type_traits>
-
 #include "snet_common.h"
 #include "snet_split.h"
 
-#ifndef SNET_GEMM_PIPE
-#define SNET_GEMM_PIPE 0
-#endif
 #ifndef SNET_GEMM_OCC
 #define SNET_GEMM_OCC 4
 #endif
 namespace {
 
 using snet::f32x16;
+
+// Row r of a GEMM is component m of node n (r = n d + m).  A 64-bit division per row costs ~100 instructions, and the
+// epilogue needs 16 of them per lane: the tile's first row is divided once (wave-uniform), every other row of the tile
+// is an offset < 256 from it, divided by a 16-bit reciprocal (exact for (d + 256) d < 65536, i.e. d <= 150).
+struct RowMap {
+  int64_t n0;
+  uint32_t m0, d, inv;
+  __device__ __forceinline__ RowMap(int64_t row0, int d_) : d((uint32_t)d_), inv(65536u / (uint32_t)d_ + 1u) {
+    n0 = row0 / d_;
+    m0 = (uint32_t)(row0 - n0 * d_);
+  }
+  __device__ __forceinline__ void at(int off, int64_t &n, int &m) const {  // row0 + off, 0 <= off < 256
+    const uint32_t x = m0 + (uint32_t)off, q = (x * inv) >> 16;
+    n = n0 + q;
+    m = (int)(x - q * d);
+  }
+};
 
 constexpr int BM = 128;
 constexpr int BK = 32;
@@ -42,6 +54,7 @@ __device__ __forceinline__ void gemm_body(float *As, float *Bs, int bx, int by,
   const int wave = tid >> 6;
   const int64_t row0 = (int64_t)bx * BM;
   const int col0 = by * BN;
+  const RowMap rows(row0, d);
 
   // each thread stages 4 A rows: r = tid/8 + 32*i, k-quad = tid%8
   const int lr = tid >> 3;
@@ -52,9 +65,9 @@ __device__ __forceinline__ void gemm_body(float *As, float *Bs, int bx, int by,
   for (int i = 0; i < 4; ++i) {
     const int64_t r = row0 + lr + 32 * i;
     a_ok[i] = r < n_rows;
-    const int64_t rr = a_ok[i] ? r : 0;
-    const int64_t n = rr / d;
-    const int m = (int)(rr - n * d);
+    int64_t n = 0;
+    int m = 0;
+    if (a_ok[i]) rows.at(lr + 32 * i, n, m);
     const int64_t node = row_idx ? (int64_t)row_idx[n] : n;
     a_ptr[i] = A + node * a_node_stride + a_off + (int64_t)m * K;
   }
@@ -121,8 +134,9 @@ __device__ __forceinline__ void gemm_body(float *As, float *Bs, int bx, int by,
     const int rl = 32 * wave + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
     const int64_t r = row0 + rl;
     if (r >= n_rows) continue;
-    const int64_t n = r / d;
-    const int m = (int)(r - n * d);
+    int64_t n;
+    int m;
+    rows.at(rl, n, m);
     const int64_t node = row_idx ? (int64_t)row_idx[n] : n;
     float *crow = C + node * c_node_stride + c_off + (int64_t)m * N;
 #pragma unroll
@@ -140,6 +154,33 @@ __device__ __forceinline__ void gemm_body(float *As, float *Bs, int bx, int by,
 // Split-precision variant (bf16 x 6 on v_mfma_f32_32x32x16_bf16, snet_split.h): same contraction,
 // weights pre-packed on the host by snet_gemm_split_pack into B fragments
 //     packed[((tile*nq + q)*3 + term)*64 + lane] = 8 bf16 : B[k = 16q + 8(lane>>5) + i][32 tile + (lane&31)]
+template <int NT, int MT>
+__device__ __forceinline__ void gemm_split_store(const snet::f32x16 (&acc)[MT][NT], const RowMap &rows, int64_t row0, int half, int li,
+    int tile0, float *__restrict__ C, int64_t n_rows, int N, int64_t c_node_stride, int64_t c_off,
+    const int32_t *__restrict__ row_idx, int accumulate) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int off = 32 * mt + (j & 3) + 8 * (j >> 2) + 4 * half;
+      const int64_t r = row0 + off;
+      if (r >= n_rows) continue;
+      int64_t n;
+      int m;
+      rows.at(off, n, m);
+      const int64_t node = row_idx ? (int64_t)row_idx[n] : n;
+      float *crow = C + node * c_node_stride + c_off + (int64_t)m * N;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 32 * (tile0 + t) + li;
+        if (col < N) {
+          const float v = acc[mt][t][j];
+          crow[col] = accumulate ? crow[col] + v : v;
+        }
+      }
+    }
+}
+
 // A wave owns MT*32 rows and all NT column tiles of its block: the A fragment (8 consecutive k of
 // one row = 32 B per lane) comes straight from global memory into registers and is split there --
 // A is not shared between waves, so it never visits LDS.  B fragments are shared by the 4 waves:
@@ -155,6 +196,7 @@ __device__ __forceinline__ void gemm_split_body(snet::u32x4 *Bs, int bx, int by,
   const int half = lane >> 5, li = lane & 31;
   const int64_t row0 = ((int64_t)bx * 4 + wave) * (32 * MT);
   const int nq = (K + 15) >> 4, n_tiles = (N + 31) >> 5, tile0 = by * NT;
+  const RowMap rows(row0, d);
 
   const float *a_ptr[MT];
   bool a_ok[MT];
@@ -162,9 +204,9 @@ __device__ __forceinline__ void gemm_split_body(snet::u32x4 *Bs, int bx, int by,
   for (int mt = 0; mt < MT; ++mt) {
     const int64_t r = row0 + 32 * mt + li;
     a_ok[mt] = r < n_rows;
-    const int64_t rr = a_ok[mt] ? r : 0;
-    const int64_t n = rr / d;
-    const int m = (int)(rr - n * d);
+    int64_t n = 0;
+    int m = 0;
+    if (a_ok[mt]) rows.at(32 * mt + li, n, m);
     const int64_t node = row_idx ? (int64_t)row_idx[n] : n;
     a_ptr[mt] = A + node * a_node_stride + a_off + (int64_t)m * K + 8 * half;
   }
@@ -210,45 +252,6 @@ __device__ __forceinline__ void gemm_split_body(snet::u32x4 *Bs, int bx, int by,
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[mt][t] = zero16();
 
-#if SNET_GEMM_PIPE
-  // Both operands run TWO k steps ahead of the MFMAs: the memory counter retires loads in order, so a B slab that is
-  // stored to LDS in the iteration that loaded it exposes the full L2 latency on every k step whatever the A rows do.
-  // Iteration q: issue A(q + 2), B(q + 2); multiply with A(q) (registers) and B(q) (LDS); store B(q + 1), loaded one iteration ago.
-  float ring[2][MT][8];
-  u32x4 stb[2][NST];
-  load_a(0, ring[0]);
-  load_b(0, stb[0]);
-  if (nq > 1) {
-    load_a(1, ring[1]);
-    load_b(1, stb[1]);
-  }
-  store_b(0, stb[0]);
-  __syncthreads();
-  auto step = [&](int q, auto J) {
-    constexpr int jj = decltype(J)::value;
-    Split3 a[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = split8(ring[jj][mt]);
-    if (q + 2 < nq) {
-      load_a(q + 2, ring[jj]);
-      load_b(q + 2, stb[jj]);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      bf16x8 b[3];
-#pragma unroll
-      for (int term = 0; term < 3; ++term) b[term] = as_bf16x8(Bs[jj * SLAB + (t * 3 + term) * 64 + lane]);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][t] = mfma6(a[mt], b, acc[mt][t]);
-    }
-    if (q + 1 < nq) store_b(jj ^ 1, stb[jj ^ 1]);
-    __syncthreads();
-  };
-  for (int q = 0; q < nq; q += 2) {
-    step(q, std::integral_constant<int, 0>{});
-    if (q + 1 < nq) step(q + 1, std::integral_constant<int, 1>{});
-  }
-#else
   float av[MT][8], an[MT][8];
   u32x4 st[NST];
   load_a(0, av);
@@ -284,28 +287,9 @@ __device__ __forceinline__ void gemm_split_body(snet::u32x4 *Bs, int bx, int by,
     buf ^= 1;
   }
 
-#endif
-
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int64_t r = row0 + 32 * mt + (j & 3) + 8 * (j >> 2) + 4 * half;
-      if (r >= n_rows) continue;
-      const int64_t n = r / d;
-      const int m = (int)(r - n * d);
-      const int64_t node = row_idx ? (int64_t)row_idx[n] : n;
-      float *crow = C + node * c_node_stride + c_off + (int64_t)m * N;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int col = 32 * (tile0 + t) + li;
-        if (col < N) {
-          const float v = acc[mt][t][j];
-          crow[col] = accumulate ? crow[col] + v : v;
-        }
-      }
-    }
+  gemm_split_store<NT, MT>(acc, rows, row0, half, li, tile0, C, n_rows, N, c_node_stride, c_off, row_idx, accumulate);
 }
+
 
 template <int NT>
 __global__ __launch_bounds__(256) void gemm_kernel(
@@ -441,7 +425,7 @@ extern "C" int snet_gemm_grouped(const snet_gemm_desc *descs_host, int32_t n_des
   int64_t total = 0;
   for (int i = 0; i < n_desc; ++i) {
     const snet_gemm_desc &p = descs_host[i];
-    SNET_REQUIRE(p.d >= 1 && p.K >= 1 && p.N >= 1 && (p.B != nullptr || p.B_split != nullptr),
+    SNET_REQUIRE(p.d >= 1 && p.d <= 150 && p.K >= 1 && p.N >= 1 && (p.B != nullptr || p.B_split != nullptr),
                  "snet_gemm_grouped: bad problem");
     const int bn = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
     const int64_t nbx = (n_nodes * p.d + bm - 1) / bm;
@@ -468,7 +452,7 @@ extern "C" int snet_gemm_grouped(const snet_gemm_desc *descs_host, int32_t n_des
 extern "C" int snet_gemm(const float *A, const float *B, float *C, int64_t n_nodes, int32_t d, int32_t K,
                          int32_t N, int64_t a_node_stride, int64_t a_off, int64_t c_node_stride, int64_t c_off,
                          const int32_t *row_idx, int32_t accumulate, void *stream) {
-  SNET_REQUIRE(d >= 1 && K >= 1 && N >= 1, "snet_gemm: bad shape");
+  SNET_REQUIRE(d >= 1 && d <= 150 && K >= 1 && N >= 1, "snet_gemm: bad shape (1 <= d <= 150)");
   if (n_nodes <= 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t n_rows = n_nodes * d;
