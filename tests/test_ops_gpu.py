@@ -749,3 +749,59 @@ def test_edge_vectors_from_positions():
     assert (out.cpu() == want).float().mean() > 0.99
     naive = (pd.float()[s_.long()] - pd.float()[c.long()] + sd.float()).cpu()
     assert (naive - want).abs().max() > 3e-6                      # what the fp64 subtraction avoids
+
+
+def test_edges_by_source_and_transposed_scalar_convolution():
+    """snet_edges_by_source (destination atom / radial row of every edge in source-grouped order) and the last layer's
+    source-row gradient as a forward convolution of the transposed product (snet_conv_plan_transposed):
+    == g_xe rows of the fused reverse kernel summed per source atom, ragged degrees and atoms without edges included"""
+    L, lib = _lib()
+    dev = 'cuda:0'
+    from sevennet_amd.engine import build_graph
+    from sevennet_amd.model_spec import build_model_spec, transposed_scalar_conv
+    from sevennet_amd.model_spec import sevennet_0_config
+    from sevennet_amd.neighbor import diamond_cubic, neighbor_list
+    pos, cell = diamond_cubic(5.431, (3, 2, 2), 0.07, 3)
+    ei, ev, _ = neighbor_list(pos, cell, [True] * 3, 4.4)
+    keep = np.ones(ei.shape[1], bool)
+    keep[(ei[0] == 5) | (ei[1] == 7)] = False   # an atom without in-edges, one that is nobody's source
+    keep[::11] = False                          # ragged degrees, one-directional pairs
+    ei, ev = ei[:, keep], ev[keep]
+    g = build_graph(np.zeros(len(pos), np.int64), ei, ev, device=dev, share_pairs=False)
+    E, N = g.n_edges, g.n_local
+    ct, wt = torch.empty_like(g.eperm), torch.empty_like(g.eperm)
+    L.check(lib.snet_edges_by_source(_p(g.row_ptr), N, _p(g.eperm), None, E, _p(ct), _p(wt), None))
+    torch.cuda.synchronize()
+    assert torch.equal(ct, g.center[g.eperm.long()]) and torch.equal(wt, g.eperm)
+    w_row = torch.randint(0, E, (E,), device=dev, dtype=torch.int32)
+    L.check(lib.snet_edges_by_source(_p(g.row_ptr), N, _p(g.eperm), _p(w_row), E, _p(ct), _p(wt), None))
+    torch.cuda.synchronize()
+    assert torch.equal(wt, w_row[g.eperm.long()])
+    # the transposed shape of SevenNet-0's last layer reproduces sum_e w_e T Y_e g_out[center(e)] per source atom
+    conv = build_model_spec(sevennet_0_config()).layers[-1].conv
+    spec_t, kappa = transposed_scalar_conv(conv)
+    tag = C.create_string_buffer(13)
+    plan, plan_t = C.c_void_p(), C.c_void_p()
+    L.check(lib.snet_conv_plan_create(conv.tag.encode(), C.byref(plan)))
+    col = np.zeros(conv.weight_numel, np.float32)
+    L.check(lib.snet_conv_plan_transposed(plan, tag, col.ctypes.data_as(C.c_void_p), None, 0, None))
+    assert tag.value.decode() == spec_t.tag
+    L.check(lib.snet_conv_plan_create(spec_t.tag.encode(), C.byref(plan_t)))
+    dx, dout, wn, nsh = conv.irreps_x.dim, conv.irreps_out.dim, conv.weight_numel, conv.irreps_sh.dim
+    gen = torch.Generator(device='cpu').manual_seed(5)
+    x, g_out = torch.randn(N, dx, generator=gen).to(dev), torch.randn(N, dout, generator=gen).to(dev)
+    sh, w = torch.randn(E, nsh, generator=gen).to(dev), torch.randn(E, wn, generator=gen).to(dev)
+    dsh = torch.zeros(E, nsh, 3, device=dev)
+    g_w, g_xe, g_vec = torch.empty(E, wn, device=dev), torch.empty(E, dx, device=dev), torch.zeros(E, 3, device=dev)
+    L.check(lib.snet_conv_bwd_edge_vec(plan, _p(x), _p(sh), _p(dsh), _p(w), None, _p(g.row_ptr), _p(g.src), N, 0.25, _p(g_out),
+                                       _p(g_w), _p(g_xe), _p(g_vec), None))
+    want = torch.zeros(N, dx, device=dev).index_add_(0, g.src.long(), g_xe)
+    ep = g.eperm.long()
+    sh_t, w_t = sh[ep].contiguous(), (w * torch.from_numpy(col).to(dev))[ep].contiguous()
+    got = torch.zeros(N, dx, device=dev)
+    L.check(lib.snet_conv_fwd(plan_t, _p(g_out), _p(sh_t), _p(w_t), None, _p(g.col_ptr), _p(ct), N, 0.25, _p(got), None))
+    torch.cuda.synchronize()
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    assert want[7].abs().max().item() == 0.0 and got[7].abs().max().item() == 0.0
+    lib.snet_conv_plan_destroy(plan)
+    lib.snet_conv_plan_destroy(plan_t)
