@@ -67,8 +67,9 @@ def schedule_bwd(spec: ConvSpec):
     the wave's 32-row LDS buffer).  Stream order: for x block: for
     block: for sub-step.  SNET_CODEGEN_OPTS=nopairct=1 keeps U = 1 everywhere (the round-2 schedule)."""
     out, cols = [], []
-    # first interaction layer (one x block, 8-wave workgroups at <= 128 VGPRs): two-tile blocks push it past 128 registers
-    # and halve its occupancy (measured 1.70 -> 2.36 ms): it keeps one channel tile per block
+    # first interaction layer of an lmax-2 model (one x block, three paths): it keeps one channel tile per block.  Two-tile
+    # blocks push its 8-wave configuration past 128 registers (2.46 ms against 2.06 stand-alone); in 4-wave workgroups they
+    # win stand-alone (1.83 ms) but not inside the step with the hidden-layer tail (1.77 against 1.72 ms)
     n_cats = sum(1 for i in range(len(spec.irreps_x)) if _Cat(spec, i, 0).paths)
     for i in range(len(spec.irreps_x)):
         cat = _Cat(spec, i, 0)
@@ -1140,8 +1141,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         # global->LDS staging) where the LDS and the register count of this nt allow it, 8 or 4 waves otherwise
         if 'fnwvf' in OPTS:
             return def_f
-        if len(cats) == 1 and fwd_lds(nt, 8) <= 80 * 1024:   # first layer (scalar inputs only): 0.87 vs 1.03 ms
-            return (8, 1, 2)
+        if len(cats) == 1 and fwd_lds(nt, 8) <= 80 * 1024:   # first layer (scalar inputs only): 0.87 vs 1.03 ms at 12 waves;
+            return (8, 0, 2)                                   # slabs staged through registers: 0.85 vs 1.00 ms direct
         if nt <= 2 and fwd_lds(nt, 12) <= 160 * 1024:
             return (12, 0 if OPTS.get('f12reg') else 1, 3)
         for w in (8, 4, 2, 1):
