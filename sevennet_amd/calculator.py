@@ -123,7 +123,7 @@ def fix_old_convolution_signs(cfg: dict, sd: dict, strict_reference: bool = Fals
         flipped = {}
         ww_key = f'{ls.t}_convolution.weight_nn.layer{len(ls.mlp_dims) - 2}.weight'
         ww = None
-        for p in ls.conv.paths:
+        for p in ls.conv_full.paths:   # the checkpoint's column layout (the engine may have pruned unread paths)
             if not (p.l1 > 0 and p.l2 > 0 and p.l3 > 0):
                 continue
             key = W3J_KEY.format(t=ls.t, l1=p.l1, l2=p.l2, l3=p.l3)

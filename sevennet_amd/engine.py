@@ -332,8 +332,9 @@ class HipForceEngine:
                 L.si1 = _Linear(ls.si1, sd[ls.si1.name], self.dev, split, mi)
                 L.si2 = _Linear(ls.si2, sd[ls.si2.name], self.dev, split, mi)
                 L.mlp_w, L.mlp_wt = [], []
+                rw = ls.radial_weights(sd)   # last layer restricted to the live paths' columns
                 for i in range(len(ls.mlp_dims) - 1):
-                    w = sd[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] / np.sqrt(ls.mlp_dims[i])
+                    w = rw[i] / np.sqrt(ls.mlp_dims[i])
                     L.mlp_w.append(torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(self.dev))
                     L.mlp_wt.append(torch.from_numpy(np.ascontiguousarray(w.T, dtype=np.float32)).to(self.dev))
                 L.fused_mlp = (len(ls.mlp_dims) == 4 and ls.mlp_dims[1] == 64 and ls.mlp_dims[2] == 64
@@ -341,8 +342,7 @@ class HipForceEngine:
                 L.mlp_plan = None
                 if L.fused_mlp:
                     d = ls.mlp_dims
-                    hw = [np.ascontiguousarray(sd[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] / np.sqrt(d[i]),
-                                               dtype=np.float32) for i in range(3)]
+                    hw = [np.ascontiguousarray(rw[i] / np.sqrt(d[i]), dtype=np.float32) for i in range(3)]
                     fp = [w.ctypes.data_as(C.POINTER(C.c_float)) for w in hw]
                     mp = C.c_void_p()
                     _lib.check(self.lib.snet_radial_mlp_plan_create(d[0], d[1], d[2], d[3], fp[0], fp[1], fp[2],

@@ -120,8 +120,9 @@ def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray],
         out.append(ls.conv.tag.encode()[:12].ljust(12, b'\0'))
         out.append(_f(1.0 / float(sd[f'{ls.t}_convolution.denominator'][0])))
         out.append(_i(*d))
+        rw = ls.radial_weights(sd)   # the last layer's columns of paths nothing reads are not stored
         for i in range(3):
-            out.append(_arr(sd[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] / np.sqrt(d[i])))
+            out.append(_arr(rw[i] / np.sqrt(d[i])))
         out.append(_write_linear(ls.sc, sd[ls.sc.name] if ls.sc is not None else None))
         out.append(_write_linear(ls.si1, sd[ls.si1.name], mi))
         out.append(_write_linear(ls.si2, sd[ls.si2.name], mi))

@@ -306,11 +306,55 @@ class LayerSpec:
     irreps_out: Irreps
     sc: Optional[LinearSpec]
     si1: LinearSpec
-    conv: ConvSpec
-    mlp_dims: List[int]
+    conv: ConvSpec            # what the engine evaluates: the reference's paths minus those whose output nothing reads
+    mlp_dims: List[int]       # radial MLP widths of `conv` (last = conv.weight_numel)
     si2: LinearSpec
     gate: GateSpec
     denominator: float
+    conv_full: Optional[ConvSpec] = None     # the reference's instruction list (checkpoint layout of the last MLP layer)
+    mlp_dims_full: Optional[List[int]] = None
+    w_cols: Optional[np.ndarray] = None      # columns of the checkpoint's last radial layer that `conv` keeps (None: all)
+
+    def __post_init__(self):
+        if self.conv_full is None:
+            self.conv_full = self.conv
+        if self.mlp_dims_full is None:
+            self.mlp_dims_full = list(self.mlp_dims)
+
+    def radial_weights(self, sd) -> List[np.ndarray]:
+        """[W0, W1, ...] of this layer's radial MLP as stored (no 1/sqrt(fan_in)), the last one restricted to the live paths"""
+        n = len(self.mlp_dims) - 1
+        ws = [np.asarray(sd[f'{self.t}_convolution.weight_nn.layer{i}.weight']) for i in range(n)]
+        if self.w_cols is not None:
+            ws[-1] = ws[-1][:, self.w_cols]
+        return ws
+
+
+def prune_unread_paths(conv: ConvSpec, si2: LinearSpec):
+    """Drop the tensor-product paths whose output block no block of the following linear reads (`o3.Linear` ignores input
+    irreps it has no output for: SURVEY.md section 8 table note -- the third interaction layer of SevenNet-MF-ompa computes
+    0o, 1e, 2o, 3e blocks that its SI2 discards: 34 of its 68 paths, half of its radial weights).  The output layout is
+    kept (the unread columns are simply never written), so everything downstream is unchanged and results are identical.
+    Returns (pruned ConvSpec, kept weight columns) or (conv, None)."""
+    offs = si2.irreps_in.offsets()
+    read = {b.in_off for b in si2.blocks}
+    ends = [off + mul * (2 * l + 1) for off, (mul, l, _) in zip(offs, si2.irreps_in)]
+
+    def block_of(off):
+        for o, e in zip(offs, ends):
+            if o <= off < e:
+                return o
+        raise AssertionError(off)
+    keep = [k for k, p in enumerate(conv.paths) if block_of(p.out_off) in read]
+    if len(keep) == len(conv.paths) or not keep:
+        return conv, None
+    paths, cols, w = [], [], 0
+    for k in keep:
+        p = conv.paths[k]
+        paths.append(ConvPath(p.i_x, p.i_sh, p.l1, p.l2, p.l3, p.mul, w, p.x_off, p.sh_off, p.out_off, p.out_mul, p.out_ch))
+        cols.extend(range(p.w_off, p.w_off + p.mul))
+        w += p.mul
+    return ConvSpec(conv.irreps_x, conv.irreps_sh, conv.irreps_mid, conv.irreps_out, paths, w), np.asarray(cols, np.int64)
 
 
 @dataclass
@@ -342,8 +386,8 @@ class ModelSpec:
                 s[ls.sc.name] = (ls.sc.numel,)
             s[ls.si1.name] = (ls.si1.numel,)
             s[f'{ls.t}_convolution.denominator'] = (1,)
-            for i in range(len(ls.mlp_dims) - 1):
-                s[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] = (ls.mlp_dims[i], ls.mlp_dims[i + 1])
+            for i in range(len(ls.mlp_dims_full) - 1):
+                s[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] = (ls.mlp_dims_full[i], ls.mlp_dims_full[i + 1])
             s[ls.si2.name] = (ls.si2.numel,)
         s[self.readout1.name] = (self.readout1.numel,)
         s[self.readout2.name] = (self.readout2.numel,)
@@ -478,12 +522,13 @@ def build_model_spec(config: dict) -> ModelSpec:
             sc = None
         else:
             raise ValueError(f'Unknown self_connection_type found: {sc_types[t]}')
+        si2 = make_linear(f'{t}_self_interaction_2.linear.weight', irreps_out_tp, gate.irreps_in, n_modal=m_si2)
+        live, w_cols = prune_unread_paths(conv, si2) if cfg.get('_prune_unread_paths', True) else (conv, None)
         layers.append(LayerSpec(
             t, irreps_x, irreps_out, sc,
             make_linear(f'{t}_self_interaction_1.linear.weight', irreps_x, irreps_x, n_modal=m_si1),
-            conv, [n_basis] + hidden + [conv.weight_numel],
-            make_linear(f'{t}_self_interaction_2.linear.weight', irreps_out_tp, gate.irreps_in, n_modal=m_si2),
-            gate, float(denom[t])))
+            live, [n_basis] + hidden + [live.weight_numel], si2, gate, float(denom[t]),
+            conv_full=conv, mlp_dims_full=[n_basis] + hidden + [conv.weight_numel], w_cols=w_cols))
         irreps_x = irreps_out
     hid = Irreps([((ch if legacy else irreps_x.dim) // 2, 0, 1)])
     tm = cfg.get('_type_map') or {}

@@ -62,7 +62,19 @@ def _compare(eng, out, ref, n, rel=3e-5, check_inter=True, e_unit=1.0):
             for key, irr in ((f'{t}_si1', ls.si1.irreps_out), (f'{t}_conv', ls.conv.irreps_out),
                              (f'{t}_gate_in', ls.gate.irreps_in), (f'{t}_x', ls.gate.irreps_out)):
                 downstream = t > first or (t == first and not key.endswith('_si1'))
-                _close(irmul_to_mulir(out['inter'][key], irr), ref['inter'][key], 4e-5 if downstream else 1e-5, 1e-9, key)
+                got, want = irmul_to_mulir(out['inter'][key], irr), ref['inter'][key]
+                if key.endswith('_conv') and ls.w_cols is not None:
+                    # the engine does not evaluate paths whose output block the following linear ignores
+                    # (model_spec.prune_unread_paths): those columns of its buffer are never written
+                    live = torch.zeros(1, irr.dim)
+                    for p in ls.conv.paths:
+                        for m3 in range(2 * p.l3 + 1):
+                            live[0, p.out_off + m3 * p.out_mul + p.out_ch:p.out_off + m3 * p.out_mul + p.out_ch + p.mul] = 1.0
+                    live = irmul_to_mulir(live, irr)[0] > 0
+                    assert 0 < int(live.sum()) < irr.dim
+                    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
+                    got, want = got[:, live], want[:, live]
+                _close(got, want, 4e-5 if downstream else 1e-5, 1e-9, key)
 
 
 @pytest.mark.parametrize('name', ['hfo2_12', 'hfo_rs64', 'hfo2_96'])

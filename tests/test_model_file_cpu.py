@@ -189,3 +189,40 @@ def test_species_wise_rescale_checkpoint_with_scalar_config():
         build_model_spec(unit_test_config(act_radial='relu'))
     with pytest.raises(NotImplementedError, match='cutoff function'):
         build_model_spec(unit_test_config(cutoff_function={'cutoff_function_name': 'cosine'}))
+
+
+def test_paths_nothing_reads_are_not_evaluated():
+    """SevenNet-MF-ompa's third interaction layer computes 0o / 1e / 2o / 3e blocks that its SI2 (an o3.Linear: unmatched
+    input irreps are ignored) never reads: the engine's shape keeps the 34 paths that are read, the checkpoint layout
+    (parameter shapes, old-checkpoint sign fix) keeps all 68"""
+    from sevennet_amd.model_spec import (build_model_spec, sevennet_0_config, sevennet_l3i5_config,
+                                         sevennet_mf_ompa_config)
+    cfg = sevennet_mf_ompa_config()
+    sp = build_model_spec(cfg)
+    ls = sp.layers[3]
+    assert (len(ls.conv_full.paths), len(ls.conv.paths)) == (68, 34)
+    assert (ls.conv_full.weight_numel, ls.conv.weight_numel, len(ls.w_cols)) == (3520, 1760, 1760)
+    assert sp.param_shapes()['3_convolution.weight_nn.layer2.weight'] == (64, 3520)
+    read = {b.in_off for b in ls.si2.blocks}
+    offs = ls.si2.irreps_in.offsets()
+    blocks = [(o, o + m * (2 * l + 1)) for o, (m, l, _) in zip(offs, ls.si2.irreps_in)]
+    block_of = lambda off: next(o for o, e in blocks if o <= off < e)   # noqa: E731
+    kept = {(p.i_x, p.i_sh, p.out_off, p.out_ch) for p in ls.conv.paths}
+    col = 0
+    for p in ls.conv_full.paths:
+        live = block_of(p.out_off) in read
+        assert ((p.i_x, p.i_sh, p.out_off, p.out_ch) in kept) == live
+        if live:   # weight columns of the kept paths, in order
+            assert list(ls.w_cols[col:col + p.mul]) == list(range(p.w_off, p.w_off + p.mul))
+            col += p.mul
+    sd = {f'3_convolution.weight_nn.layer{i}.weight': np.arange(a * b, dtype=np.float64).reshape(a, b)
+          for i, (a, b) in enumerate(zip(ls.mlp_dims_full[:-1], ls.mlp_dims_full[1:]))}
+    w = ls.radial_weights(sd)
+    assert w[2].shape == (64, 1760) and np.array_equal(w[2], sd['3_convolution.weight_nn.layer2.weight'][:, ls.w_cols])
+    # every other layer of the three benchmark shapes reads all it computes; the switch restores the reference's list
+    for c in (sevennet_0_config(), sevennet_l3i5_config(), cfg):
+        for l2 in build_model_spec(c).layers:
+            assert (l2.w_cols is None) == (len(l2.conv.paths) == len(l2.conv_full.paths))
+            assert l2.w_cols is None or (c is cfg and l2.t == 3)
+    full = build_model_spec(dict(cfg, _prune_unread_paths=False)).layers[3]
+    assert len(full.conv.paths) == 68 and full.w_cols is None
