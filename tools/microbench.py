@@ -110,6 +110,11 @@ def main():
         'sc_fwd': lambda: eng._linear(L.sc, h, N, g),
         'si1_bwd': lambda: eng._linear_T(L.si1, h, N, g),
         'si2_bwd': lambda: eng._linear_T(L.si2, gy_r, N, g),
+        # the same launches with every node reading / writing row 0 (strides 0): what the kernel costs without its HBM streams
+        'si2_fwd_rows_aliased': lambda: eng._run_groups(L.si2.groups_fwd, m, y_r, N, 0, 0, g),
+        'si2_fwd_A_aliased': lambda: eng._run_groups(L.si2.groups_fwd, m, y_r, N, 0, ls.si2.dim_out, g),
+        'si2_bwd_rows_aliased': lambda: eng._run_groups(L.si2.groups_T, gy_r, m, N, 0, 0, g),
+        'si1_fwd_rows_aliased': lambda: eng._run_groups(L.si1.groups_fwd, h, g_h, N, 0, 0, g),
         'sc_bwd': lambda: eng._linear_T(L.sc, gy_r, N, g),
         'gate_fwd': lambda: lib.snet_gate_fwd(_ptr(y_r), _ptr(sc_r), _ptr(xo_r), N, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st),
         'gate_bwd': lambda: lib.snet_gate_bwd_norm(_ptr(y_r), _ptr(xo_r), _ptr(gy_r), N, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), 1.0, _ptr(g_max), st),
