@@ -58,6 +58,10 @@ SIGNATURES = {
                                     c_i32p, c_stream]),
     'snet_gemm_split_size': (C.c_int64, [C.c_int32, C.c_int32]),
     'snet_gemm_split_pack': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    'snet_gemm_f16_size': (C.c_int64, [C.c_int32, C.c_int32]),
+    'snet_gemm_f16_pack': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
+    'snet_gemm_grouped_f16': (C.c_int, [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.c_int32, c_f32p, c_f32p, C.c_int64, C.c_int64,
+                                        C.c_int64, c_i32p, c_f32p, C.c_float, c_stream]),
     'snet_act_fwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_stream]),
     'snet_act_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_stream]),
     'snet_conv_plan_create': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),

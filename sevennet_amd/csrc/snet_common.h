@@ -121,6 +121,12 @@ constexpr int FUSED_TAIL_FRAGS = 22;  // z1 (4) + z2 (8) + g_a1 (8) + g_emb (2) 
 int pack_fused_slabs(const float *w2, int wn, int n_sub, const int32_t *sub_cols, int mode, const MlpHidden *tail,
                      void **dev_out, int32_t (&exps)[3]);
 
+// host-side fp16 helpers of the two-term ("f16x3") operand formats (snet_mlp.hip): round-to-nearest-even conversion with
+// subnormals, its inverse, and the exponent k that puts max |v| 2^k into [2^13, 2^14)
+uint16_t f16_rne(float f);
+float f16_f(uint16_t h);
+int f16_scale_exp(const float *v, size_t n);
+
 struct ConvRegistrar {
   explicit ConvRegistrar(const ConvKernels *k) { register_conv(k); }
 };

@@ -818,7 +818,7 @@ MlpHidden mlp_plan_hidden(const snet_mlp_plan *plan) {
   return h;
 }
 // fp32 -> fp16 bits, round-to-nearest-even, subnormals kept (what v_cvt_pk_f16_f32 does on the device)
-static uint16_t f16_rne(float f) {
+uint16_t f16_rne(float f) {
   uint32_t u;
   std::memcpy(&u, &f, 4);
   const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
@@ -835,7 +835,7 @@ static uint16_t f16_rne(float f) {
   const uint32_t r = a + 0xfffu + ((a >> 13) & 1);              // normal: round the 13 dropped bits
   return sign | (uint16_t)((r - 0x38000000u) >> 13);
 }
-static float f16_f(uint16_t h) {
+float f16_f(uint16_t h) {
   const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31, m = h & 0x3ffu;
   float f;
   if (e == 0) {
@@ -847,7 +847,7 @@ static float f16_f(uint16_t h) {
   return sign ? -f : f;
 }
 // k with max |v| * 2^k in [2^13, 2^14) (what the kernels' bound_exp / F16_TOP produce for dynamic operands)
-static int f16_scale_exp(const float *v, size_t n) {
+int f16_scale_exp(const float *v, size_t n) {
   float m = 0.f;
   for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(v[i]));
   if (!(m > 0.f) || !std::isfinite(m)) return 0;

@@ -39,7 +39,9 @@ def main():
     from sevennet_amd.neighbor import diamond_cubic, neighbor_list
     from sevennet_amd.synthetic import random_state_dict
     cfg = model_config(a.model)
-    eng = HipForceEngine(cfg, random_state_dict(cfg, 0), mlp_mode=a.mlp_mode, fused_terms=a.terms)
+    eng_sd = random_state_dict(cfg, 0)
+    eng_sd = {k: (v.detach().cpu().numpy() if hasattr(v, 'detach') else np.asarray(v)) for k, v in eng_sd.items()}
+    eng = HipForceEngine(cfg, eng_sd, mlp_mode=a.mlp_mode, fused_terms=a.terms)
     lib = eng.lib
     pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
     if a.order == 'random':
@@ -91,6 +93,36 @@ def main():
     x_max, g_max = h.abs().amax(1).contiguous(), g_m.abs().amax(1).contiguous()   # bounds of the fp16-operand mode
     gy_r, y_r, sc_r = rnd(N, ls.si2.dim_out), rnd(N, ls.gate.irreps_in.dim), rnd(N, ls.gate.irreps_in.dim)
     xo_r = rnd(N, ls.gate.irreps_out.dim)
+    from sevennet_amd.model_spec import linear_weight_matrices
+    rb16 = torch.full((N,), 40.0, device=dev)   # |randn| < 6, so any row's norm bound
+    packs16 = {}
+
+    def run16(lin, transpose, A_, C_, a_stride, c_stride):
+        """the linear's per-irrep GEMMs as ONE snet_gemm_grouped_f16 launch (timing only: blocks that share an output would
+        need the accumulate flags of _Linear._plan)"""
+        key = (id(lin), transpose)
+        if key not in packs16:
+            sd_w = eng_sd[lin.spec.name]
+            mats = linear_weight_matrices(lin.spec, sd_w)
+            descs, exps, keep = [], [], []
+            for b, mt in zip(lin.spec.blocks, mats):
+                Bm = np.ascontiguousarray(mt.T if transpose else mt, np.float32)
+                K_, N_ = Bm.shape
+                buf = np.empty(int(lib.snet_gemm_f16_size(K_, N_)), np.uint8)
+                e_ = C.c_int32()
+                _lib.check(lib.snet_gemm_f16_pack(Bm.ctypes.data_as(C.c_void_p), K_, N_, buf.ctypes.data_as(C.c_void_p), C.byref(e_)))
+                t_ = torch.from_numpy(buf).to(dev)
+                keep.append(t_)
+                a_off, c_off = (b.out_off, b.in_off) if transpose else (b.in_off, b.out_off)
+                descs.append(_lib.GemmDesc(None, t_.data_ptr(), a_off, c_off, 2 * b.l + 1, K_, N_, 0))
+                exps.append(e_.value)
+            packs16[key] = ((_lib.GemmDesc * len(descs))(*descs), (C.c_int32 * len(exps))(*exps), len(descs), keep)
+        d_, e_, n_, _ = packs16[key]
+        for i0 in range(0, n_, 8):
+            cnt = min(8, n_ - i0)
+            sub_d = (_lib.GemmDesc * cnt)(*[d_[i] for i in range(i0, i0 + cnt)])
+            sub_e = (C.c_int32 * cnt)(*[e_[i] for i in range(i0, i0 + cnt)])
+            _lib.check(lib.snet_gemm_grouped_f16(sub_d, sub_e, cnt, _ptr(A_), _ptr(C_), N, a_stride, c_stride, None, _ptr(rb16), 1.0, st))
     ops = {
         'radial_mlp_hidden_fwd': lambda: lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb), E, _ptr(h2), st),
         f'conv_fwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_fwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
@@ -110,6 +142,10 @@ def main():
         'sc_fwd': lambda: eng._linear(L.sc, h, N, g),
         'si1_bwd': lambda: eng._linear_T(L.si1, h, N, g),
         'si2_bwd': lambda: eng._linear_T(L.si2, gy_r, N, g),
+        'si2_bwd_f16x3': lambda: run16(L.si2, True, gy_r, m, ls.si2.dim_out, ls.si2.dim_in),
+        'sc_bwd_f16x3': lambda: run16(L.sc, True, gy_r, g_h, ls.sc.dim_out, ls.sc.dim_in),
+        'si2_fwd_f16x3': lambda: run16(L.si2, False, m, y_r, ls.si2.dim_in, ls.si2.dim_out),
+        'si1_fwd_f16x3': lambda: run16(L.si1, False, h, g_h, ls.si1.dim_in, ls.si1.dim_out),
         # the same launches with every node reading / writing row 0 (strides 0): what the kernel costs without its HBM streams
         'si2_fwd_rows_aliased': lambda: eng._run_groups(L.si2.groups_fwd, m, y_r, N, 0, 0, g),
         'si2_fwd_A_aliased': lambda: eng._run_groups(L.si2.groups_fwd, m, y_r, N, 0, ls.si2.dim_out, g),
