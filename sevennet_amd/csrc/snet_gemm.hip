@@ -362,7 +362,6 @@ __global__ __launch_bounds__(256, MT == 1 ? SNET_GEMM_OCC : 2) void gemm_split_g
                            row_idx, P.accumulate);
 }
 
-
 // ---------------------------------------------------------------------------------------------
 // Two-fp16-term variant ("f16x3": hi*lo + lo*hi + hi*hi on v_mfma_f32_32x32x16_f16, snet_split.h): three products and a
 // two-term split per k step instead of six and three -- the bf16 x 6 kernel is bound by exactly that instruction stream
