@@ -338,7 +338,7 @@ __device__ __forceinline__ void hidden_forward_split(const float *__restrict__ e
   for (int q = 0; q < 4; ++q) {
     float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = snet::act_fwd(z1[q >> 1][8 * (q & 1) + i], act) * cst;
+    for (int i = 0; i < 8; ++i) v[i] = snet::act_fwd_fast(z1[q >> 1][8 * (q & 1) + i], act) * cst;
     const Split3 b = split8(v);
 #pragma unroll
     for (int to = 0; to < 2; ++to) {
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_kernel(const floa
   for (int q = 0; q < 4; ++q) {
     float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = snet::act_fwd(z2[q >> 1][8 * (q & 1) + i], act) * cst;
+    for (int i = 0; i < 8; ++i) v[i] = snet::act_fwd_fast(z2[q >> 1][8 * (q & 1) + i], act) * cst;
     a2[q] = split8(v);
   }
   int buf = 0;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_hidden_split_kernel(const f
     for (int g = 0; g < 4; ++g) {
       f32x4 v;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = snet::act_fwd(z2[t][4 * g + i], act) * cst;
+      for (int i = 0; i < 4; ++i) v[i] = snet::act_fwd_fast(z2[t][4 * g + i], act) * cst;
       *reinterpret_cast<f32x4 *>(h2 + e_lane * H + 32 * t + 8 * g + 4 * half) = v;
     }
 }
