@@ -229,3 +229,13 @@ def test_two_fp16_term_weight_packing_reconstructs_the_matrix():
         want[:K, :N] = B.astype(np.float64) * 2.0 ** e.value
         assert np.abs(rec - want).max() <= 2.0 ** -22 * 2.0 ** 14
         assert np.all(rec[K:] == 0) and np.all(rec[:, N:] == 0)
+
+
+def test_row_map_reciprocal_is_exact_in_its_stated_range():
+    """csrc/snet_gemm.hip::RowMap divides (m0 + off) by d with a 16-bit reciprocal, m0 < d, off < 256, and the entry points
+    refuse d > 150: the identity ((x * (65536 / d + 1)) >> 16) == x / d must hold for every such x"""
+    src = open(os.path.join(ROOT, 'sevennet_amd', 'csrc', 'snet_gemm.hip')).read()
+    assert 'inv(65536u / (uint32_t)d_ + 1u)' in src and '(x * inv) >> 16' in src and 'p.d <= 150' in src and 'd <= 150' in src
+    for d in range(1, 151):
+        inv = 65536 // d + 1
+        assert all(((x * inv) >> 16) == x // d for x in range(d + 256)), d
