@@ -313,6 +313,18 @@ int snet_permute_cols(const float *x, const int32_t *col_idx, float *out, int64_
 int snet_rescale_reduce(const float *e_scaled, const int32_t *types, const float *scale, const float *shift,
                         int32_t n_scale, int64_t n_nodes, float *e_atom, double *energy, void *stream);
 
+/* Folded readout (a3 + a7 + a8 in one pass): the reference's two readout linears (reduce_input_to_hidden,
+ * reduce_hidden_to_energy; sevenn/model_build.py, nn/linear.py:94-100) have no nonlinearity between them, so
+ * a host may fold them to one vector v[dim] and constant c (fp64, at load time).  For the first n rows:
+ * e_atom[i] = (x[i] . v + c) * scale[t] + shift[t] with the dot product and the rescale in fp64,
+ * *energy (device double) = their deterministic fp64 sum.  v is a DEVICE pointer to doubles.  */
+int snet_readout_energy(const float *x, int64_t n_nodes, int32_t dim, const double *v, double c, const int32_t *types,
+                        const float *scale, const float *shift, int32_t n_scale, float *e_atom, double *energy,
+                        void *stream);
+/* its reverse: g_x[i, k] = scale[type_i] * v[k]  (dE/dx of the folded readout)  */
+int snet_readout_grad(const double *v, int32_t dim, const int32_t *types, const float *scale, int32_t n_scale,
+                      int64_t n_nodes, float *g_x, void *stream);
+
 /* ---- a9/a11: forces and virial from dE/d edge_vec --------------------------
  * replaces ForceStressOutputFromEdge.forward force_output.py:189-228 and the
  * host loops of pair_e3gnn.cpp:210-270.  Over n_nodes rows (locals + ghosts):

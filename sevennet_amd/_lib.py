@@ -107,6 +107,9 @@ SIGNATURES = {
     'snet_permute_cols': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
     'snet_rescale_reduce': (C.c_int, [c_f32p, c_i32p, c_f32p, c_f32p, C.c_int32, C.c_int64, c_f32p, c_f64p,
                                       c_stream]),
+    'snet_readout_energy': (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f64p, C.c_double, c_i32p, c_f32p, c_f32p, C.c_int32,
+                                      c_f32p, c_f64p, c_stream]),
+    'snet_readout_grad': (C.c_int, [c_f64p, C.c_int32, c_i32p, c_f32p, C.c_int32, C.c_int64, c_f32p, c_stream]),
     'snet_edge_force': (C.c_int, [c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_int64, c_f32p, c_f32p,
                                   c_f64p, c_stream]),
     'snet_nl_grid': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int32)]),

@@ -39,6 +39,20 @@ struct Reader {
     get(&v, 4);
     return v;
   }
+  double f64() {
+    double v = 0;
+    get(&v, 8);
+    return v;
+  }
+  std::vector<double> darr(size_t n) {
+    if (!ok || n > (size_t)(end - p) / 8) {
+      ok = false;
+      return {};
+    }
+    std::vector<double> v(n);
+    if (n) get(v.data(), 8 * n);
+    return v;
+  }
   std::vector<float> farr(size_t n) {
     // bounds first: a corrupt count must not reach the allocator (bad_alloc / length_error would cross the C ABI)
     if (!ok || n > (size_t)(end - p) / 4) {
@@ -208,6 +222,8 @@ struct snet_model {
   float cutoff, cutoff_on, act_cst;
   std::vector<float> coeffs;
   float *embed = nullptr, *scale = nullptr, *shift = nullptr;
+  double *ro_v = nullptr, ro_c = 0.0;  // folded readout vector (device) and constant
+  float *h0_table = nullptr, *sc0_table = nullptr;  // [n_species, dx0], [n_species, gin0]: layer 0's SI1(x) / sc(x) per species
   float scale0 = 1.f;
   std::vector<Layer> layers;
   Linear ro1, ro2;
@@ -273,7 +289,7 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
   Reader r{static_cast<const unsigned char *>(blob), static_cast<const unsigned char *>(blob) + n_bytes};
   char magic[8];
   r.get(magic, 8);
-  SNET_REQUIRE(r.ok && memcmp(magic, "SNETMDL2", 8) == 0, "snet_model_load: not a .snet model file");
+  SNET_REQUIRE(r.ok && memcmp(magic, "SNETMDL3", 8) == 0, "snet_model_load: not a .snet model file of this version (SNETMDL3)");
   auto *m = new snet_model;
   bool good = false;
   try {
@@ -350,6 +366,24 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
     m->layers.push_back(L);
   }
   good = good && read_linear(r, m->ro1) && read_linear(r, m->ro2);
+  if (good) {  // layer 0's species-only rows SI1(x), sc(x): fp64-evaluated tables (model_spec.species_only_tables)
+    const int dx0 = r.i32(), gin0 = r.i32();
+    good = r.ok && dx0 == m->layers[0].dx && (gin0 == 0 || gin0 == m->layers[0].gin) && (gin0 != 0) == m->layers[0].sc.present();
+    if (good) {
+      std::vector<float> h0 = r.farr((size_t)m->n_species * dx0), sc0 = r.farr((size_t)m->n_species * gin0);
+      good = r.ok && dev_upload(h0, &m->h0_table) && dev_upload(sc0, &m->sc0_table);
+    }
+  }
+  if (good) {  // folded readout: e_i = x_i . v + c (model_spec.folded_readout)
+    const int d_ro = r.i32();
+    m->ro_c = r.f64();
+    good = r.ok && d_ro == m->ro1.dim_in && d_ro == m->layers.back().dout;
+    if (good) {
+      std::vector<double> v = r.darr((size_t)d_ro);
+      good = r.ok && hipMalloc((void **)&m->ro_v, v.size() * 8) == hipSuccess &&
+             hipMemcpy(m->ro_v, v.data(), v.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+    }
+  }
   if (good) {
     const int nm = r.i32();
     good = r.ok && nm >= 0 && nm <= (1 << 20) && (int64_t)(r.end - r.p) == nm;
@@ -410,7 +444,7 @@ extern "C" void snet_model_destroy(snet_model *m) {
   for (hipEvent_t e : m->ev_w) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : {m->ev_main, m->ev_bwd[0], m->ev_bwd[1]}) if (e) (void)hipEventDestroy(e);
   if (m->side) (void)hipStreamDestroy(m->side);
-  for (void *d : {(void *)m->embed, (void *)m->scale, (void *)m->shift, (void *)m->arena.base, (void *)m->species_rows})
+  for (void *d : {(void *)m->embed, (void *)m->scale, (void *)m->shift, (void *)m->h0_table, (void *)m->sc0_table, (void *)m->ro_v, (void *)m->arena.base, (void *)m->species_rows})
     if (d) (void)hipFree(d);
   delete m;
 }
@@ -564,8 +598,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     if ((rc = snet_gather_rows(emb, pair_edge, ep, WR, nb, st))) return rc;
     emb_w = ep;
   }
-  float *x = A.f((size_t)NT * dmax), *x2 = A.f((size_t)NT * dmax);
-  if ((rc = snet_embed_rows(m->embed, types, x, NT, m->d0, st))) return rc;
+  float *x = A.f((size_t)NT * dmax), *x2 = A.f((size_t)NT * dmax);  // layer 0 reads the species tables, not x
 
   struct Saved { float *h, *w, *y; };  // w: radial weights [WR, wn], or (fused layers) hidden activations h2 [WR, 64]
   std::vector<Saved> saved(Lc);
@@ -610,12 +643,20 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     Layer &L = m->layers[t];
     A.off = mark;
     float *sc = nullptr;
-    if (L.sc.present()) {
-      sc = A.f((size_t)N * L.gin);
-      if ((rc = run_linear(m, L.sc, x, sc, N, false, false, st))) return rc;
-    }
     float *h = saved[t].h;
-    if ((rc = run_linear(m, L.si1, x, h, t == 0 ? NT : N, false, false, st))) return rc;
+    if (t == 0) {  // species-only inputs: table lookups (ghost rows included)
+      if (L.sc.present()) {
+        sc = A.f((size_t)N * L.gin);
+        if ((rc = snet_embed_rows(m->sc0_table, types, sc, N, L.gin, st))) return rc;
+      }
+      if ((rc = snet_embed_rows(m->h0_table, types, h, NT, L.dx, st))) return rc;
+    } else {
+      if (L.sc.present()) {
+        sc = A.f((size_t)N * L.gin);
+        if ((rc = run_linear(m, L.sc, x, sc, N, false, false, st))) return rc;
+      }
+      if ((rc = run_linear(m, L.si1, x, h, N, false, false, st))) return rc;
+    }
     if (t > 0 && has_halo)
       if ((rc = m->halo_fwd(m->halo_user, h, NT, N, L.dx, stream))) {
         snet::set_error("snet_model_eval: forward halo callback failed");
@@ -623,6 +664,10 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
       }
     float *mid = A.f((size_t)N * L.dmid);
     if (E == 0) SNET_REQUIRE(hipMemsetAsync(mid, 0, (size_t)N * L.dmid * 4, st) == hipSuccess, "snet_model_eval: memset");
+    else  // columns of pruned (unread) paths are never written by the tensor-product kernel: defined zeros
+      for (auto &z : L.si2.zero_in)
+        SNET_REQUIRE(hipMemset2DAsync(mid + z.first, (size_t)L.dmid * 4, 0, (size_t)z.second * 4, (size_t)N, st) == hipSuccess,
+                     "snet_model_eval: memset");
     if (L.fused) {  // w = h2 @ W2 is formed inside the tensor-product kernel
       if ((rc = snet_radial_mlp_hidden_fwd(L.mlp_plan, emb_w, WR, saved[t].w, st))) return rc;
       if ((rc = snet_conv_fwd_fused(L.fused, h, sh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, N, L.conv_scale, mid, st)))
@@ -641,29 +686,13 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     std::swap(x, x2);
   }
   A.off = mark;
-  float *h1 = A.f((size_t)N * m->ro1.dim_out), *e_sc = A.f((size_t)N + 64);
-  if ((rc = run_linear(m, m->ro1, x, h1, N, false, false, st))) return rc;
-  if ((rc = run_linear(m, m->ro2, h1, e_sc, N, false, false, st))) return rc;
   float *ea = e_atom ? e_atom : A.f((size_t)N + 64);
-  if ((rc = snet_rescale_reduce(e_sc, types, m->scale, m->shift, m->n_scale, N, ea, energy, st))) return rc;
+  if ((rc = snet_readout_energy(x, N, m->ro1.dim_in, m->ro_v, m->ro_c, types, m->scale, m->shift, m->n_scale, ea, energy, st)))
+    return rc;
 
-  // ---------------- reverse: dE/d(e_scaled) = scale[type]
-  float *g_e = A.f((size_t)N + 64);
-  if (m->n_scale > 1) {
-    if ((rc = snet_embed_rows(m->scale, types, g_e, N, 1, st))) return rc;
-  } else {
-    uint32_t bits;
-    memcpy(&bits, &m->scale0, 4);
-    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g_e), bits,
-                          (size_t)N, st) != hipSuccess) {
-      snet::set_error("snet_model_eval: fill failed");
-      return 1;
-    }
-  }
-  float *g_h1 = A.f((size_t)N * m->ro1.dim_out);
-  if ((rc = run_linear(m, m->ro2, g_e, g_h1, N, true, false, st))) return rc;
+  // ---------------- reverse: dE/dx of the folded readout = scale[type] * v
   float *g_x = x2, *gx_next = x;  // the forward features are dead: x / x2 ping-pong as gradient rows
-  if ((rc = run_linear(m, m->ro1, g_h1, g_x, N, true, false, st))) return rc;
+  if ((rc = snet_readout_grad(m->ro_v, m->ro1.dim_in, types, m->scale, m->n_scale, N, g_x, st))) return rc;
   SNET_REQUIRE(hipMemsetAsync(g_vec, 0, (size_t)E * 3 * 4, st) == hipSuccess &&
                    hipMemsetAsync(g_emb, 0, (size_t)E * nb * 4, st) == hipSuccess,
                "snet_model_eval: memset failed");

@@ -360,6 +360,43 @@ __global__ __launch_bounds__(256) void rescale_partial_kernel(const float *__res
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
 }
+// Folded readout: the two readout linears have no nonlinearity between them (reduce_input_to_hidden /
+// reduce_hidden_to_energy, model_build.py), so they are ONE vector v (product taken in fp64 at load time).
+// One wave per atom: e = x_i . v + c accumulated in fp64, rescaled, atomic energy stored, fp64 two-stage sum.
+__global__ __launch_bounds__(256) void readout_energy_kernel(const float *__restrict__ x, int64_t n, int dim,
+                                                             const double *__restrict__ v, double c,
+                                                             const int32_t *__restrict__ types, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, int n_scale,
+                                                             float *__restrict__ e_atom, double *__restrict__ partial) {
+  __shared__ double sm[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += (int64_t)gridDim.x * 4) {
+    const float *row = x + i * dim;
+    double d = 0.0;
+    for (int k = lane; k < dim; k += 64) d += (double)row[k] * v[k];
+    d = snet::wave_sum_d(d) + c;
+    const int t = n_scale > 1 ? types[i] : 0;
+    const double e = d * (double)scale[t] + (double)shift[t];
+    if (lane == 0) {
+      e_atom[i] = (float)e;
+      acc += e;
+    }
+  }
+  if (lane == 0) sm[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+// reverse of the folded readout: g_x[i, k] = scale[type_i] * v[k]
+__global__ __launch_bounds__(256) void readout_grad_kernel(const double *__restrict__ v, int dim, const int32_t *__restrict__ types,
+                                                           const float *__restrict__ scale, int n_scale, int64_t total,
+                                                           float *__restrict__ g_x) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / dim;
+    const int k = (int)(idx - i * dim);
+    g_x[idx] = (float)((double)scale[n_scale > 1 ? types[i] : 0] * v[k]);
+  }
+}
 __global__ __launch_bounds__(64) void final_sum_kernel(const double *__restrict__ partial, int n, int stride, int ncomp,
                                                        double *__restrict__ out) {
   // out[c] = sum_b partial[b*stride + c], fixed order
@@ -525,6 +562,28 @@ extern "C" int snet_segment_sum_rows(const float *x, const int32_t *seg_ptr, con
   if (n_seg <= 0) return 0;
   launch_segment_sum(x, seg_ptr, perm, n_seg, dim, nullptr, out, static_cast<hipStream_t>(stream));
   SNET_CHECK_LAUNCH("snet_segment_sum_rows");
+  return 0;
+}
+extern "C" int snet_readout_energy(const float *x, int64_t n, int32_t dim, const double *v, double c, const int32_t *types,
+                                   const float *scale, const float *shift, int32_t n_scale, float *e_atom, double *energy,
+                                   void *stream) {
+  SNET_REQUIRE(n_scale >= 1 && dim > 0, "snet_readout_energy: n_scale >= 1 and dim > 0 required");
+  SNET_REQUIRE(n_scale == 1 || types != nullptr, "snet_readout_energy: species-wise scale needs types");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double *partial = snet::reduce_scratch(RED_BLOCKS, st);
+  SNET_REQUIRE(partial != nullptr, "snet_readout_energy: scratch allocation failed");
+  readout_energy_kernel<<<RED_BLOCKS, 256, 0, st>>>(x, n < 0 ? 0 : n, dim, v, c, types, scale, shift, n_scale, e_atom, partial);
+  snet::launch_final_sum(partial, RED_BLOCKS, 1, 1, energy, st);
+  SNET_CHECK_LAUNCH("snet_readout_energy");
+  return 0;
+}
+extern "C" int snet_readout_grad(const double *v, int32_t dim, const int32_t *types, const float *scale, int32_t n_scale,
+                                 int64_t n, float *g_x, void *stream) {
+  SNET_REQUIRE(n_scale >= 1 && dim > 0, "snet_readout_grad: n_scale >= 1 and dim > 0 required");
+  SNET_REQUIRE(n_scale == 1 || types != nullptr, "snet_readout_grad: species-wise scale needs types");
+  if (n <= 0) return 0;
+  readout_grad_kernel<<<grid_for(n * dim), 256, 0, static_cast<hipStream_t>(stream)>>>(v, dim, types, scale, n_scale, n * dim, g_x);
+  SNET_CHECK_LAUNCH("snet_readout_grad");
   return 0;
 }
 extern "C" int snet_rescale_reduce(const float *e_scaled, const int32_t *types, const float *scale,

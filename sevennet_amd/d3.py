@@ -124,29 +124,41 @@ class D3Calculator(Calculator):
         self.results = self.compute(atoms.get_atomic_numbers(), atoms.get_positions(), np.array(atoms.get_cell()), atoms.get_pbc())
 
 
-class SevenNetD3Calculator:
-    """SevenNet + D3 (sevenn/calculator.py:236-314: a SumCalculator of the two).  With ASE present this IS an
-    ase.calculators.mixing.SumCalculator; without it, `compute(numbers, positions, cell, pbc)` returns the summed results."""
+def _d3_pair(model, file_type, device, modal, enable_cueq, enable_flash, enable_oeq, sevennet_config, damping_type,
+             functional_name, vdw_cutoff, cn_cutoff, kwargs):
+    import warnings
+    from .calculator import SevenNetCalculator
+    if kwargs.get('compute_atomic_virial', False):
+        warnings.warn('D3Calculator does not support per-atom stress. Atomic stress from SevenNetD3Calculator will not '
+                      'include D3 contributions.')
+    d3_kwargs = {k: v for k, v in kwargs.items() if k != 'compute_atomic_virial'}
+    d3_calc = D3Calculator(damping_type=damping_type, functional_name=functional_name, vdw_cutoff=vdw_cutoff,
+                           cn_cutoff=cn_cutoff, **d3_kwargs)
+    sevennet_calc = SevenNetCalculator(model=model, file_type=file_type, device=device, modal=modal, enable_cueq=enable_cueq,
+                                       enable_flash=enable_flash, enable_oeq=enable_oeq, sevennet_config=sevennet_config, **kwargs)
+    return sevennet_calc, d3_calc
 
-    def __new__(cls, model='7net-0', file_type: str = 'checkpoint', device='auto', modal=None, enable_cueq=False,
-                enable_flash=False, enable_oeq=False, sevennet_config=None, damping_type: str = 'damp_bj',
-                functional_name: str = 'pbe', vdw_cutoff: float = 9000, cn_cutoff: float = 1600, **kwargs):
-        import warnings
-        from .calculator import SevenNetCalculator
-        if kwargs.get('compute_atomic_virial', False):
-            warnings.warn('D3Calculator does not support per-atom stress. Atomic stress from SevenNetD3Calculator will not '
-                          'include D3 contributions.')
-        d3_kwargs = {k: v for k, v in kwargs.items() if k != 'compute_atomic_virial'}
-        d3_calc = D3Calculator(damping_type=damping_type, functional_name=functional_name, vdw_cutoff=vdw_cutoff,
-                               cn_cutoff=cn_cutoff, **d3_kwargs)
-        sevennet_calc = SevenNetCalculator(model=model, file_type=file_type, device=device, modal=modal, enable_cueq=enable_cueq,
-                                           enable_flash=enable_flash, enable_oeq=enable_oeq, sevennet_config=sevennet_config, **kwargs)
+
+if _HAVE_ASE:
+    from ase.calculators.mixing import SumCalculator as _SumBase
+else:
+    _SumBase = object
+
+
+class SevenNetD3Calculator(_SumBase):
+    """SevenNet + D3 (sevenn/calculator.py:236-314: a SumCalculator subclass holding the two).  With ASE present this is an
+    ase.calculators.mixing.SumCalculator subclass like the reference's; without it, `compute(numbers, positions, cell, pbc)`
+    returns the summed results."""
+
+    def __init__(self, model='7net-0', file_type: str = 'checkpoint', device='auto', modal=None, enable_cueq=False,
+                 enable_flash=False, enable_oeq=False, sevennet_config=None, damping_type: str = 'damp_bj',
+                 functional_name: str = 'pbe', vdw_cutoff: float = 9000, cn_cutoff: float = 1600, **kwargs):
+        pair = _d3_pair(model, file_type, device, modal, enable_cueq, enable_flash, enable_oeq, sevennet_config, damping_type,
+                        functional_name, vdw_cutoff, cn_cutoff, kwargs)
         if _HAVE_ASE:
-            from ase.calculators.mixing import SumCalculator
-            return SumCalculator([sevennet_calc, d3_calc])
-        self = object.__new__(cls)
-        self.calcs = [sevennet_calc, d3_calc]
-        return self
+            super().__init__(list(pair))
+        else:
+            self.calcs = list(pair)
 
     def compute(self, numbers, positions, cell, pbc) -> Dict[str, Any]:
         a, b = (c.compute(numbers, positions, cell, pbc) for c in self.calcs)

@@ -23,8 +23,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .model_spec import (ACT_CST, ACT_ID, LinearSpec, ModelSpec, build_model_spec, linear_modal_bias,
-                         linear_weight_matrices, transposed_scalar_conv)
+from .model_spec import (ACT_CST, ACT_ID, LinearSpec, ModelSpec, build_model_spec, folded_readout, linear_modal_bias,
+                         linear_weight_matrices, species_only_tables, transposed_scalar_conv)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -186,6 +186,8 @@ class _Linear:
         else:
             self.w = [torch.from_numpy(m).to(dev) for m in mats]
             self.wt = [torch.from_numpy(np.ascontiguousarray(m.T)).to(dev) for m in mats]
+        fed = {b.in_off for b in spec.blocks}   # input column ranges no block reads (model_file._write_linear's zero_in)
+        self.zero_in = [(off, m * (2 * l + 1)) for off, (m, l, _) in zip(spec.irreps_in.offsets(), spec.irreps_in) if off not in fed]
         self.groups_fwd = self._plan(transpose=False)
         self.groups_T = self._plan(transpose=True)
         # largest row norm of the TRANSPOSED map: |(Linear^T g)[k]| <= t_norm * ||g||_2 for every input entry k
@@ -249,7 +251,8 @@ class HipForceEngine:
 
     def __init__(self, config: dict, state_dict: Dict[str, np.ndarray], device='cuda:0', mlp_mode: str = 'bf16x6',
                  linear_mode: str = 'bf16x6', fused='auto', fused_terms='f16x3', modal=None, overlap: bool = True,
-                 mlp_tail: bool = True, transposed_conv: bool = True):
+                 mlp_tail: bool = True, transposed_conv: bool = True, species_tables: bool = True,
+                 fold_readout: bool = True):
         """mlp_mode / linear_mode: 'bf16x6' (split-precision MFMA, fp32-class accuracy, default) or
         'fp32' (exact fp32 MFMA) for the fused radial MLP / the node-level equivariant linears.
         fused: 'auto' (default) / True / False / 'fwd' / 'bwd' -- run the radial MLP's last layer INSIDE the
@@ -274,6 +277,11 @@ class HipForceEngine:
         caching allocator fall back to hipMalloc/hipFree, a 3x slowdown at 100k atoms.
         transposed_conv: scalar-output layers (the last one) take their source-row gradient from a forward convolution of the
         transposed tensor product over the edges grouped by source atom instead of per-edge g_xe rows + a segment sum.
+        species_tables: layer 0's SI1(x) and self-connection rows, which depend on the species alone, come from per-species
+        tables evaluated in fp64 at load time (model_spec.species_only_tables) instead of per-atom GEMMs (False: the
+        GEMMs, kept for A/B measurements).
+        fold_readout: the two readout linears as one fp64-folded vector, per-atom dot product and rescale in fp64
+        (snet_readout_energy) instead of two GEMMs + snet_rescale_reduce (False: the GEMMs, for A/B measurements).
         modal: fidelity channel (name from config['_modal_map'] or index) of a multi-modal model; the
         one-hot inputs of its linears become constant biases, shift/scale rows are selected at load.
         """
@@ -408,6 +416,15 @@ class HipForceEngine:
                                            ACT_CST[inv_act[s.act]])
                 L.gate_segs = segs
                 self.layers.append(L)
+            self.h0_table = self.sc0_table = None
+            if species_tables:
+                h0, sc0 = species_only_tables(sp, sd, mi)
+                self.h0_table = torch.from_numpy(h0).to(self.dev)
+                self.sc0_table = None if sc0 is None else torch.from_numpy(sc0).to(self.dev)
+            self.ro_v = None
+            if fold_readout:
+                v, self.ro_c = folded_readout(sp, sd, mi)
+                self.ro_v = torch.from_numpy(v).to(self.dev)
             self.ro1 = _Linear(sp.readout1, sd[sp.readout1.name], self.dev, split, mi)
             self.ro2 = _Linear(sp.readout2, sd[sp.readout2.name], self.dev, split, mi)
             sc_v, sh_v = sp.rescale_vectors(sd, mi)
@@ -584,9 +601,11 @@ class HipForceEngine:
                         ev.record(side)
                         w_ready[t_] = (w_bufs[t_], ev)
             d0 = sp.embed.dim_out
-            x = self._new(NT, d0)  # ghost layer-0 features depend only on species (model_build.py:383-421)
-            _lib.check(lib.snet_embed_rows(_ptr(self.embed_table), _ptr(g.types), _ptr(x), NT, d0, st),
-                       'snet_embed_rows')
+            x = None
+            if keep or self.h0_table is None:
+                x = self._new(NT, d0)  # ghost layer-0 features depend only on species (model_build.py:383-421)
+                _lib.check(lib.snet_embed_rows(_ptr(self.embed_table), _ptr(g.types), _ptr(x), NT, d0, st),
+                           'snet_embed_rows')
             if keep:
                 inter['edge_embedding'], inter['edge_attr'], inter['x_embed'] = emb, sh, x[:N]
             saved = []
@@ -595,7 +614,11 @@ class HipForceEngine:
                 n_in = NT if t == 0 else N  # rows of x that are valid
                 with _Span(self, 'node_linear_fwd'):
                     h = self._new(NT, ls.si1.dim_out)
-                    self._linear(L.si1, x, n_in, g, out=h)
+                    if t == 0 and self.h0_table is not None:   # species-only rows: fp64-evaluated table lookup
+                        _lib.check(lib.snet_embed_rows(_ptr(self.h0_table), _ptr(g.types), _ptr(h), NT, ls.si1.dim_out, st),
+                                   'snet_embed_rows')
+                    else:
+                        self._linear(L.si1, x, n_in, g, out=h)
                 # ghost rows of h travel while the self-connection and the radial MLP (which do not read
                 # them) run: hosts with a split exchange overlap the transfer with that work
                 pending = None
@@ -606,11 +629,21 @@ class HipForceEngine:
                         else:
                             halo.forward(h, N)
                 with _Span(self, 'node_linear_fwd'):
-                    sc = self._linear(L.sc, x, N, g) if L.sc is not None else None
+                    if t == 0 and self.h0_table is not None:
+                        sc = None
+                        if self.sc0_table is not None:
+                            sc = self._new(N, ls.gate.irreps_in.dim)
+                            _lib.check(lib.snet_embed_rows(_ptr(self.sc0_table), _ptr(g.types), _ptr(sc), N, ls.gate.irreps_in.dim,
+                                                           st), 'snet_embed_rows')
+                    else:
+                        sc = self._linear(L.sc, x, N, g) if L.sc is not None else None
                 dmid = ls.conv.irreps_out.dim
                 m = self._new(N, dmid)
                 if E == 0:
                     m.zero_()
+                else:   # columns of pruned (unread) paths are never written by the tensor-product kernel: defined zeros
+                    for off, ln in L.si2.zero_in:
+                        m[:, off:off + ln].zero_()
                 h2 = w = zs = None
                 rows_w = g.n_pairs if pairs else E
                 if L.fused_fwd or L.fused_bwd:  # hidden activations of the radial MLP, one row per pair
@@ -649,21 +682,28 @@ class HipForceEngine:
                 if keep:
                     inter[f'{t}_si1'], inter[f'{t}_conv'], inter[f'{t}_gate_in'], inter[f'{t}_x'] = h[:N], m, y, xo
                 x = xo
-            h1 = self._linear(self.ro1, x, N, g)
-            e_sc = self._linear(self.ro2, h1, N, g)
             e_atom = self._new(N)
             energy = torch.empty(1, dtype=torch.float64, device=self.dev)
-            _lib.check(lib.snet_rescale_reduce(_ptr(e_sc), _ptr(g.types), _ptr(self.scale), _ptr(self.shift),
-                                               self.n_scale, N, _ptr(e_atom), _ptr(energy), st), 'snet_rescale_reduce')
-
-            # ---------------- reverse pass: dE/d(e_scaled) = scale[type]
-            g_e = self._new(N, 1)
-            if self.n_scale > 1:
-                _lib.check(lib.snet_embed_rows(_ptr(self.scale), _ptr(g.types), _ptr(g_e), N, 1, st), 'snet_embed_rows')
+            d_ro = sp.readout1.dim_in
+            if self.ro_v is not None:   # folded readout: fp64 dot product + rescale + energy sum in one pass
+                _lib.check(lib.snet_readout_energy(_ptr(x), N, d_ro, _ptr(self.ro_v), self.ro_c, _ptr(g.types), _ptr(self.scale),
+                                                   _ptr(self.shift), self.n_scale, _ptr(e_atom), _ptr(energy), st), 'snet_readout_energy')
+                g_x = self._new(N, d_ro)
+                _lib.check(lib.snet_readout_grad(_ptr(self.ro_v), d_ro, _ptr(g.types), _ptr(self.scale), self.n_scale, N, _ptr(g_x),
+                                                 st), 'snet_readout_grad')
             else:
-                g_e.fill_(self.scale0)
-            g_h1 = self._linear_T(self.ro2, g_e, N, g)
-            g_x = self._linear_T(self.ro1, g_h1, N, g)
+                h1 = self._linear(self.ro1, x, N, g)
+                e_sc = self._linear(self.ro2, h1, N, g)
+                _lib.check(lib.snet_rescale_reduce(_ptr(e_sc), _ptr(g.types), _ptr(self.scale), _ptr(self.shift),
+                                                   self.n_scale, N, _ptr(e_atom), _ptr(energy), st), 'snet_rescale_reduce')
+                # ---------------- reverse pass: dE/d(e_scaled) = scale[type]
+                g_e = self._new(N, 1)
+                if self.n_scale > 1:
+                    _lib.check(lib.snet_embed_rows(_ptr(self.scale), _ptr(g.types), _ptr(g_e), N, 1, st), 'snet_embed_rows')
+                else:
+                    g_e.fill_(self.scale0)
+                g_h1 = self._linear_T(self.ro2, g_e, N, g)
+                g_x = self._linear_T(self.ro1, g_h1, N, g)
             sh_T = None   # spherical harmonics in source-grouped edge order (transposed scalar convolution)
             g_vec = torch.zeros(E, 3, dtype=torch.float32, device=self.dev)  # spherical part, all layers
             g_emb = torch.zeros(E, nb, dtype=torch.float32, device=self.dev)

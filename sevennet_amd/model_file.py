@@ -7,7 +7,7 @@ all tables of `ModelSpec` plus the weights with every normalisation already fold
 host needs no Python, no torch and no e3nn.
 
 Layout (all ints int32, floats float32 unless noted):
-    magic 'SNETMDL2'
+    magic 'SNETMDL3'   (v3: species tables of layer 0; unread tensor-product paths are not stored)
     header  : n_species n_layers lmax normalize n_basis cutoff_kind poly_p act_radial n_scale d0
               cutoff(f32) cutoff_on(f32) act_cst(f32)
     coeffs[n_basis]  embed[n_species*d0]  scale[n_scale]  shift[n_scale]
@@ -16,6 +16,9 @@ Layout (all ints int32, floats float32 unless noted):
                linear sc (all-zero header if absent), si1, si2   (see _write_linear)
                n_gate_segs, segs[kind in_off out_off mul l gate_off act | cst f32]
     readout linears ro1, ro2
+    species tables of layer 0 (model_spec.species_only_tables): dx0, gin0 (0 = no self-connection),
+               h0[n_species*dx0], sc0[n_species*gin0]  -- SI1(x) and sc(x) of the species-only layer-0 inputs, fp64-evaluated
+    folded readout (model_spec.folded_readout): d_ro, c (float64), v[d_ro] (float64)  -- e_i = x_i . v + c
     metadata : n_bytes, then `key=value` lines (utf-8) -- the `_extra_files` of the reference's deployed
                model (deploy.py:56-72): chemical_symbols_to_index, cutoff, num_species, model_type,
                version, dtype
@@ -27,9 +30,10 @@ from typing import Dict
 
 import numpy as np
 
-from .model_spec import ACT_CST, ACT_ID, LinearSpec, build_model_spec, linear_modal_bias, linear_weight_matrices
+from .model_spec import (ACT_CST, ACT_ID, LinearSpec, build_model_spec, folded_readout, linear_modal_bias,
+                         linear_weight_matrices, species_only_tables)
 
-MAGIC = b'SNETMDL2'
+MAGIC = b'SNETMDL3'
 
 _SYMBOLS = ('X H He Li Be B C N O F Ne Na Mg Al Si P S Cl Ar K Ca Sc Ti V Cr Mn Fe Co Ni Cu Zn Ga Ge As Se Br Kr Rb Sr '
             'Y Zr Nb Mo Tc Ru Rh Pd Ag Cd In Sn Sb Te I Xe Cs Ba La Ce Pr Nd Pm Sm Eu Gd Tb Dy Ho Er Tm Yb Lu Hf Ta W '
@@ -132,6 +136,15 @@ def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray],
             out.append(_f(ACT_CST[inv_act[s.act]]))
     out.append(_write_linear(sp.readout1, sd[sp.readout1.name], mi))
     out.append(_write_linear(sp.readout2, sd[sp.readout2.name]))
+    h0, sc0 = species_only_tables(sp, sd, mi)
+    out.append(_i(h0.shape[1], 0 if sc0 is None else sc0.shape[1]))
+    out.append(_arr(h0))
+    if sc0 is not None:
+        out.append(_arr(sc0))
+    v, c = folded_readout(sp, sd, mi)
+    out.append(_i(len(v)))
+    out.append(struct.pack('<d', c))
+    out.append(np.ascontiguousarray(v, dtype='<f8').tobytes())
     meta = {'chemical_symbols_to_index': ' '.join(species_symbols(config, sp.num_species)),
             'cutoff': repr(float(sp.cutoff)), 'num_species': str(sp.num_species),
             'model_type': str(config.get('model_type', 'E3_equivariant_model')),

@@ -144,6 +144,55 @@ def linear_weight_matrices(spec: LinearSpec, flat: np.ndarray):
     return out
 
 
+def linear_rows_fp64(spec: LinearSpec, flat: np.ndarray, x: np.ndarray, species=None, modal_idx: int = -1) -> np.ndarray:
+    """y = Linear(x) for ir_mul rows x[n, dim_in], evaluated in fp64 on the host (load time only).
+    species[n] selects the weight slice of a per-species (FCTP) linear."""
+    flat = np.asarray(flat, dtype=np.float64).reshape(-1)
+    x = np.asarray(x, dtype=np.float64)
+    ns = max(spec.n_species, 1)
+    y = np.zeros((x.shape[0], spec.dim_out), np.float64)
+    for b in spec.blocks:
+        w = flat[b.w_off:b.w_off + b.mul_in * ns * b.mul_out]
+        w = (w.reshape(b.mul_in, ns, b.mul_out)[:, b.species, :] if spec.n_species else w.reshape(b.mul_in, b.mul_out)) * b.alpha
+        rows = slice(None) if b.species < 0 else np.nonzero(np.asarray(species) == b.species)[0]
+        for m in range(2 * b.l + 1):
+            y[rows, b.out_off + m * b.mul_out:b.out_off + (m + 1) * b.mul_out] += \
+                x[rows, b.in_off + m * b.mul_in:b.in_off + (m + 1) * b.mul_in] @ w
+    if spec.n_modal:
+        for off, mo, w_off, alpha in spec.modal_bias:
+            y[:, off:off + mo] += flat[w_off:w_off + spec.n_modal * mo].reshape(spec.n_modal, mo)[modal_idx] * alpha
+    return y
+
+
+def species_only_tables(sp: 'ModelSpec', sd, modal_idx: int):
+    """The first interaction block's node-level inputs depend on the species alone (one-hot embedding,
+    model_build.py:383-421), so `SI1(x)` and the self-connection `sc(x)` of layer 0 are one row per SPECIES.  They are
+    evaluated once at load time in fp64 and rounded once to fp32 -- the per-atom GEMMs of that layer (and their rounding,
+    which is the same vector on every atom of a species and therefore does not average out over atoms: it was the engine's
+    whole energy error, profiles/r04_energy_error_attribution.txt) are replaced by a table lookup.
+    -> (h0[n_species, dx0] float32, sc0[n_species, gin0] float32 or None)"""
+    ls = sp.layers[0]
+    e64 = linear_rows_fp64(sp.embed, sd[sp.embed.name], np.eye(sp.num_species), None, modal_idx)   # fp64 embedding rows
+    species = np.arange(sp.num_species)
+    h0 = linear_rows_fp64(ls.si1, sd[ls.si1.name], e64, species, modal_idx)
+    sc0 = linear_rows_fp64(ls.sc, sd[ls.sc.name], e64, species, modal_idx) if ls.sc is not None else None
+    return h0.astype(np.float32), (None if sc0 is None else sc0.astype(np.float32))
+
+
+def folded_readout(sp: 'ModelSpec', sd, modal_idx: int):
+    """The reference's readout is two o3.Linear maps with nothing between them (reduce_input_to_hidden then
+    reduce_hidden_to_energy, sevenn/model_build.py; `readout_as_fcn` models are refused upstream of here), i.e. ONE vector:
+    e_i = x_i . v + c.  The product is taken in fp64 at load time -> (v[dim_in] float64, c float)."""
+    d = sp.readout1.dim_in
+
+    def chain(x):
+        return linear_rows_fp64(sp.readout2, sd[sp.readout2.name], linear_rows_fp64(sp.readout1, sd[sp.readout1.name], x, None, modal_idx))
+
+    c = chain(np.zeros((1, d)))[0, 0]
+    v = chain(np.eye(d))[:, 0] - c
+    return np.ascontiguousarray(v, np.float64), float(c)
+
+
 # --------------------------------------------------------------------------- #
 @dataclass
 class ConvPath:
@@ -202,6 +251,11 @@ def transposed_scalar_conv(conv: ConvSpec):
     irreps_g = Irreps([(conv.paths[k].mul, 0, 1) for k in order])
     g_index = {k: i for i, k in enumerate(order)}
     g_off = irreps_g.offsets()
+    # the dense concatenation of the per-path scalar blocks must BE the g_out row: every path at its real position and no
+    # scalar column that no live path writes (pruned paths, an unread 0o block) -- otherwise the transposed kernel would
+    # read g_out at the wrong offsets and the caller falls back to per-edge g_xe rows + a segment sum
+    if irreps_g.dim != conv.irreps_out.dim or any(g_off[g_index[k]] != p.out_off + p.out_ch for k, p in enumerate(conv.paths)):
+        return None
     paths, kappa = [], []
     for k, p in enumerate(conv.paths):      # same path order -> same weight-column offsets
         mul, l, par = conv.irreps_x[p.i_x]

@@ -249,7 +249,9 @@ class RcclComm:
             raw = bcast(raw)
         else:
             import torch.distributed as dist
-            if world > 1 or (dist.is_available() and dist.is_initialized()):   # world 1 inside a process group: same path
+            # a world-1 communicator inside a LARGER process group keeps its own id (every process would otherwise
+            # create a 1-rank communicator from rank 0's id); the broadcast runs only when the group IS this communicator's world
+            if world > 1 or (dist.is_available() and dist.is_initialized() and dist.get_world_size() == world):
                 box = [raw]
                 dist.broadcast_object_list(box, src=0)
                 raw = box[0]

@@ -19,7 +19,7 @@ def test_model_file_header_and_size(tmp_path):
     cfg = sevennet_0_config()
     p, sd = _write(tmp_path, cfg)
     blob = p.read_bytes()
-    assert blob[:8] == b'SNETMDL2'
+    assert blob[:8] == b'SNETMDL3'
     sp = build_model_spec(cfg)
     hdr = struct.unpack('<10i3f', blob[8:8 + 52])
     assert hdr[0] == sp.num_species and hdr[1] == 5 and hdr[2] == 2 and hdr[4] == 8 and hdr[9] == 128
@@ -74,7 +74,7 @@ def test_deploy_cli_from_checkpoint(tmp_path):
     out = tmp_path / 'm.snet'
     assert main([str(ck), '-o', str(out)]) == 0
     blob = out.read_bytes()
-    assert blob[:8] == b'SNETMDL2'
+    assert blob[:8] == b'SNETMDL3'
     tail = blob[-400:].decode('latin1')
     assert 'chemical_symbols_to_index=Hf O\n' in tail and 'model_type=E3_equivariant_model' in tail
 

@@ -1,16 +1,19 @@
 #!/bin/bash
-# Round-end evidence on one MI355X:  gpurun --timeout 3400 -- bash tools/gpu/round_end.sh r03
-# full -m gpu suite (exit code captured) + smoke, tools/collect_profiles.sh <tag>, bench lines of the lmax-3 shapes, the
-# world-1 RCCL soak.
-TAG=${1:-r03}
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/round_end_tests_full.log 2>&1; echo "pytest rc=$?" | tee gpurun_out/round_end_tests.log
-grep -E "passed|failed|error" gpurun_out/round_end_tests_full.log | tail -3 | tee -a gpurun_out/round_end_tests.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee -a gpurun_out/round_end_tests.log
-timeout 1500 bash tools/collect_profiles.sh $TAG 2>&1 | tail -2 | cut -c1-300
+# Round-end evidence on one MI355X:  gpurun --timeout 3400 -- bash tools/gpu/round_end.sh r04
+# full -m gpu suite + smoke (tools/gpu/tests_only.sh: exit codes printed, nothing piped through tail),
+# tools/collect_profiles.sh <tag>, bench lines of the lmax-3 shapes, the world-1 RCCL soak.
+set -o pipefail
+TAG=${1:-r04}
+bash tools/gpu/tests_only.sh
+echo "tests_only rc=$?" | tee -a gpurun_out/tests.log
+cp gpurun_out/tests.log gpurun_out/${TAG}_gpu_tests.txt
+timeout 1500 bash tools/collect_profiles.sh $TAG > gpurun_out/${TAG}_collect.log 2>&1; echo "collect_profiles rc=$?"
+tail -2 gpurun_out/${TAG}_collect.log | cut -c1-300
 for m in sevennet_l3i5 sevennet_mf_ompa; do
-timeout 300 python bench.py --no-cpu-baseline --model $m 2>/dev/null | tee gpurun_out/${TAG}_bench_${m}_n1.json | python -c "
+timeout 300 python bench.py --no-cpu-baseline --model $m 2>/dev/null > gpurun_out/${TAG}_bench_${m}_n1.json; echo "bench $m rc=$?"
+python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); r=d['roofline']
+d=json.loads(open('gpurun_out/${TAG}_bench_${m}_n1.json').read()); r=d['roofline']
 print('$m', d['ms_per_step'], d['value'], r['avg_ms'], r['frac'])"
 done
-timeout 900 bash tools/gpu/rccl_world1_soak.sh 2>&1 | tail -5
+timeout 900 bash tools/gpu/rccl_world1_soak.sh > gpurun_out/${TAG}_soak.log 2>&1; echo "soak rc=$?"; tail -5 gpurun_out/${TAG}_soak.log
