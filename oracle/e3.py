@@ -273,5 +273,5 @@ def normalize2mom_const(name: str) -> float:
     gen = torch.Generator().manual_seed(0)
     z = torch.randn(1_000_000, generator=gen, dtype=torch.float64)
     f = {'ssp': lambda x: torch.nn.functional.softplus(x) - math.log(2.0),
-         'abs': torch.abs, 'relu': torch.relu}[name]
+         'abs': torch.abs, 'relu': torch.relu, 'sigmoid': torch.sigmoid, 'elu': torch.nn.functional.elu}[name]
     return float(f(z).pow(2).mean().pow(-0.5))

@@ -29,7 +29,8 @@ DEFAULTS = dict(  # sevenn/_const.py:95-135
     act_radial='silu', act_scalar={'e': 'silu', 'o': 'tanh'},
     act_gate={'e': 'silu', 'o': 'tanh'}, weight_nn_hidden_neurons=[64, 64],
     conv_denominator=1.0, self_connection_type='nequip', _normalize_sph=True,
-    shift=0.0, scale=1.0, version='0.12.0',
+    shift=0.0, scale=1.0, version='0.12.0', use_bias_in_linear=False, readout_as_fcn=False,
+    readout_fcn_hidden_neurons=[30, 30], readout_fcn_activation='relu',
 )
 
 
@@ -38,7 +39,10 @@ def _version_tuple(v: str):
 
 
 def _act(name: str):
-    return {'silu': torch.nn.functional.silu, 'tanh': torch.tanh}[name]
+    """sevenn/_const.py:33-47 (ssp: sevenn/nn/activation.py:7)"""
+    return {'silu': torch.nn.functional.silu, 'tanh': torch.tanh, 'relu': torch.relu, 'abs': torch.abs,
+            'ssp': lambda x: torch.nn.functional.softplus(x) - math.log(2.0), 'sigmoid': torch.sigmoid,
+            'elu': torch.nn.functional.elu}[name]
 
 
 # --------------------------------------------------------------------------- #
@@ -85,9 +89,15 @@ def linear_weight_numel(irreps_in, irreps_out):
     return sum(irreps_in[i][0] * irreps_out[j][0] for i, j in linear_instructions(irreps_in, irreps_out))
 
 
-def linear_apply(x, irreps_in: Irreps, irreps_out: Irreps, w_flat):
+def linear_bias_numel(irreps_out: Irreps) -> int:
+    return sum(mo for mo, (l, p) in irreps_out if (l, p) == (0, 1))
+
+
+def linear_apply(x, irreps_in: Irreps, irreps_out: Irreps, w_flat, bias=None):
     """e3nn o3.Linear (sevenn/nn/linear.py:94-100): per matching irrep pair a
-    [mul_in, mul_out] block, scaled 1/sqrt(total fan-in of that output block)."""
+    [mul_in, mul_out] block, scaled 1/sqrt(total fan-in of that output block).
+    bias (o3.Linear(biases=True), `use_bias_in_linear`): one value per channel of every 0e output block, concatenated in
+    irreps_out order, added unscaled."""
     ins = linear_instructions(irreps_in, irreps_out)
     sl_in, sl_out = irreps_in.slices(), irreps_out.slices()
     fan = [0] * len(irreps_out)
@@ -104,12 +114,17 @@ def linear_apply(x, irreps_in: Irreps, irreps_out: Irreps, w_flat):
         y = torch.einsum('nui,uv->nvi', xi, w) / math.sqrt(fan[j])
         outs[j] = y if outs[j] is None else outs[j] + y
     assert o == w_flat.numel()
-    cols = []
-    for j, (mo, (l, _)) in enumerate(irreps_out):
+    cols, b_off = [], 0
+    for j, (mo, (l, p_)) in enumerate(irreps_out):
         if outs[j] is None:
-            cols.append(x.new_zeros(x.shape[0], mo * (2 * l + 1)))
+            c = x.new_zeros(x.shape[0], mo * (2 * l + 1))
         else:
-            cols.append(outs[j].reshape(x.shape[0], -1))
+            c = outs[j].reshape(x.shape[0], -1)
+        if bias is not None and (l, p_) == (0, 1):
+            c = c + bias[b_off:b_off + mo]
+            b_off += mo
+        cols.append(c)
+    assert bias is None or b_off == bias.numel()
     return torch.cat(cols, dim=1)
 
 
@@ -331,6 +346,10 @@ class OracleModel:
             irreps_x = irreps_out
         self.irreps_final = irreps_x
         self.irreps_hidden = Irreps([((ch if legacy else irreps_x.dim) // 2, (0, 1))])
+        self.use_bias = bool(cfg.get('use_bias_in_linear', False))
+        self.readout_fcn_dims = ([irreps_x.dim] + [int(v) for v in cfg.get('readout_fcn_hidden_neurons', [30, 30])] + [1]
+                                 if cfg.get('readout_as_fcn') else None)
+        self.readout_fcn_act = str(cfg.get('readout_fcn_activation', 'relu'))
 
         self.p: Dict[str, torch.Tensor] = OrderedDict()
         shapes = self.param_shapes()
@@ -375,9 +394,21 @@ class OracleModel:
                 s[f'{t}_convolution.weight_nn.layer{i}.weight'] = (ls.mlp_dims[i], ls.mlp_dims[i + 1])
             s[f'{t}_self_interaction_2.linear.weight'] = (
                 linear_weight_numel(self._mi(ls.irreps_out_tp, 'si2'), ls.irreps_gate_in),)
-        s['reduce_input_to_hidden.linear.weight'] = (
-            linear_weight_numel(self._mi(self.irreps_final, 'out'), self.irreps_hidden),)
-        s['reduce_hidden_to_energy.linear.weight'] = (linear_weight_numel(self.irreps_hidden, Irreps('1x0e')),)
+        if self.readout_fcn_dims:   # readout_as_fcn (model_build.py:124-138)
+            for i in range(len(self.readout_fcn_dims) - 1):
+                s[f'readout_FCN.fcn.layer{i}.weight'] = (self.readout_fcn_dims[i], self.readout_fcn_dims[i + 1])
+        else:
+            s['reduce_input_to_hidden.linear.weight'] = (
+                linear_weight_numel(self._mi(self.irreps_final, 'out'), self.irreps_hidden),)
+            s['reduce_hidden_to_energy.linear.weight'] = (linear_weight_numel(self.irreps_hidden, Irreps('1x0e')),)
+        if self.use_bias:   # use_bias_in_linear: embedding, SI1 / SI2, readout linears (model_build.py:518,531; interaction_blocks.py:50,72)
+            s['onehot_to_feature_x.linear.bias'] = (linear_bias_numel(self.irreps_embed),)
+            for ls in self.layers:
+                s[f'{ls.t}_self_interaction_1.linear.bias'] = (linear_bias_numel(ls.irreps_x),)
+                s[f'{ls.t}_self_interaction_2.linear.bias'] = (linear_bias_numel(ls.irreps_gate_in),)
+            if not self.readout_fcn_dims:
+                s['reduce_input_to_hidden.linear.bias'] = (linear_bias_numel(self.irreps_hidden),)
+                s['reduce_hidden_to_energy.linear.bias'] = (1,)
         if self.n_modal:  # ModalWiseRescale (scale.py:196-363): always per species, optionally per modal
             ns = self.num_species
             s['rescale_atomic_energy.shift'] = (self.n_modal, ns) if self.cfg.get('use_modal_wise_shift') else (ns,)
@@ -418,7 +449,7 @@ class OracleModel:
     def node_embed(self, types):
         onehot = torch.nn.functional.one_hot(types, self.num_species).to(self.dtype)
         x = linear_apply(self._mx(onehot, 'embed'), self._mi(Irreps(f'{self.num_species}x0e'), 'embed'), self.irreps_embed,
-                         self.p['onehot_to_feature_x.linear.weight'])
+                         self.p['onehot_to_feature_x.linear.weight'], self.p.get('onehot_to_feature_x.linear.bias'))
         return onehot, x
 
     def sc_intro(self, ls, x, onehot):
@@ -433,7 +464,7 @@ class OracleModel:
 
     def si1(self, ls, x):
         return linear_apply(self._mx(x, 'si1'), self._mi(ls.irreps_x, 'si1'), ls.irreps_x,
-                            self.p[f'{ls.t}_self_interaction_1.linear.weight'])
+                            self.p[f'{ls.t}_self_interaction_1.linear.weight'], self.p.get(f'{ls.t}_self_interaction_1.linear.bias'))
 
     def radial_weights(self, ls, emb):
         ws = [self.p[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] for i in range(len(ls.mlp_dims) - 1)]
@@ -451,12 +482,17 @@ class OracleModel:
 
     def si2(self, ls, x):
         return linear_apply(self._mx(x, 'si2'), self._mi(ls.irreps_out_tp, 'si2'), ls.irreps_gate_in,
-                            self.p[f'{ls.t}_self_interaction_2.linear.weight'])
+                            self.p[f'{ls.t}_self_interaction_2.linear.weight'], self.p.get(f'{ls.t}_self_interaction_2.linear.bias'))
 
     def readout(self, x, types):
-        h = linear_apply(self._mx(x, 'out'), self._mi(self.irreps_final, 'out'), self.irreps_hidden,
-                         self.p['reduce_input_to_hidden.linear.weight'])
-        e = linear_apply(h, self.irreps_hidden, Irreps('1x0e'), self.p['reduce_hidden_to_energy.linear.weight'])
+        if self.readout_fcn_dims:   # FCN_e3nn (nn/linear.py:145-180): FullyConnectedNet on the final scalars
+            ws = [self.p[f'readout_FCN.fcn.layer{i}.weight'] for i in range(len(self.readout_fcn_dims) - 1)]
+            e = fcn_apply(x, ws, self.readout_fcn_act)
+        else:
+            h = linear_apply(self._mx(x, 'out'), self._mi(self.irreps_final, 'out'), self.irreps_hidden,
+                             self.p['reduce_input_to_hidden.linear.weight'], self.p.get('reduce_input_to_hidden.linear.bias'))
+            e = linear_apply(h, self.irreps_hidden, Irreps('1x0e'), self.p['reduce_hidden_to_energy.linear.weight'],
+                             self.p.get('reduce_hidden_to_energy.linear.bias'))
         sc, sh = self.p['rescale_atomic_energy.scale'], self.p['rescale_atomic_energy.shift']
         return rescale_apply(e, types, sc, sh, self.modal_idx if self.n_modal else None)
 

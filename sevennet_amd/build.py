@@ -30,7 +30,7 @@ _sfx = ('_' + os.path.basename(LIB).replace('.so', '')) if os.environ.get('SNET_
 GEN = os.path.join(CSRC, 'generated' + _sfx)
 OBJ = os.path.join(CSRC, 'build' + _sfx)
 ARCH = 'gfx950'
-STATIC_SOURCES = ['snet_api.cpp', 'snet_model.cpp', 'snet_halo.cpp', 'snet_gemm.hip', 'snet_mlp.hip', 'snet_edge.hip', 'snet_node.hip', 'snet_force.hip', 'snet_neighbor.hip', 'snet_md.hip', 'snet_d3.hip']
+STATIC_SOURCES = ['snet_api.cpp', 'snet_model.cpp', 'snet_halo.cpp', 'snet_gemm.hip', 'snet_mlp.hip', 'snet_edge.hip', 'snet_node.hip', 'snet_force.hip', 'snet_neighbor.hip', 'snet_md.hip', 'snet_d3.hip', 'snet_d3_ref.cpp']
 
 
 def _hipcc() -> str:
@@ -73,7 +73,37 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
+def write_d3_blob() -> str:
+    """data/d3_params.bin next to the library: the D3 tables and functional parameters of data/d3_params.npz in the flat
+    layout csrc/snet_d3_ref.cpp reads (the reference's `pair_*` ABI has no table arguments: its library has them compiled in)"""
+    import struct
+
+    import numpy as np
+    src = os.path.join(HERE, 'data', 'd3_params.npz')
+    dst = os.path.join(os.path.dirname(LIB), 'data', 'd3_params.bin')
+    if os.path.exists(dst) and os.path.getmtime(dst) >= os.path.getmtime(src):
+        return dst
+    z = np.load(src)
+    out = [b'SNETD3P1', struct.pack('<q', z['c6ab'].shape[0])]
+    for k in ('r0ab', 'c6ab', 'r2r4', 'rcov'):
+        out.append(np.ascontiguousarray(z[k], dtype='<f8').tobytes())
+    sets = [(0, 'damp_zero'), (1, 'damp_bj')]
+    out.append(struct.pack('<i', len(sets)))
+    for code, name in sets:
+        names, pars = z[name + '_names'].tolist(), np.asarray(z[name + '_params'], np.float64)
+        out.append(struct.pack('<ii', code, len(names)))
+        for n, p in zip(names, pars):
+            b = n.encode()
+            assert len(b) < 32
+            out.append(b.ljust(32, b'\0') + np.ascontiguousarray(p, dtype='<f8').tobytes())
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    with open(dst, 'wb') as f:
+        f.write(b''.join(out))
+    return dst
+
+
 def build(jobs: int = 0, force: bool = False, extra_configs=(), verbose: bool = True) -> str:
+    write_d3_blob()
     os.makedirs(GEN, exist_ok=True)
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.join(CSRC, 'generated'), exist_ok=True)

@@ -335,16 +335,44 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     # SevenNet-0 middle layer needs 30 sub-steps instead of 34, its last layer (three one-path x blocks) 7 instead of 14.
     bsched, cols_b = schedule_bwd(spec)
     NSB = len(cols_b)
+    # Order of the vector-memory operations (round 4).  vmcnt retires IN ORDER, and the slab fragments of the next sub-step
+    # are waited for at the end of every sub-step: whatever was issued before those slab loads -- the gathers of the next
+    # block's source rows and g_out entries, the g_xe stores of the block just finished -- is waited for with them.  So the
+    # first sub-step of a block does not request its slab itself: the request is HOISTED in front of the previous block's
+    # stores (and, for the first block, into the prologue); the long-latency operations then have two sub-steps to complete
+    # instead of (at best) one.  SNET_CODEGEN_OPTS=novmord=1 restores the round-3 order.
+    VMORD = not OPTS.get('novmord')
+    GRAW = VMORD and not OPTS.get('nograw')    # g_out entries loaded raw, 1/denominator applied when they are parked
+    GUNC = VMORD and not OPTS.get('nogunc')    # padding entries of the g_out fetch: unconditional loads of offset 0
+    _gl0 = [[1 for u in range(bs_['U']) for _, p_ in bs_['cat'].paths for _ in range(2 * p_.l3 + 1)] for bs_ in bsched]
+    _ngp0 = max((len(g_) + 15) // 16 * 16 for g_ in _gl0)
+    if 2 * 8 * 2 * 1024 + 4 * (2 * _ngp0 * 64 + spec.irreps_sh.dim * 64) <= 53 * 1024 and \
+            12 * max(2 * c_.l1 + 1 for c_ in cats) + 32 + spec.irreps_sh.dim + 4 * (_ngp0 // 16) + 16 + 4 * max(2 * p_.l3 + 1 for p_ in spec.paths) + 35 <= 168:
+        GUNC = GUNC and bool(OPTS.get('gunc3'))   # three-waves-per-SIMD shapes (168 registers): the unpredicated form spilled 9 there
     glists = [[(pi, m3, u) for u in range(bs['U']) for pi, p in bs['cat'].paths for m3 in range(2 * p.l3 + 1)] for bs in bsched]
     NGP = max((len(gl) + 15) // 16 * 16 for gl in glists)   # rows of the LDS buffer (padded to 16 entries per load)
     NK = NGP // 16
+    # rows of the NEXT x block requested one block ahead (xp): only where the extra U d1 vector registers fit the budget of the
+    # occupancy this shape runs at (same live-state estimate as bwd_cfg below; the lmax-3 shapes sit at 256 already and
+    # spilled 200+ registers with it)
+    _maxd1 = max(2 * c_.l1 + 1 for c_ in cats)
+    _maxd3 = max(2 * p_.l3 + 1 for p_ in spec.paths)
+    _live = 12 * _maxd1 + 32 + NSH + 4 * NK + 16 + 4 * _maxd3 + 35
+    _budget = 168 if (2 * 8 * 2 * 1024 + 4 * (2 * NGP * 64 + NSH * 64) <= 53 * 1024 and _live <= 168) else 256
+    _xp_regs = max([4 * b_['U'] * (2 * b_['cat'].l1 + 1) for b_ in bsched[1:]] or [0])
+    _budget -= 24   # margin: the estimate is a lower bound of what hipcc's allocator ends up with
+    XPF = VMORD and len(bsched) > 1 and _live + _xp_regs + 8 <= _budget and not OPTS.get('noxpf')
+    # the hoisted slab request keeps the staging registers live across the block boundary: same budget rule
+    HOIST = VMORD and _live + 16 + 8 <= _budget and not OPTS.get('nohoist')
     A(f'  constexpr int NGP = {NGP}, NK = {NK}, NSUB = {NSB};   // NSUB: sub-steps of the reverse kernel\'s weight stream')
     A('  __shared__ __attribute__((aligned(16))) float s_g[NWV][2][NGP * 16];')
     A('  f32x4 gpre[NK];')
     A('  const float *gnode = g_out + (size_t)((diag & 256) ? (node & 63) : node) * DOUT + 4 * (lane & 3);')
     for ci, gl in enumerate(glists):   # per-lane offsets of the entries this lane fetches (-1: none)
         for k in range((len(gl) + 15) // 16):
-            offs = [out_index(spec.paths[gl[q][0]], gl[q][1]) + 16 * gl[q][2] if q < len(gl) else -1 for q in range(16 * k, 16 * k + 16)]
+            # (vmord: padding entries load offset 0 unconditionally -- their LDS rows are never read -- instead of a predicated
+            # load behind a zero fill, whose write-after-write hazard made the compiler wait for every pending gather)
+            offs = [out_index(spec.paths[gl[q][0]], gl[q][1]) + 16 * gl[q][2] if q < len(gl) else (0 if GUNC else -1) for q in range(16 * k, 16 * k + 16)]
             A(f'  static const int32_t GOFF{ci}_{k}[16] = {{' + ', '.join(str(o) for o in offs) + '};')
             A(f'  const int goff{ci}_{k} = GOFF{ci}_{k}[lane >> 2];')
 
@@ -352,14 +380,19 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         gl = glists[ci]
         U_ = bsched[ci]['U']
         for k in range((len(gl) + 15) // 16):
-            dg = '(diag & 8) ? f32x4{scale, scale, scale, scale} : ' if exp else ''
-            A(f'{ind}gpre[{k}] = {dg}(goff{ci}_{k} < 0) ? f32x4{{0.f, 0.f, 0.f, 0.f}} : '
-              f'*reinterpret_cast<const f32x4 *>(gnode + goff{ci}_{k} + {16 * U_} * ({cb_expr})) * scale;')
+            # (the 1/denominator factor is applied when the entries are PARKED: multiplied here, the value is needed at once and
+            # the compiler answers with s_waitcnt vmcnt(0) right behind the load -- a full gather latency, and a drain of the
+            # g_xe stores and the source-row prefetch in front of it, at the top of every block: round 4, `vmord`)
+            dg = '(diag & 8) ? f32x4{1.f, 1.f, 1.f, 1.f} : ' if exp else ''
+            sc_ = ' * scale' if not GRAW else ''
+            pred = '' if GUNC else f'(goff{ci}_{k} < 0) ? f32x4{{0.f, 0.f, 0.f, 0.f}} : '
+            A(f'{ind}gpre[{k}] = {dg}{pred}*reinterpret_cast<const f32x4 *>(gnode + goff{ci}_{k} + {16 * U_} * ({cb_expr})){sc_};')
 
     def emit_g_park(ind, ci, buf_expr):
         gl = glists[ci]
         for k in range((len(gl) + 15) // 16):
-            A(f'{ind}*reinterpret_cast<f32x4 *>(&s_g[wave][{buf_expr}][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]) = gpre[{k}];')
+            sc_ = ' * scale' if GRAW else ''
+            A(f'{ind}*reinterpret_cast<f32x4 *>(&s_g[wave][{buf_expr}][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]) = gpre[{k}]{sc_};')
 
     def g_row(ci, pi, m3, u):
         return glists[ci].index((pi, m3, u))
@@ -421,6 +454,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     emit_g_park('  ', 0, '0')
     A('  stage_store(0);')
     A('  __syncthreads();')
+    if HOIST:
+        A('  if (1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(1, 1);   // the first block\'s first sub-step does not request its slab itself')
     # fp16 terms, g_h2 += W2 g_w^T: the operand g_w[edge, channel] = sum_abc C_abc G_c x_a Y_b of a path is bounded by
     # (sum |C|) max|G| max|x| max|Y|; every edge (= operand column = lane) scales its g_w by the power of two that puts
     # this bound below 2^F16_TOP -- no entry can overflow fp16, and entries down to 2^-17 of the bound keep all 22 bits
@@ -443,21 +478,35 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         if ci > 0:   # (the first x block's rows were requested in the prologue)
             A(f'  const float *xs{ci} = x + (size_t)s_src * DX + {cat.x_off} + 4 * g;')
             A(f'  f32x4 xr{ci}[{U}][{d1}], xn{ci}[{U}][{d1}];')
-            for u in range(U):
+            for u in range(U):   # (XPF: requested at the top of the previous x block's last block, one block ahead like the others)
                 for m in range(d1):
-                    A(f'  xr{ci}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {16 * u + m * cat.mul});')
+                    A(f'  xr{ci}[{u}][{m}] = ' + (f'xp{ci}[{u}][{m}];' if XPF else f'*reinterpret_cast<const f32x4 *>(xs{ci} + {16 * u + m * cat.mul});'))
+        if XPF and ci + 1 < len(bsched):   # the next x block's first rows are requested from inside this one: declared here
+            cat_n, U_n = bsched[ci + 1]['cat'], bsched[ci + 1]['U']
+            d1_n = 2 * cat_n.l1 + 1
+            A(f'  const float *xs{ci + 1}p = x + (size_t)s_src * DX + {cat_n.x_off} + 4 * g;')
+            A(f'  f32x4 xp{ci + 1}[{U_n}][{d1_n}];')
         A(f'  for (int cb = 0; cb < {ncb}; ++cb) {{')
         A(f'    f32x4 (&xr)[{U}][{d1}] = xr{ci};')
         A(f'    f32x4 gx[{U}][{d1}];')
         for u in range(U):
             for m in range(d1):
                 A(f'    gx[{u}][{m}] = f32x4{{0.f, 0.f, 0.f, 0.f}};')
+        def emit_next_xblock_rows(ind):
+            for u in range(U_n):
+                for m in range(d1_n):
+                    A(f'{ind}xp{ci + 1}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci + 1}p + {16 * u + m * cat_n.mul});')
         if ncb > 1:
             A(f'    if (cb + 1 < {ncb}' + (' && !(diag & 64)' if exp else '') + ') {')
             for u in range(U):
                 for m in range(d1):
                     A(f'      xn{ci}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {16 * U} * (cb + 1) + {16 * u + m * cat.mul});')
+            if XPF and ci + 1 < len(bsched):
+                A('    } else {')
+                emit_next_xblock_rows('      ')
             A('    }')
+        elif XPF and ci + 1 < len(bsched):
+            emit_next_xblock_rows('    ')
         A('    const float *gl_ = &s_g[wave][gbuf][4 * g];')
         # next block's g_out entries: this x block's next block, or the first block of the next x block
         if ncb > 1:
@@ -469,9 +518,10 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A('    }')
         elif ci + 1 < len(bsched):
             emit_g_loads('    ', ci + 1, '0')
-        for (ta, tb) in bs['steps']:
+        for si_, (ta, tb) in enumerate(bs['steps']):
             A('    {')
-            A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, buf ^ 1);')
+            if not (HOIST and si_ == 0):   # (first sub-step of a block: requested at the end of the previous block / the prologue)
+                A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, buf ^ 1);')
             # hipcc's machine scheduler, left alone, sinks the prefetch loads next to their use (zero overlap) and
             # interleaves the phases until ~200 VGPRs spill: pin the prefetch at the top and fence the phases
             A('      __builtin_amdgcn_sched_barrier(0);')
@@ -558,6 +608,9 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A('      buf ^= 1;')
             A('      ++sidx;')
             A('    }')
+        if HOIST:   # the next block's first sub-step: its slab request goes out BEFORE this block's stores
+            A('    if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, buf ^ 1);')
+            A('    __builtin_amdgcn_sched_barrier(0);')
         A('    if (g_xe && valid' + (' && !(diag & 16)' if exp else '') + ') {')
         for u in range(U):
             if gxe_std:

@@ -155,7 +155,7 @@ int snet_fused_plan_create(const snet_conv_plan *plan, const snet_mlp_plan *mlp,
   // the reverse kernels can run the MLP's two hidden layers backwards themselves when the basis fits one
   // 16-row operand tile and its rows are whole float4s
   snet::MlpHidden hid = snet::mlp_plan_hidden(mlp);
-  if (hid.w0 != nullptr && !(hid.nb <= 16 && hid.nb % 4 == 0)) hid.w0 = nullptr;
+  if (hid.w0 != nullptr && !(hid.nb <= 16 && hid.nb % 4 == 0 && (hid.act == 0 || hid.act == 1))) hid.w0 = nullptr;   // (the tail's fast activation pair: silu / tanh)
   int32_t exps[3] = {0, 0, 0}, exps_f[3];
   void *dev_b = nullptr;
   if (snet::pack_fused_slabs(snet::mlp_plan_w2_host(mlp), k->wn, k->n_sub, k->sub_cols, terms, nullptr, &dev, exps_f) != 0 ||

@@ -190,8 +190,44 @@ __device__ __forceinline__ float lane_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), K));
 }
 
+// Activation ids (sevenn/_const.py:33-47): 0 silu, 1 tanh, 2 relu, 3 abs, 4 ssp (softplus - ln 2, sevenn/nn/activation.py:7),
+// 5 sigmoid, 6 elu.  The e3nn `normalize2mom` constant of each travels beside the id (model_spec.ACT_CST).
+constexpr int N_ACT = 7;
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  switch (act) {
+    case 0: return z / (1.0f + expf(-z));                                     // silu
+    case 1: return tanhf(z);
+    case 2: return fmaxf(z, 0.0f);                                            // relu
+    case 3: return fabsf(z);
+    case 4: return fmaxf(z, 0.0f) + log1pf(expf(-fabsf(z))) - 0.69314718055994531f;   // softplus(z) - ln 2, overflow-free form
+    case 5: return 1.0f / (1.0f + expf(-z));                                  // sigmoid
+    default: return z > 0.0f ? z : expm1f(z);                                 // elu (alpha = 1)
+  }
+}
+// derivative of the activation wrt its pre-activation (relu / abs at 0: torch's convention, 0)
+__device__ __forceinline__ float act_grad(float z, int act) {
+  switch (act) {
+    case 0: {
+      const float s = 1.0f / (1.0f + expf(-z));
+      return s * (1.0f + z * (1.0f - s));
+    }
+    case 1: {
+      const float t = tanhf(z);
+      return 1.0f - t * t;
+    }
+    case 2: return z > 0.0f ? 1.0f : 0.0f;
+    case 3: return z > 0.0f ? 1.0f : (z < 0.0f ? -1.0f : 0.0f);
+    case 4: return 1.0f / (1.0f + expf(-z));                                  // d softplus = sigmoid
+    case 5: {
+      const float s = 1.0f / (1.0f + expf(-z));
+      return s * (1.0f - s);
+    }
+    default: return z > 0.0f ? 1.0f : expf(z);
+  }
+}
 // activation value and derivative in one go, hardware exp2 / rcp (~1 ulp each) instead of the IEEE division and
-// libm exp of act_fwd / act_grad (~25 instructions per call): for code that evaluates it per element of a tile
+// libm exp of act_fwd / act_grad (~25 instructions per call): for code that evaluates it per element of a tile.
+// silu and tanh only (the fused reverse kernels' hidden-layer tail: snet_fused_plan_create leaves the tail off for the others)
 __device__ __forceinline__ void act_both_fast(float z, int act, float &f, float &g) {
   if (act == 0) {  // silu: s = sigmoid(z); f = z s; g = s (1 + z (1 - s))
     const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
@@ -202,24 +238,11 @@ __device__ __forceinline__ void act_both_fast(float z, int act, float &f, float 
     g = 1.0f - f * f;
   }
 }
-// activation value alone, same hardware exp2 / rcp form (the hidden radial layers evaluate 128 of these per row: with libm exp
-// and the IEEE division their kernel was bound by exactly that, 0.19 ms per launch)
+// activation value alone, same hardware exp2 / rcp form for silu (the hidden radial layers evaluate 128 of these per row: with
+// libm exp and the IEEE division their kernel was bound by exactly that, 0.19 ms per launch); every other id: act_fwd
 __device__ __forceinline__ float act_fwd_fast(float z, int act) {
   if (act == 0) return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
-  return tanhf(z);
-}
-__device__ __forceinline__ float act_fwd(float z, int act) {
-  if (act == 0) return z / (1.0f + expf(-z));  // silu
-  return tanhf(z);
-}
-// derivative of the activation wrt its pre-activation
-__device__ __forceinline__ float act_grad(float z, int act) {
-  if (act == 0) {
-    const float s = 1.0f / (1.0f + expf(-z));
-    return s * (1.0f + z * (1.0f - s));
-  }
-  const float t = tanhf(z);
-  return 1.0f - t * t;
+  return act_fwd(z, act);
 }
 
 }  // namespace snet

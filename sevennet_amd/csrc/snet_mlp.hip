@@ -716,7 +716,7 @@ extern "C" int snet_radial_mlp_plan_create(int32_t nb, int32_t h1, int32_t h2, i
   SNET_REQUIRE(plan != nullptr && W0_host && W1_host && W2_host, "snet_radial_mlp_plan_create: null argument");
   SNET_REQUIRE(h1 == H && h2 == H, "snet_radial_mlp_plan_create: fused kernels need hidden widths [64, 64]");
   SNET_REQUIRE(nb >= 1 && nb <= 32 && wn >= 1, "snet_radial_mlp_plan_create: need 1 <= n_basis <= 32, wn >= 1");
-  SNET_REQUIRE(act == 0 || act == 1, "snet_radial_mlp_plan_create: unknown activation");
+  SNET_REQUIRE(act >= 0 && act < snet::N_ACT, "snet_radial_mlp_plan_create: unknown activation");
   SNET_REQUIRE(mode == 0 || mode == 1, "snet_radial_mlp_plan_create: mode 0 (fp32 MFMA) or 1 (bf16 x6 split)");
   auto *p = new snet_mlp_plan;
   p->nb = nb; p->wn = wn; p->act = act; p->mode = mode; p->cst = cst;

@@ -298,7 +298,7 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
   m->cutoff = r.f32(); m->cutoff_on = r.f32(); m->act_cst = r.f32();
   good = r.ok && m->n_layers > 0 && m->n_layers < 64 && m->n_basis > 0 && m->n_basis <= 16 && m->n_species > 0 &&
          m->n_species <= 4096 && m->lmax >= 0 && m->lmax <= 3 && (m->normalize == 0 || m->normalize == 1) &&
-         (m->act_radial == 0 || m->act_radial == 1) && (m->cutoff_kind == 0 || m->cutoff_kind == 1) &&
+         (m->act_radial >= 0 && m->act_radial < 7) && (m->cutoff_kind == 0 || m->cutoff_kind == 1) &&
          (m->n_scale == 1 || m->n_scale == m->n_species) && m->d0 > 0 && m->d0 <= (1 << 16) && m->cutoff > 0.f;
   if (good) {
     m->coeffs = r.farr(m->n_basis);

@@ -469,7 +469,7 @@ extern "C" int snet_gate_bwd_norm(const float *y, const float *g_out, float *g_y
   return 0;
 }
 extern "C" int snet_act_fwd(const float *z, float *a, int64_t n, int32_t act, float cst, void *stream) {
-  SNET_REQUIRE(act == 0 || act == 1, "snet_act_fwd: unknown activation");
+  SNET_REQUIRE(act >= 0 && act < snet::N_ACT, "snet_act_fwd: unknown activation");
   if (n <= 0) return 0;
   act_fwd_kernel<<<grid_for(n), 256, 0, static_cast<hipStream_t>(stream)>>>(z, a, n, act, cst);
   SNET_CHECK_LAUNCH("snet_act_fwd");
@@ -477,7 +477,7 @@ extern "C" int snet_act_fwd(const float *z, float *a, int64_t n, int32_t act, fl
 }
 extern "C" int snet_act_bwd(const float *z, const float *g_a, float *g_z, int64_t n, int32_t act, float cst,
                             void *stream) {
-  SNET_REQUIRE(act == 0 || act == 1, "snet_act_bwd: unknown activation");
+  SNET_REQUIRE(act >= 0 && act < snet::N_ACT, "snet_act_bwd: unknown activation");
   if (n <= 0) return 0;
   act_bwd_kernel<<<grid_for(n), 256, 0, static_cast<hipStream_t>(stream)>>>(z, g_a, g_z, n, act, cst);
   SNET_CHECK_LAUNCH("snet_act_bwd");

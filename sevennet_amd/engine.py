@@ -174,10 +174,10 @@ class _Linear:
     """Device weights of one LinearSpec (per-GEMM [K,N] and [N,K] copies) and its launch plan:
     per-irrep GEMMs that write distinct output blocks are grouped into one launch."""
 
-    def __init__(self, spec: LinearSpec, flat: np.ndarray, dev, split: bool = True, modal_idx: int = -1):
+    def __init__(self, spec: LinearSpec, flat: np.ndarray, dev, split: bool = True, modal_idx: int = -1, bias_flat=None):
         self.spec = spec
         self.split = split
-        b = linear_modal_bias(spec, flat, modal_idx)   # multi-modal linear: constant row bias for this channel
+        b = linear_modal_bias(spec, flat, modal_idx, bias_flat)   # constant row: multi-modal one-hot for this channel + o3.Linear bias
         self.bias = None if b is None else torch.from_numpy(b).to(dev)
         mats = linear_weight_matrices(spec, flat)
         if split:  # bf16 x 6 split-precision MFMA: weights live on the device as packed B fragments
@@ -328,7 +328,7 @@ class HipForceEngine:
         with torch.cuda.device(self.dev):
             emb = linear_weight_matrices(sp.embed, sd[sp.embed.name])
             assert len(emb) == 1
-            eb = linear_modal_bias(sp.embed, sd[sp.embed.name], mi)
+            eb = linear_modal_bias(sp.embed, sd[sp.embed.name], mi, sd.get(sp.embed.bias_name))
             table = emb[0] if eb is None else emb[0] + eb[None, :]
             self.embed_table = torch.from_numpy(np.ascontiguousarray(table, np.float32)).to(self.dev)  # [n_species, dim0]
             self.layers = []
@@ -337,8 +337,8 @@ class HipForceEngine:
                 L = type('L', (), {})()
                 L.spec = ls
                 L.sc = _Linear(ls.sc, sd[ls.sc.name], self.dev, split, mi) if ls.sc is not None else None
-                L.si1 = _Linear(ls.si1, sd[ls.si1.name], self.dev, split, mi)
-                L.si2 = _Linear(ls.si2, sd[ls.si2.name], self.dev, split, mi)
+                L.si1 = _Linear(ls.si1, sd[ls.si1.name], self.dev, split, mi, sd.get(ls.si1.bias_name))
+                L.si2 = _Linear(ls.si2, sd[ls.si2.name], self.dev, split, mi, sd.get(ls.si2.bias_name))
                 L.mlp_w, L.mlp_wt = [], []
                 rw = ls.radial_weights(sd)   # last layer restricted to the live paths' columns
                 for i in range(len(ls.mlp_dims) - 1):
@@ -421,12 +421,21 @@ class HipForceEngine:
                 h0, sc0 = species_only_tables(sp, sd, mi)
                 self.h0_table = torch.from_numpy(h0).to(self.dev)
                 self.sc0_table = None if sc0 is None else torch.from_numpy(sc0).to(self.dev)
-            self.ro_v = None
-            if fold_readout:
-                v, self.ro_c = folded_readout(sp, sd, mi)
-                self.ro_v = torch.from_numpy(v).to(self.dev)
-            self.ro1 = _Linear(sp.readout1, sd[sp.readout1.name], self.dev, split, mi)
-            self.ro2 = _Linear(sp.readout2, sd[sp.readout2.name], self.dev, split, mi)
+            self.ro_v = self.ro_fcn = None
+            if sp.readout_fcn_dims:   # `readout_as_fcn`: e3nn FullyConnectedNet on the final scalars (exact fp32 GEMMs + activations)
+                d = sp.readout_fcn_dims
+                ws = [np.ascontiguousarray(sd[f'readout_FCN.fcn.layer{i}.weight'] / np.sqrt(d[i]), dtype=np.float32) for i in range(len(d) - 1)]
+                self.ro_fcn = type('F', (), {})()
+                self.ro_fcn.dims = d
+                self.ro_fcn.w = [torch.from_numpy(w).to(self.dev) for w in ws]
+                self.ro_fcn.wt = [torch.from_numpy(np.ascontiguousarray(w.T)).to(self.dev) for w in ws]
+                self.ro_fcn.act, self.ro_fcn.cst = ACT_ID[sp.readout_fcn_act], ACT_CST[sp.readout_fcn_act]
+            else:
+                if fold_readout:
+                    v, self.ro_c = folded_readout(sp, sd, mi)
+                    self.ro_v = torch.from_numpy(v).to(self.dev)
+                self.ro1 = _Linear(sp.readout1, sd[sp.readout1.name], self.dev, split, mi, sd.get(sp.readout1.bias_name))
+                self.ro2 = _Linear(sp.readout2, sd[sp.readout2.name], self.dev, split, mi, sd.get(sp.readout2.bias_name))
             sc_v, sh_v = sp.rescale_vectors(sd, mi)
             self.n_scale = len(sc_v)
             self.scale = torch.tensor(sc_v, dtype=torch.float32, device=self.dev)
@@ -685,7 +694,32 @@ class HipForceEngine:
             e_atom = self._new(N)
             energy = torch.empty(1, dtype=torch.float64, device=self.dev)
             d_ro = sp.readout1.dim_in
-            if self.ro_v is not None:   # folded readout: fp64 dot product + rescale + energy sum in one pass
+            if self.ro_fcn is not None:   # readout_as_fcn: x -> act(x W0) cst -> ... -> e, then its reverse (nn/linear.py:145-180)
+                F = self.ro_fcn
+                d, nl = F.dims, len(F.w)
+                zs, a = [], x
+                for i in range(nl):
+                    z = self._new(N, d[i + 1])
+                    self._gemm(a, F.w[i], z, N, 1, d[i], d[i + 1], d[i], 0, d[i + 1], 0)
+                    if i + 1 < nl:
+                        a = self._new(N, d[i + 1])
+                        _lib.check(lib.snet_act_fwd(_ptr(z), _ptr(a), z.numel(), F.act, F.cst, st), 'snet_act_fwd')
+                        zs.append(z)
+                _lib.check(lib.snet_rescale_reduce(_ptr(z), _ptr(g.types), _ptr(self.scale), _ptr(self.shift),
+                                                   self.n_scale, N, _ptr(e_atom), _ptr(energy), st), 'snet_rescale_reduce')
+                gz = self._new(N, 1)
+                if self.n_scale > 1:
+                    _lib.check(lib.snet_embed_rows(_ptr(self.scale), _ptr(g.types), _ptr(gz), N, 1, st), 'snet_embed_rows')
+                else:
+                    gz.fill_(self.scale0)
+                for i in range(nl - 1, -1, -1):
+                    ga = self._new(N, d[i])
+                    self._gemm(gz, F.wt[i], ga, N, 1, d[i + 1], d[i], d[i + 1], 0, d[i], 0)
+                    if i > 0:
+                        _lib.check(lib.snet_act_bwd(_ptr(zs[i - 1]), _ptr(ga), _ptr(ga), ga.numel(), F.act, F.cst, st), 'snet_act_bwd')
+                    gz = ga
+                g_x = gz
+            elif self.ro_v is not None:   # folded readout: fp64 dot product + rescale + energy sum in one pass
                 _lib.check(lib.snet_readout_energy(_ptr(x), N, d_ro, _ptr(self.ro_v), self.ro_c, _ptr(g.types), _ptr(self.scale),
                                                    _ptr(self.shift), self.n_scale, _ptr(e_atom), _ptr(energy), st), 'snet_readout_energy')
                 g_x = self._new(N, d_ro)

@@ -64,7 +64,7 @@ def _arr(a):
     return np.ascontiguousarray(a, dtype='<f4').tobytes()
 
 
-def _write_linear(spec: LinearSpec, flat, modal_idx: int = -1) -> bytes:
+def _write_linear(spec: LinearSpec, flat, modal_idx: int = -1, bias_flat=None) -> bytes:
     """dim_in dim_out n_species n_blocks n_zero n_zero_in
     | blocks[l in_off mul_in out_off mul_out species accumulate]
     | zero[off len] (output columns no block writes) | zero_in[off len] (input columns no block reads)
@@ -83,7 +83,7 @@ def _write_linear(spec: LinearSpec, flat, modal_idx: int = -1) -> bytes:
         out.append(_i(off, ln))
     for m in mats:
         out.append(_arr(m))
-    bias = linear_modal_bias(spec, flat, modal_idx)
+    bias = linear_modal_bias(spec, flat, modal_idx, bias_flat)   # modal one-hot share + o3.Linear bias: one constant row
     out.append(_i(0 if bias is None else 1))
     if bias is not None:
         out.append(_arr(bias))
@@ -94,6 +94,9 @@ def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray],
     """modal: fidelity channel of a multi-modal model, fixed in the file like the reference's
     `prepare_modal_deploy` (sevenn/scripts/deploy.py:42-47)."""
     sp = build_model_spec(config)
+    if sp.readout_fcn_dims:
+        raise NotImplementedError('readout_as_fcn models run through the Python host (HipForceEngine); the .snet format of the '
+                                  'native sequencer carries the two-linear readout only')
     mi = sp.modal_index(modal)
     sd = {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, 'detach') else v, dtype=np.float64)
           for k, v in state_dict.items()}
@@ -105,7 +108,7 @@ def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray],
     scale_v, shift_v = sp.rescale_vectors(sd, mi)
     n_scale = len(scale_v)
     embed = linear_weight_matrices(sp.embed, sd[sp.embed.name])[0]
-    eb = linear_modal_bias(sp.embed, sd[sp.embed.name], mi)
+    eb = linear_modal_bias(sp.embed, sd[sp.embed.name], mi, sd.get(sp.embed.bias_name))
     if eb is not None:
         embed = embed + eb[None, :]
     out = [MAGIC,
@@ -128,14 +131,14 @@ def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray],
         for i in range(3):
             out.append(_arr(rw[i] / np.sqrt(d[i])))
         out.append(_write_linear(ls.sc, sd[ls.sc.name] if ls.sc is not None else None))
-        out.append(_write_linear(ls.si1, sd[ls.si1.name], mi))
-        out.append(_write_linear(ls.si2, sd[ls.si2.name], mi))
+        out.append(_write_linear(ls.si1, sd[ls.si1.name], mi, sd.get(ls.si1.bias_name)))
+        out.append(_write_linear(ls.si2, sd[ls.si2.name], mi, sd.get(ls.si2.bias_name)))
         out.append(_i(len(ls.gate.segs)))
         for s in ls.gate.segs:
             out.append(_i(s.kind, s.in_off, s.out_off, s.mul, s.l, s.gate_off, s.act))
             out.append(_f(ACT_CST[inv_act[s.act]]))
-    out.append(_write_linear(sp.readout1, sd[sp.readout1.name], mi))
-    out.append(_write_linear(sp.readout2, sd[sp.readout2.name]))
+    out.append(_write_linear(sp.readout1, sd[sp.readout1.name], mi, sd.get(sp.readout1.bias_name)))
+    out.append(_write_linear(sp.readout2, sd[sp.readout2.name], -1, sd.get(sp.readout2.bias_name)))
     h0, sc0 = species_only_tables(sp, sd, mi)
     out.append(_i(h0.shape[1], 0 if sc0 is None else sc0.shape[1]))
     out.append(_arr(h0))

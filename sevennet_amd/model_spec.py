@@ -26,9 +26,13 @@ import numpy as np
 
 from .irreps import Irreps, infer_irreps_out
 
-ACT_ID = {'silu': 0, 'tanh': 1}
-# e3nn normalize2mom constants as baked into the reference's deployed models
-ACT_CST = {'silu': 1.6791767923989418, 'tanh': 1.5937334472592695}
+# activation ids of the kernels (csrc/snet_common.h::act_fwd): every entry of sevenn/_const.py:33-47
+ACT_ID = {'silu': 0, 'tanh': 1, 'relu': 2, 'abs': 3, 'ssp': 4, 'sigmoid': 5, 'elu': 6}
+# e3nn normalize2mom constants: silu / tanh as baked into the reference's deployed models; the others are what e3nn's
+# `moment(f, 2) ** -0.5` evaluates to (1e6 float64 samples of torch's CPU generator seeded with 0 -- reproduced offline with
+# this image's torch: it returns the baked silu value to the last digit, tanh to 3e-16)
+ACT_CST = {'silu': 1.6791767923989418, 'tanh': 1.5937334472592695, 'relu': 1.4163393446331367, 'abs': 1.001110600838467,
+           'ssp': 1.878204668541552, 'sigmoid': 1.8467055342154763, 'elu': 1.2467863885570512}
 
 DEFAULT_CONFIG = dict(  # sevenn/_const.py:95-135
     cutoff=4.5, channel=32, irreps_manual=False, lmax=1, lmax_edge=-1, lmax_node=-1,
@@ -38,6 +42,7 @@ DEFAULT_CONFIG = dict(  # sevenn/_const.py:95-135
     act_radial='silu', act_scalar={'e': 'silu', 'o': 'tanh'}, act_gate={'e': 'silu', 'o': 'tanh'},
     weight_nn_hidden_neurons=[64, 64], conv_denominator=1.0, self_connection_type='nequip',
     _normalize_sph=True, shift=0.0, scale=1.0, version='0.12.0', use_bias_in_linear=False,
+    readout_as_fcn=False, readout_fcn_hidden_neurons=[30, 30], readout_fcn_activation='relu',
 )
 
 
@@ -69,6 +74,17 @@ class LinearSpec:
     # (out_off, mul_out, w_off, alpha) per 0e output block, weights [n_modal, mul_out] row-major
     n_modal: int = 0
     modal_bias: List[Tuple[int, int, int, float]] = field(default_factory=list)
+    # o3.Linear(biases=True) (`use_bias_in_linear`, sevenn/model_build.py:468,518): one bias per channel of every 0e output
+    # block, concatenated in irreps_out order -> (out_off, mul, offset into the bias tensor)
+    bias_blocks: List[Tuple[int, int, int]] = field(default_factory=list)
+
+    @property
+    def bias_name(self) -> str:
+        return self.name[:-len('weight')] + 'bias'
+
+    @property
+    def n_bias(self) -> int:
+        return sum(m for _, m, _ in self.bias_blocks)
 
     @property
     def dim_in(self):
@@ -79,7 +95,8 @@ class LinearSpec:
         return self.irreps_out.dim
 
 
-def make_linear(name: str, irreps_in: Irreps, irreps_out: Irreps, n_species: int = 0, n_modal: int = 0) -> LinearSpec:
+def make_linear(name: str, irreps_in: Irreps, irreps_out: Irreps, n_species: int = 0, n_modal: int = 0,
+                biases: bool = False) -> LinearSpec:
     """o3.Linear (n_species=0) or FCTP(x, n_species x 0e) -> per-irrep GEMM list.
     Normalisation: 1/sqrt(total fan-in of the output block).
     n_modal > 0: the reference appends `n_modal x 0e` to the input irreps (a separate last block), so
@@ -113,19 +130,34 @@ def make_linear(name: str, irreps_in: Irreps, irreps_out: Irreps, n_species: int
         w_off += n_modal * mo
     zero = [(out_off[j], irreps_out[j][0] * (2 * irreps_out[j][1] + 1))
             for j in range(len(irreps_out)) if j not in seen]
-    return LinearSpec(name, irreps_in, irreps_out, blocks, zero, n_species, w_off, n_modal, modal_bias)
+    bias_blocks, b_off = [], 0
+    if biases:
+        for j, (mo, l, p) in enumerate(irreps_out):
+            if (l, p) == (0, 1):
+                bias_blocks.append((out_off[j], mo, b_off))
+                b_off += mo
+    return LinearSpec(name, irreps_in, irreps_out, blocks, zero, n_species, w_off, n_modal, modal_bias, bias_blocks)
 
 
-def linear_modal_bias(spec: LinearSpec, flat: np.ndarray, modal_idx: int):
-    """Constant the modal one-hot contributes to every output row for fidelity channel `modal_idx`
-    ([dim_out] float32), or None for a linear without modal inputs."""
-    if not spec.n_modal:
+def linear_modal_bias(spec: LinearSpec, flat: np.ndarray, modal_idx: int, bias_flat=None, dtype=np.float32):
+    """Constant row every output of this linear carries ([dim_out], or None when there is none): what the modal one-hot
+    contributes for fidelity channel `modal_idx` (multi-modal linears) plus the o3.Linear bias (`use_bias_in_linear`,
+    `bias_flat` = the layer's `.bias` tensor)."""
+    if not spec.n_modal and not spec.bias_blocks:
         return None
-    flat = np.asarray(flat, dtype=np.float64).reshape(-1)
     bias = np.zeros(spec.dim_out, np.float64)
-    for off, mo, w_off, alpha in spec.modal_bias:
-        bias[off:off + mo] = flat[w_off:w_off + spec.n_modal * mo].reshape(spec.n_modal, mo)[modal_idx] * alpha
-    return bias.astype(np.float32)
+    if spec.n_modal:
+        flat = np.asarray(flat, dtype=np.float64).reshape(-1)
+        for off, mo, w_off, alpha in spec.modal_bias:
+            bias[off:off + mo] = flat[w_off:w_off + spec.n_modal * mo].reshape(spec.n_modal, mo)[modal_idx] * alpha
+    if spec.bias_blocks:
+        if bias_flat is None:
+            raise KeyError(f'state_dict is missing {spec.bias_name}')
+        b = np.asarray(bias_flat, dtype=np.float64).reshape(-1)
+        assert b.size == spec.n_bias, (spec.bias_name, b.size, spec.n_bias)
+        for off, mo, b_off in spec.bias_blocks:
+            bias[off:off + mo] += b[b_off:b_off + mo]
+    return bias.astype(dtype)
 
 
 def linear_weight_matrices(spec: LinearSpec, flat: np.ndarray):
@@ -144,7 +176,7 @@ def linear_weight_matrices(spec: LinearSpec, flat: np.ndarray):
     return out
 
 
-def linear_rows_fp64(spec: LinearSpec, flat: np.ndarray, x: np.ndarray, species=None, modal_idx: int = -1) -> np.ndarray:
+def linear_rows_fp64(spec: LinearSpec, flat: np.ndarray, x: np.ndarray, species=None, modal_idx: int = -1, bias_flat=None) -> np.ndarray:
     """y = Linear(x) for ir_mul rows x[n, dim_in], evaluated in fp64 on the host (load time only).
     species[n] selects the weight slice of a per-species (FCTP) linear."""
     flat = np.asarray(flat, dtype=np.float64).reshape(-1)
@@ -158,9 +190,9 @@ def linear_rows_fp64(spec: LinearSpec, flat: np.ndarray, x: np.ndarray, species=
         for m in range(2 * b.l + 1):
             y[rows, b.out_off + m * b.mul_out:b.out_off + (m + 1) * b.mul_out] += \
                 x[rows, b.in_off + m * b.mul_in:b.in_off + (m + 1) * b.mul_in] @ w
-    if spec.n_modal:
-        for off, mo, w_off, alpha in spec.modal_bias:
-            y[:, off:off + mo] += flat[w_off:w_off + spec.n_modal * mo].reshape(spec.n_modal, mo)[modal_idx] * alpha
+    b = linear_modal_bias(spec, flat, modal_idx, bias_flat, dtype=np.float64)
+    if b is not None:
+        y += b[None, :]
     return y
 
 
@@ -172,9 +204,9 @@ def species_only_tables(sp: 'ModelSpec', sd, modal_idx: int):
     whole energy error, profiles/r04_energy_error_attribution.txt) are replaced by a table lookup.
     -> (h0[n_species, dx0] float32, sc0[n_species, gin0] float32 or None)"""
     ls = sp.layers[0]
-    e64 = linear_rows_fp64(sp.embed, sd[sp.embed.name], np.eye(sp.num_species), None, modal_idx)   # fp64 embedding rows
+    e64 = linear_rows_fp64(sp.embed, sd[sp.embed.name], np.eye(sp.num_species), None, modal_idx, sd.get(sp.embed.bias_name))   # fp64 embedding rows
     species = np.arange(sp.num_species)
-    h0 = linear_rows_fp64(ls.si1, sd[ls.si1.name], e64, species, modal_idx)
+    h0 = linear_rows_fp64(ls.si1, sd[ls.si1.name], e64, species, modal_idx, sd.get(ls.si1.bias_name))
     sc0 = linear_rows_fp64(ls.sc, sd[ls.sc.name], e64, species, modal_idx) if ls.sc is not None else None
     return h0.astype(np.float32), (None if sc0 is None else sc0.astype(np.float32))
 
@@ -186,7 +218,9 @@ def folded_readout(sp: 'ModelSpec', sd, modal_idx: int):
     d = sp.readout1.dim_in
 
     def chain(x):
-        return linear_rows_fp64(sp.readout2, sd[sp.readout2.name], linear_rows_fp64(sp.readout1, sd[sp.readout1.name], x, None, modal_idx))
+        return linear_rows_fp64(sp.readout2, sd[sp.readout2.name],
+                                linear_rows_fp64(sp.readout1, sd[sp.readout1.name], x, None, modal_idx, sd.get(sp.readout1.bias_name)),
+                                None, -1, sd.get(sp.readout2.bias_name))
 
     c = chain(np.zeros((1, d)))[0, 0]
     v = chain(np.eye(d))[:, 0] - c
@@ -430,6 +464,16 @@ class ModelSpec:
     readout2: LinearSpec
     type_map: Dict[int, int] = field(default_factory=dict)
     n_modal: int = 0
+    # `readout_as_fcn` (sevenn/model_build.py:124-138, nn/linear.py:145-180): the readout is an e3nn FullyConnectedNet
+    # [dim_in] + hidden + [1] with activation `readout_fcn_act` instead of the two linears; None otherwise
+    readout_fcn_dims: Optional[List[int]] = None
+    readout_fcn_act: str = 'relu'
+
+    def linears(self) -> List[LinearSpec]:
+        out = [self.embed]
+        for ls in self.layers:
+            out += [l_ for l_ in (ls.sc, ls.si1, ls.si2) if l_ is not None]
+        return out + ([] if self.readout_fcn_dims else [self.readout1, self.readout2])
 
     def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
         s: Dict[str, Tuple[int, ...]] = {}
@@ -443,8 +487,15 @@ class ModelSpec:
             for i in range(len(ls.mlp_dims_full) - 1):
                 s[f'{ls.t}_convolution.weight_nn.layer{i}.weight'] = (ls.mlp_dims_full[i], ls.mlp_dims_full[i + 1])
             s[ls.si2.name] = (ls.si2.numel,)
-        s[self.readout1.name] = (self.readout1.numel,)
-        s[self.readout2.name] = (self.readout2.numel,)
+        if self.readout_fcn_dims:
+            for i in range(len(self.readout_fcn_dims) - 1):
+                s[f'readout_FCN.fcn.layer{i}.weight'] = (self.readout_fcn_dims[i], self.readout_fcn_dims[i + 1])
+        else:
+            s[self.readout1.name] = (self.readout1.numel,)
+            s[self.readout2.name] = (self.readout2.numel,)
+        for lin in self.linears():
+            if lin.bias_blocks:
+                s[lin.bias_name] = (lin.n_bias,)
         if self.n_modal:  # ModalWiseRescale (scale.py:196-363): per species, optionally per modal
             ns = self.num_species
             s['rescale_atomic_energy.shift'] = (self.n_modal, ns) if self.config.get('use_modal_wise_shift') else (ns,)
@@ -507,10 +558,7 @@ def old_convolution_order(version) -> bool:
 def build_model_spec(config: dict) -> ModelSpec:
     cfg = dict(DEFAULT_CONFIG)
     cfg.update(config)
-    if cfg.get('use_bias_in_linear'):
-        raise NotImplementedError('use_bias_in_linear=True is not supported by the HIP engine')
-    if cfg.get('readout_as_fcn'):
-        raise NotImplementedError('readout_as_fcn models are not supported by the HIP engine yet')
+    ub = bool(cfg.get('use_bias_in_linear'))
     n_modal = int(cfg.get('_number_of_modalities', 0)) if cfg.get('use_modality') else 0
     if cfg.get('use_modality') and n_modal < 2:
         raise ValueError('use_modality needs _number_of_modalities >= 2')
@@ -544,7 +592,7 @@ def build_model_spec(config: dict) -> ModelSpec:
     if cfg['radial_basis'].get('radial_basis_name', 'bessel') != 'bessel':
         raise NotImplementedError(f"radial basis {cfg['radial_basis'].get('radial_basis_name')!r}: the HIP engine "
                                   "implements 'bessel' (sevenn/nn/edge_embedding.py:81-103)")
-    for key in ('act_radial',):
+    for key in ('act_radial',) + (('readout_fcn_activation',) if cfg.get('readout_as_fcn') else ()):
         if cfg[key] not in ACT_ID:
             raise ValueError(f"{key}={cfg[key]!r}: supported activations are {sorted(ACT_ID)}")
     for key in ('act_scalar', 'act_gate'):
@@ -556,7 +604,7 @@ def build_model_spec(config: dict) -> ModelSpec:
     hidden = list(cfg['weight_nn_hidden_neurons'])
 
     irreps_x = Irreps(f'{ch}x0e') if manual is False else manual[0]
-    embed = make_linear('onehot_to_feature_x.linear.weight', Irreps(f'{ns}x0e'), irreps_x, n_modal=m_embed)
+    embed = make_linear('onehot_to_feature_x.linear.weight', Irreps(f'{ns}x0e'), irreps_x, n_modal=m_embed, biases=ub)
     layers = []
     for t in range(L):
         parity_mode = 'full'
@@ -576,11 +624,11 @@ def build_model_spec(config: dict) -> ModelSpec:
             sc = None
         else:
             raise ValueError(f'Unknown self_connection_type found: {sc_types[t]}')
-        si2 = make_linear(f'{t}_self_interaction_2.linear.weight', irreps_out_tp, gate.irreps_in, n_modal=m_si2)
+        si2 = make_linear(f'{t}_self_interaction_2.linear.weight', irreps_out_tp, gate.irreps_in, n_modal=m_si2, biases=ub)
         live, w_cols = prune_unread_paths(conv, si2) if cfg.get('_prune_unread_paths', True) else (conv, None)
         layers.append(LayerSpec(
             t, irreps_x, irreps_out, sc,
-            make_linear(f'{t}_self_interaction_1.linear.weight', irreps_x, irreps_x, n_modal=m_si1),
+            make_linear(f'{t}_self_interaction_1.linear.weight', irreps_x, irreps_x, n_modal=m_si1, biases=ub),
             live, [n_basis] + hidden + [live.weight_numel], si2, gate, float(denom[t]),
             conv_full=conv, mlp_dims_full=[n_basis] + hidden + [conv.weight_numel], w_cols=w_cols))
         irreps_x = irreps_out
@@ -590,9 +638,11 @@ def build_model_spec(config: dict) -> ModelSpec:
         cfg, float(cfg['cutoff']), ns, lmax_edge, bool(cfg['_normalize_sph']), irreps_sh, n_basis,
         ckind, int(cf.get('poly_cut_p_value', 6)), float(cf.get('cutoff_on', 0.0)), cfg['act_radial'],
         embed, layers,
-        make_linear('reduce_input_to_hidden.linear.weight', irreps_x, hid, n_modal=m_out),
-        make_linear('reduce_hidden_to_energy.linear.weight', hid, Irreps('1x0e')),
-        {int(k): int(v) for k, v in tm.items()}, n_modal)
+        make_linear('reduce_input_to_hidden.linear.weight', irreps_x, hid, n_modal=m_out, biases=ub),
+        make_linear('reduce_hidden_to_energy.linear.weight', hid, Irreps('1x0e'), biases=ub),
+        {int(k): int(v) for k, v in tm.items()}, n_modal,
+        ([irreps_x.dim] + [int(v) for v in cfg.get('readout_fcn_hidden_neurons', [30, 30])] + [1]) if cfg.get('readout_as_fcn') else None,
+        str(cfg.get('readout_fcn_activation', 'relu')))
 
 
 # --------------------------------------------------------------------------- #

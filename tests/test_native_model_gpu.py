@@ -53,6 +53,9 @@ CASES = {
     'unit_o3_l2': dict(cfg='unit', over={}, cutoff=4.0, nsp=4),                    # per-species FCTP self-connection
     'unit_so3_l2_linear': dict(cfg='unit', over={'is_parity': False, 'self_connection_type': 'linear'}, cutoff=4.0, nsp=4),
     'mini_7net0': dict(cfg='mini', over={}, cutoff=5.0, nsp=2),
+    # o3.Linear biases (folded into the .snet linears' constant rows, the species tables and the readout vector) + other activations
+    'unit_bias_ssp_abs': dict(cfg='unit', over={'use_bias_in_linear': True, 'act_radial': 'ssp', 'act_scalar': {'e': 'ssp', 'o': 'abs'},
+                                                'act_gate': {'e': 'ssp', 'o': 'abs'}}, cutoff=4.0, nsp=4),
 }
 
 
