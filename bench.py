@@ -263,7 +263,7 @@ def main():
     else:
         from sevennet_amd.parallel import HaloExchange, build_brick_graph
         bg = build_brick_graph(pos, cell, species_of(cfg, n_atoms), cfg['cutoff'], world, rank)
-        graph = build_graph(bg.types, bg.edge_index, bg.edge_vec, n_local=bg.n_local, device=dev,
+        graph = build_graph(bg.types, bg.edge_index, bg.edge_vec, n_local=bg.n_local, n_interior=bg.n_interior, device=dev,
                             num_species=eng.spec.num_species)
         use_native = a.halo == 'native' or (a.halo == 'auto' and backend == 'nccl')
         if use_native:
@@ -466,6 +466,7 @@ def main():
                                                           else f'torch.distributed all_to_all_single ({backend})')),
                        'halo_overlap': (None if not dist_mode else bool(getattr(halo, 'overlap', True))),
                        'ghost_rows_rank0': (None if not dist_mode else int(graph.n_total - graph.n_local)),
+                       'halo_exposed_ms': (None if not dist_mode else round(halo_ms, 3)),   # main-stream time inside the exchange calls (start: enqueue only; finish: the wait)
                        'halo_ms_per_step_rank0': (None if not dist_mode else round(halo_ms, 4)),
                        'halo_exchanges_per_step': (None if not dist_mode else halo_n),
                        'halo_bytes_per_step_rank0': (None if not dist_mode else halo_bytes),

@@ -313,6 +313,9 @@ int snet_permute_cols(const float *x, const int32_t *col_idx, float *out, int64_
 int snet_rescale_reduce(const float *e_scaled, const int32_t *types, const float *scale, const float *shift,
                         int32_t n_scale, int64_t n_nodes, float *e_atom, double *energy, void *stream);
 
+/* out[i] = in[i] + delta over n int32 entries (tile pointers of a sub-list of the reverse kernels' tile list) */
+int snet_i32_shift(const int32_t *in, int32_t delta, int32_t *out, int64_t n, void *stream);
+
 /* Folded readout (a3 + a7 + a8 in one pass): the reference's two readout linears (reduce_input_to_hidden,
  * reduce_hidden_to_energy; sevenn/model_build.py, nn/linear.py:94-100) have no nonlinearity between them, so
  * a host may fold them to one vector v[dim] and constant c (fp64, at load time).  For the first n rows:
@@ -345,23 +348,27 @@ int snet_gather_rows(const float *x, const int32_t *idx, float *out, int64_t n_i
 int snet_scatter_add_rows(const float *x, const int32_t *idx, float *y, int64_t n_idx, int32_t dim,
                           void *stream);
 
-/* ---- f1: neighbor list on the GPU (fully periodic cells) ---------------------
+/* ---- f1: neighbor list on the GPU ---------------------------------------------
  * replaces the host graph build unlabeled_atoms_to_graph / _graph_build_{ase,matscipy}
  * (sevenn/train/dataload.py:32-129) and yields the CSR-by-center edge layout directly.
  * cell_host[9] row-major lattice vectors (HOST), positions / wrapped positions fp64 (device).
- * Every cell height must be >= cutoff (rc 4 otherwise: use a host list for such tiny cells).
+ * pbc_host[3] (HOST, nullable = fully periodic): open axes are neither wrapped nor imaged; frac_range_host[6] (HOST,
+ * required with an open axis) = lower (3) and upper (3) bound of the atoms' fractional coordinates, read for open axes.
+ * A periodic cell may be thinner than the cutoff (it then meets itself through ceil(cutoff / height) images).
  * Sequence: snet_nl_grid (bins per axis) -> snet_nl_bin (wrapped positions, image index, bin id)
  * -> [caller sorts atoms by bin id: order[], bin_start[]] -> snet_nl_count -> [exclusive scan:
  * row_ptr] -> snet_nl_fill (src, center, edge_vec fp32, optional image shifts).              */
-int snet_nl_grid(const double *cell_host, double cutoff, int32_t *nbins_host);
-int snet_nl_bin(const double *cell_host, double cutoff, const double *pos, int64_t n_atoms, double *wpos,
-                int32_t *wrap, int32_t *cell_id, void *stream);
-int snet_nl_count(const double *cell_host, double cutoff, const double *wpos, const int32_t *cell_id,
-                  const int32_t *order, const int32_t *bin_start, int64_t n_atoms, int32_t *count, void *stream);
-int snet_nl_fill(const double *cell_host, double cutoff, const double *wpos, const int32_t *wrap,
-                 const int32_t *cell_id, const int32_t *order, const int32_t *bin_start, int64_t n_atoms,
-                 const int32_t *row_ptr, int32_t *src, int32_t *center, float *edge_vec, int32_t *shifts,
-                 void *stream);
+int snet_nl_grid(const double *cell_host, double cutoff, const int32_t *pbc_host, const double *frac_range_host,
+                 int32_t *nbins_host);
+int snet_nl_bin(const double *cell_host, double cutoff, const int32_t *pbc_host, const double *frac_range_host,
+                const double *pos, int64_t n_atoms, double *wpos, int32_t *wrap, int32_t *cell_id, void *stream);
+int snet_nl_count(const double *cell_host, double cutoff, const int32_t *pbc_host, const double *frac_range_host,
+                  const double *wpos, const int32_t *cell_id, const int32_t *order, const int32_t *bin_start,
+                  int64_t n_atoms, int32_t *count, void *stream);
+int snet_nl_fill(const double *cell_host, double cutoff, const int32_t *pbc_host, const double *frac_range_host,
+                 const double *wpos, const int32_t *wrap, const int32_t *cell_id, const int32_t *order,
+                 const int32_t *bin_start, int64_t n_atoms, const int32_t *row_ptr, int32_t *src, int32_t *center,
+                 float *edge_vec, int32_t *shifts, void *stream);
 
 /* ---- whole-model sequencer ------------------------------------------------------------------
  * replaces, for a native (C++) host, `model.forward(input_dict)` + `torch::autograd::grad(...)` of
@@ -392,6 +399,19 @@ int snet_model_meta(const snet_model *model, const char *key, char *value, int32
  * on forces[n_total,3] (and virial_atom) so ghost rows end up in their owners; 0: ghost rows are
  * left to the host (LAMMPS folds them itself with reverse_comm when newton_pair is on). */
 typedef int (*snet_halo_fn)(void *user, float *x, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
+/* Topology cache: with it on, snet_model_eval keeps what depends on the edge list only (tile list of the reverse kernels --
+ * its construction reads a count back, i.e. synchronises the stream --, the edges grouped by source, per-species row lists)
+ * across evaluations for as long as the caller passes the SAME device index arrays (row_ptr, src, eperm, w_row; same counts)
+ * and has not called snet_model_topology_changed.  A caller that rewrites those arrays in place must call it.  Off by default.
+ * snet_model_eval_syncs: stream synchronisations issued inside snet_model_eval since the model was loaded (diagnostic). */
+/* Bricks of a spatial decomposition that number their local atoms INTERIOR FIRST (rows [0, n_interior) have no ghost source;
+ * sevennet_amd.parallel.BrickGraph.n_interior) let the sequencer run the interior rows of the fused convolutions while the
+ * ghost exchange of the layer is in flight (library halo installed with snet_model_set_rccl_halo; second stream inside the
+ * model).  0 (default) = no split.  Applies to the following evaluations until set again.                              */
+int snet_model_set_interior(snet_model *model, int64_t n_interior);
+int snet_model_set_topology_cache(snet_model *model, int32_t enable);
+int snet_model_topology_changed(snet_model *model);
+int64_t snet_model_eval_syncs(const snet_model *model);
 int snet_model_set_halo(snet_model *model, snet_halo_fn forward, snet_halo_fn reverse, void *user,
                         int32_t fold_forces);
 /* ---- a12, native: the ghost exchange itself, on RCCL (xGMI point-to-point), no host staging --------------
@@ -423,6 +443,11 @@ int64_t snet_halo_ghost_rows(const snet_halo *halo);
 int64_t snet_halo_send_rows(const snet_halo *halo);
 int snet_halo_forward(void *halo, float *x, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
 int snet_halo_reverse(void *halo, float *gx, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
+/* snet_halo_reverse in two halves, for hosts that overlap the exchange with work that still WRITES the local rows
+ * (interior / boundary split of the convolution): _exchange reads the ghost rows gx[n_local ..] only and stages what the peers
+ * return inside the halo; _accumulate adds the staged rows into gx[.. n_local].  One exchange may be staged at a time.   */
+int snet_halo_reverse_exchange(void *halo, const float *gx, int64_t n_total, int64_t n_local, int32_t dim, void *stream);
+int snet_halo_reverse_accumulate(void *halo, float *gx, int32_t dim, void *stream);
 int snet_model_set_rccl_halo(snet_model *model, snet_halo *halo, int32_t fold_forces);
 /* In-process stand-in for the RCCL communicator -- TEST infrastructure for one GPU: W host threads play W ranks; a
  * send posts {device pointer, ready event}, the matching receive copies device to device on the receiver's stream
@@ -484,6 +509,10 @@ int snet_md_create(snet_model *model, snet_md_host **host);
 int snet_md_nodes(int32_t inum, const int32_t *ilist, int32_t nall, const void *tag, int32_t tag_bytes,
                   int32_t ghost_mode, int32_t *node_to_atom_out, int64_t *n_nodes_out);
 void snet_md_destroy(snet_md_host *host);
+/* One-shot hint: the NEXT snet_md_compute call gets the same neighbor list as the previous one (LAMMPS `neighbor->ago > 0`:
+ * same inum / ilist / numneigh / firstneigh / nall / tags / types) -- the flattened list, node maps and species uploaded then
+ * are reused, only the positions travel (the edge set inside the cutoff is still re-derived from them every step).       */
+int snet_md_list_unchanged(snet_md_host *host);
 int snet_md_compute(snet_md_host *host, int32_t inum, const int32_t *ilist, const int32_t *numneigh,
                     const int32_t *const *firstneigh, int32_t nall, const double *x, const int32_t *type,
                     const void *tag, int32_t tag_bytes, const int32_t *type_map, int32_t ntypes, int32_t ghost_mode,

@@ -213,6 +213,7 @@ void PairE3GNNHip::compute(int eflag, int vflag) {
   node_to_atom.resize(nall);
   int64_t n_nodes = 0, n_edges = 0;
   double e = 0.0, v[6] = {0, 0, 0, 0, 0, 0};
+  if (neighbor->ago > 0) snet_md_list_unchanged(host);   // no rebuild since the last step: the uploaded list is reused
   const int rc = snet_md_compute(host, list->inum, list->ilist, list->numneigh, list->firstneigh, nall, &atom->x[0][0],
                                  atom->type, atom->tag, (int)sizeof(tagint), map, atom->ntypes, ghost_mode, eflag_atom,
                                  vflag_either, vflag_atom, &atom->f[0][0], &e, v, eflag_atom ? eatom : nullptr,

@@ -112,13 +112,13 @@ SIGNATURES = {
     'snet_readout_grad': (C.c_int, [c_f64p, C.c_int32, c_i32p, c_f32p, C.c_int32, C.c_int64, c_f32p, c_stream]),
     'snet_edge_force': (C.c_int, [c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_int64, c_f32p, c_f32p,
                                   c_f64p, c_stream]),
-    'snet_nl_grid': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int32)]),
-    'snet_nl_bin': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.c_void_p, C.c_int64, C.c_void_p, c_i32p, c_i32p,
-                              c_stream]),
-    'snet_nl_count': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.c_void_p, c_i32p, c_i32p, c_i32p, C.c_int64,
-                                c_i32p, c_stream]),
-    'snet_nl_fill': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.c_void_p, c_i32p, c_i32p, c_i32p, c_i32p,
-                               C.c_int64, c_i32p, c_i32p, c_i32p, c_f32p, c_i32p, c_stream]),
+    'snet_nl_grid': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    'snet_nl_bin': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p, C.c_int64,
+                              C.c_void_p, c_i32p, c_i32p, c_stream]),
+    'snet_nl_count': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p, c_i32p,
+                                c_i32p, c_i32p, C.c_int64, c_i32p, c_stream]),
+    'snet_nl_fill': (C.c_int, [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p, c_i32p,
+                               c_i32p, c_i32p, c_i32p, C.c_int64, c_i32p, c_i32p, c_i32p, c_f32p, c_i32p, c_stream]),
     'snet_gather_rows': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
     'snet_scatter_add_rows': (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int64, C.c_int32, c_stream]),
     'snet_model_load': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -127,6 +127,11 @@ SIGNATURES = {
     'snet_model_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32), C.c_int32]),
     'snet_model_meta': (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32]),
+    'snet_i32_shift': (C.c_int, [c_i32p, C.c_int32, c_i32p, C.c_int64, c_stream]),
+    'snet_model_set_interior': (C.c_int, [C.c_void_p, C.c_int64]),
+    'snet_model_set_topology_cache': (C.c_int, [C.c_void_p, C.c_int32]),
+    'snet_model_topology_changed': (C.c_int, [C.c_void_p]),
+    'snet_model_eval_syncs': (C.c_int64, [C.c_void_p]),
     'snet_model_set_halo': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     'snet_model_eval': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p,
                                   c_i32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, c_stream]),
@@ -144,6 +149,8 @@ SIGNATURES = {
     'snet_halo_send_rows': (C.c_int64, [C.c_void_p]),
     'snet_halo_forward': (C.c_int, [C.c_void_p, c_f32p, C.c_int64, C.c_int64, C.c_int32, c_stream]),
     'snet_halo_reverse': (C.c_int, [C.c_void_p, c_f32p, C.c_int64, C.c_int64, C.c_int32, c_stream]),
+    'snet_halo_reverse_exchange': (C.c_int, [C.c_void_p, c_f32p, C.c_int64, C.c_int64, C.c_int32, c_stream]),
+    'snet_halo_reverse_accumulate': (C.c_int, [C.c_void_p, c_f32p, C.c_int32, c_stream]),
     'snet_model_set_rccl_halo': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'snet_edge_pairs': (C.c_int, [c_i32p, c_i32p, c_f32p, C.c_int64, C.c_int64, c_i32p, c_i32p, C.POINTER(C.c_int64),
                                   c_stream]),
@@ -161,6 +168,7 @@ SIGNATURES = {
     'snet_md_create': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     'snet_md_destroy': (None, [C.c_void_p]),
     'snet_md_nodes': (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]),
+    'snet_md_list_unchanged': (C.c_int, [C.c_void_p]),
     'snet_md_compute': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

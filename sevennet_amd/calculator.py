@@ -252,10 +252,11 @@ class SevenNetCalculator(Calculator):
         cell = np.asarray(cell, np.float64).reshape(3, 3)
         # per-species row lists only where a per-species (FCTP) self-connection reads them
         ns = self.model.spec.num_species if self.model.needs_species_rows else 0
-        if gpu_neighbor_supported(cell, pbc, self.cutoff):  # bulk periodic cell: cell list on the GPU
-            g = build_graph_gpu(types, positions, cell, self.cutoff, device=str(self.device), num_species=ns)
+        if len(numbers) and gpu_neighbor_supported(cell, pbc, self.cutoff, np.asarray(positions, np.float64)):
+            # cell list on the GPU: bulk cells, slabs / wires / molecules (open axes), cells thinner than the cutoff
+            g = build_graph_gpu(types, positions, cell, self.cutoff, device=str(self.device), num_species=ns, pbc=pbc)
             n_edges = g.n_edges
-        else:  # molecules, slabs, cells smaller than the cutoff: host KD-tree
+        else:  # singular cells only: host list
             ei, ev, _ = neighbor_list(positions, cell, pbc, self.cutoff)
             g = build_graph(types, ei, ev, device=str(self.device), num_species=ns)
             n_edges = int(ei.shape[1])

@@ -247,6 +247,7 @@ struct snet_halo {
   int world = 1, rank = 0;
   std::vector<int64_t> send_cnt, recv_cnt, send_off, recv_off;  // rows per peer and their prefix sums
   int64_t n_send = 0, n_ghost = 0, n_seg = 0;
+  int32_t seg_dim = 0;  // row width of the reverse exchange staged in seg_buf (0: none)
   Dev<int32_t> send_idx, red_rows, red_perm, red_ptr;
   int64_t max_send_row = -1;  // send_idx entries are local rows: max_send_row < n_local must hold on every call
   Dev<int32_t> ghost_perm, ghost_inv;      // optional: k-th received row (peer order) <-> ghost row (host's node order)
@@ -446,8 +447,10 @@ int snet_halo_forward(void *user, float *x, int64_t n_total, int64_t n_local, in
   return 0;
 }
 
-// snet_halo_fn: add ghost rows gx[n_local ..] into their owners' rows
-int snet_halo_reverse(void *user, float *gx, int64_t n_total, int64_t n_local, int32_t dim, void *stream) {
+// Reverse exchange in two halves so that a host can overlap it with work that WRITES the local rows (round 4: interior /
+// boundary split of the convolution): _exchange reads the ghost rows gx[n_local ..] only, sends them home and reduces what
+// the peers return into the halo's own staging rows; _accumulate adds those into the owners' rows gx[.. n_local].
+int snet_halo_reverse_exchange(void *user, const float *gx, int64_t n_total, int64_t n_local, int32_t dim, void *stream) {
   auto *h = static_cast<snet_halo *>(user);
   SNET_REQUIRE(h != nullptr && gx != nullptr && dim > 0, "snet_halo_reverse: bad argument");
   SNET_REQUIRE(n_total - n_local == h->n_ghost, "snet_halo_reverse: ghost row count does not match the exchange plan");
@@ -474,11 +477,25 @@ int snet_halo_reverse(void *user, float *gx, int64_t n_total, int64_t n_local, i
   const int rc2 = x_group_end(h->comm);
   if (rc) return rc;
   if (rc2) return rc2;
-  if (h->n_seg > 0) {
+  if (h->n_seg > 0)
     if (int e = snet_segment_sum_rows(h->recv_buf.p, h->red_ptr.p, h->red_perm.p, h->n_seg, dim, h->seg_buf.p, stream)) return e;
-    if (int e = snet_scatter_add_rows(h->seg_buf.p, h->red_rows.p, gx, h->n_seg, dim, stream)) return e;
-  }
+  h->seg_dim = dim;
   return 0;
+}
+
+int snet_halo_reverse_accumulate(void *user, float *gx, int32_t dim, void *stream) {
+  auto *h = static_cast<snet_halo *>(user);
+  SNET_REQUIRE(h != nullptr && gx != nullptr && dim > 0, "snet_halo_reverse_accumulate: bad argument");
+  SNET_REQUIRE(h->seg_dim == dim, "snet_halo_reverse_accumulate: no exchange of this row width is staged");
+  h->seg_dim = 0;
+  if (h->n_seg > 0) return snet_scatter_add_rows(h->seg_buf.p, h->red_rows.p, gx, h->n_seg, dim, stream);
+  return 0;
+}
+
+// snet_halo_fn: add ghost rows gx[n_local ..] into their owners' rows
+int snet_halo_reverse(void *user, float *gx, int64_t n_total, int64_t n_local, int32_t dim, void *stream) {
+  if (int rc = snet_halo_reverse_exchange(user, gx, n_total, n_local, dim, stream)) return rc;
+  return snet_halo_reverse_accumulate(user, gx, dim, stream);
 }
 
 // convenience: install the exchange on a model (ghost forces / atomic virials folded by the same hooks)

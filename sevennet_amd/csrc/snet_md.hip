@@ -291,6 +291,11 @@ struct snet_md_host {
   std::vector<int32_t> node_to_atom, types_host;
   std::vector<int32_t> dense_tag;
   std::unordered_map<int64_t, int32_t> sparse_tag;
+  // the neighbor list of the previous call, already flattened and uploaded: reused when the pair style reports that LAMMPS
+  // has not rebuilt its list since (snet_md_list_unchanged; neighbor->ago > 0)
+  bool reuse_next = false, have_list = false;
+  int32_t last_inum = -1, last_nall = -1, last_ghost_mode = -1;
+  int64_t last_slots = 0;
 };
 
 extern "C" int snet_md_create(snet_model *model, snet_md_host **out) {
@@ -344,6 +349,15 @@ extern "C" int snet_md_nodes(int32_t inum, const int32_t *ilist, int32_t nall, c
   return 0;
 }
 
+// The next snet_md_compute sees the SAME neighbor list as the previous one (same inum, ilist, numneigh, firstneigh, nall,
+// tags and types: LAMMPS `neighbor->ago > 0`, i.e. no rebuild since): the flattened list, node maps and species already on
+// the device are reused and only the positions travel.  One-shot: applies to the next call only.
+extern "C" int snet_md_list_unchanged(snet_md_host *h) {
+  SNET_REQUIRE(h != nullptr, "snet_md_list_unchanged: null host");
+  h->reuse_next = true;
+  return 0;
+}
+
 extern "C" int snet_md_compute(snet_md_host *h, int32_t inum, const int32_t *ilist, const int32_t *numneigh,
                                const int32_t *const *firstneigh, int32_t nall, const double *x, const int32_t *type,
                                const void *tag, int32_t tag_bytes, const int32_t *type_map, int32_t ntypes,
@@ -368,6 +382,14 @@ extern "C" int snet_md_compute(snet_md_host *h, int32_t inum, const int32_t *ili
   snet_model_info(h->model, &cutoff, &n_species, nullptr, nullptr, 0);
 
   // ---- host: tag -> graph node, node -> LAMMPS atom, species per node, flattened neighbor rows
+  // (skipped when the pair style said the list is the one of the previous call: ilist / firstneigh / tags / types / nall
+  // only change when LAMMPS rebuilds its neighbor list; the positions -- and with them the edges inside the cutoff -- change
+  // every step and are handled below)
+  const bool reuse = h->reuse_next && h->have_list && h->last_inum == inum && h->last_nall == nall && h->last_ghost_mode == ghost_mode;
+  h->reuse_next = false;
+  int64_t n_slots = h->last_slots;
+  if (!reuse) {
+  n_slots = 0;
   int64_t max_tag = 0;
   for (int a = 0; a < nall; ++a) max_tag = tag_of(a) > max_tag ? tag_of(a) : max_tag;
   const bool dense = max_tag <= 8LL * nall + 1024;
@@ -384,7 +406,6 @@ extern "C" int snet_md_compute(snet_md_host *h, int32_t inum, const int32_t *ili
   };
   h->node_to_atom.clear();
   h->types_host.clear();
-  int64_t n_slots = 0;
   for (int ii = 0; ii < inum; ++ii) {
     const int i = ilist[ii];
     SNET_REQUIRE(i >= 0 && i < nall, "snet_md_compute: ilist entry out of range");
@@ -407,12 +428,10 @@ extern "C" int snet_md_compute(snet_md_host *h, int32_t inum, const int32_t *ili
         h->node_to_atom.push_back(j);
         h->types_host.push_back(sp);
       }
-  const int64_t NT = (int64_t)h->node_to_atom.size(), N = inum;
-  if (node_to_atom_out) memcpy(node_to_atom_out, h->node_to_atom.data(), (size_t)NT * 4);  // the halo hooks need it
-  if (n_nodes_out) *n_nodes_out = NT;
-  const size_t small = (size_t)(inum + 1) + nall + NT + inum;
+  const int64_t NT0 = (int64_t)h->node_to_atom.size();
+  const size_t small = (size_t)(inum + 1) + nall + NT0 + inum;
   SNET_REQUIRE(h->h_small.ensure(small) && h->h_neigh.ensure((size_t)n_slots + 1), "snet_md_compute: pinned allocation failed");
-  int32_t *hp_nb = h->h_small.p, *hp_node = hp_nb + inum + 1, *hp_types = hp_node + nall, *hp_ilist = hp_types + NT;
+  int32_t *hp_nb = h->h_small.p, *hp_node = hp_nb + inum + 1, *hp_types = hp_node + nall, *hp_ilist = hp_types + NT0;
   hp_nb[0] = 0;
   for (int ii = 0; ii < inum; ++ii) {
     const int i = ilist[ii];
@@ -421,7 +440,12 @@ extern "C" int snet_md_compute(snet_md_host *h, int32_t inum, const int32_t *ili
     hp_ilist[ii] = i;
   }
   for (int j = 0; j < nall; ++j) hp_node[j] = lookup(tag_of(j));
-  memcpy(hp_types, h->types_host.data(), (size_t)NT * 4);
+  memcpy(hp_types, h->types_host.data(), (size_t)NT0 * 4);
+  }  // !reuse
+  const int64_t NT = (int64_t)h->node_to_atom.size(), N = inum;
+  if (node_to_atom_out) memcpy(node_to_atom_out, h->node_to_atom.data(), (size_t)NT * 4);  // the halo hooks need it
+  if (n_nodes_out) *n_nodes_out = NT;
+  int32_t *hp_nb = h->h_small.p, *hp_node = hp_nb + inum + 1, *hp_types = hp_node + nall, *hp_ilist = hp_types + NT;
 
   // ---- device: upload, filter, CSR by center, grouping by source
   SNET_REQUIRE(h->x.ensure((size_t)nall * 3) && h->node_of.ensure(nall) && h->ilist.ensure(inum) &&
@@ -432,12 +456,16 @@ extern "C" int snet_md_compute(snet_md_host *h, int32_t inum, const int32_t *ili
                "snet_md_compute: device allocation failed");
   bool ok = true;
   ok &= hipMemcpyAsync(h->x.p, x, (size_t)nall * 24, hipMemcpyHostToDevice, st) == hipSuccess;
-  ok &= hipMemcpyAsync(h->nb_ptr.p, hp_nb, (size_t)(inum + 1) * 4, hipMemcpyHostToDevice, st) == hipSuccess;
-  ok &= hipMemcpyAsync(h->node_of.p, hp_node, (size_t)nall * 4, hipMemcpyHostToDevice, st) == hipSuccess;
-  ok &= hipMemcpyAsync(h->types.p, hp_types, (size_t)NT * 4, hipMemcpyHostToDevice, st) == hipSuccess;
-  ok &= hipMemcpyAsync(h->ilist.p, hp_ilist, (size_t)inum * 4, hipMemcpyHostToDevice, st) == hipSuccess;
-  if (n_slots)
-    ok &= hipMemcpyAsync(h->neigh.p, h->h_neigh.p, (size_t)n_slots * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+  if (!reuse) {  // the list of the previous call is still on the device otherwise
+    ok &= hipMemcpyAsync(h->nb_ptr.p, hp_nb, (size_t)(inum + 1) * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok &= hipMemcpyAsync(h->node_of.p, hp_node, (size_t)nall * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok &= hipMemcpyAsync(h->types.p, hp_types, (size_t)NT * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok &= hipMemcpyAsync(h->ilist.p, hp_ilist, (size_t)inum * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (n_slots)
+      ok &= hipMemcpyAsync(h->neigh.p, h->h_neigh.p, (size_t)n_slots * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+    h->have_list = true;
+    h->last_inum = inum; h->last_nall = nall; h->last_ghost_mode = ghost_mode; h->last_slots = n_slots;
+  }
   ok &= hipMemsetAsync(h->cnt.p, 0, (size_t)(NT + 1) * 4, st) == hipSuccess;
   SNET_REQUIRE(ok, "snet_md_compute: upload failed");
   const double cutsq = (double)cutoff * (double)cutoff;

@@ -236,6 +236,25 @@ struct snet_model {
   int32_t *species_rows = nullptr;                       // device, concatenated
   size_t species_rows_cap = 0;
   std::vector<int64_t> species_off, species_cnt;
+  // Topology cache (snet_model_set_topology_cache): what depends on the edge LIST only -- the per-species row lists, the
+  // 16-edge tile list of the reverse kernels (whose construction reads a count back: a stream sync), the grouping of the
+  // edges by source -- is kept across evaluations while the caller's index arrays are the same device buffers and
+  // snet_model_topology_changed has not been called.  A host whose list is rebuilt every step (snet_md_compute filters the
+  // LAMMPS list by the cutoff per step, like pair_e3gnn.cpp:150-200) leaves it off.
+  bool topo_cache = false, topo_valid = false;
+  struct TopoKey { int64_t NT, N, E; const void *row_ptr, *src, *eperm, *w_row; } topo_key{0, 0, 0, nullptr, nullptr, nullptr, nullptr};
+  int32_t *c_tile_ptr = nullptr, *c_tile_node = nullptr, *c_center_t = nullptr, *c_w_row_t = nullptr;
+  size_t c_tile_cap = 0, c_edge_cap = 0, c_node_cap = 0;
+  int64_t c_n_tiles = 0;
+  // interior / boundary split around the ghost exchange (snet_model_set_interior; library halo only)
+  int64_t n_interior = 0;
+  hipStream_t halo_stream = nullptr;
+  hipEvent_t ev_h0 = nullptr, ev_h1 = nullptr;
+  int32_t *c_tile_ptr_b = nullptr;   // tile pointers re-based on the boundary rows' sub-list
+  size_t c_tile_ptr_b_cap = 0;
+  int64_t c_tile_k = 0;              // first tile of the first boundary row
+  std::vector<int32_t> types_prev;  // species of the local atoms the cached row lists were built from
+  int64_t eval_syncs = 0;           // stream synchronisations issued inside snet_model_eval so far (tests / tools)
   // second stream for the radial MLPs (graphs of at most OVERLAP_MAX_EDGES edges, see engine.py)
   hipStream_t side = nullptr;
   hipEvent_t ev_main = nullptr, ev_bwd[2] = {nullptr, nullptr};
@@ -444,7 +463,10 @@ extern "C" void snet_model_destroy(snet_model *m) {
   for (hipEvent_t e : m->ev_w) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : {m->ev_main, m->ev_bwd[0], m->ev_bwd[1]}) if (e) (void)hipEventDestroy(e);
   if (m->side) (void)hipStreamDestroy(m->side);
-  for (void *d : {(void *)m->embed, (void *)m->scale, (void *)m->shift, (void *)m->h0_table, (void *)m->sc0_table, (void *)m->ro_v, (void *)m->arena.base, (void *)m->species_rows})
+  if (m->halo_stream) (void)hipStreamDestroy(m->halo_stream);
+  for (hipEvent_t e : {m->ev_h0, m->ev_h1}) if (e) (void)hipEventDestroy(e);
+  for (void *d : {(void *)m->embed, (void *)m->scale, (void *)m->shift, (void *)m->h0_table, (void *)m->sc0_table, (void *)m->ro_v, (void *)m->c_tile_ptr, (void *)m->c_tile_node,
+                  (void *)m->c_center_t, (void *)m->c_w_row_t, (void *)m->c_tile_ptr_b, (void *)m->arena.base, (void *)m->species_rows})
     if (d) (void)hipFree(d);
   delete m;
 }
@@ -490,6 +512,29 @@ extern "C" int snet_model_set_halo(snet_model *m, snet_halo_fn forward, snet_hal
   return 0;
 }
 
+extern "C" int snet_model_set_interior(snet_model *m, int64_t n_interior) {
+  SNET_REQUIRE(m != nullptr && n_interior >= 0, "snet_model_set_interior: bad argument");
+  if (m->n_interior != n_interior) m->topo_valid = false;   // the tile sub-lists depend on it
+  m->n_interior = n_interior;
+  return 0;
+}
+
+extern "C" int snet_model_set_topology_cache(snet_model *m, int32_t enable) {
+  SNET_REQUIRE(m != nullptr, "snet_model_set_topology_cache: null model");
+  m->topo_cache = enable != 0;
+  m->topo_valid = false;
+  return 0;
+}
+
+extern "C" int snet_model_topology_changed(snet_model *m) {
+  SNET_REQUIRE(m != nullptr, "snet_model_topology_changed: null model");
+  m->topo_valid = false;
+  m->types_prev.clear();
+  return 0;
+}
+
+extern "C" int64_t snet_model_eval_syncs(const snet_model *m) { return m ? m->eval_syncs : -1; }
+
 extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, const int32_t *types,
                                const int32_t *types_host, const int32_t *row_ptr, const int32_t *src,
                                const int32_t *col_ptr, const int32_t *eperm, const float *edge_vec,
@@ -532,6 +577,9 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   for (auto &L : m->layers) need_rows |= L.sc.n_species > 0;
   if (need_rows) {
     SNET_REQUIRE(types_host != nullptr, "snet_model_eval: this model needs types_host (per-species self-connection)");
+    const bool same_types = (int64_t)m->types_prev.size() == N && m->species_rows != nullptr &&
+                            memcmp(m->types_prev.data(), types_host, (size_t)N * 4) == 0;
+    if (!same_types) {
     m->species_rows_host.assign(m->n_species, {});
     for (int64_t i = 0; i < N; ++i) {
       SNET_REQUIRE(types_host[i] >= 0 && types_host[i] < m->n_species, "snet_model_eval: species index out of range");
@@ -555,6 +603,9 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
       o += (int64_t)v.size();
     }
     SNET_REQUIRE(hipStreamSynchronize(st) == hipSuccess, "snet_model_eval: sync");  // host vectors are reused
+    ++m->eval_syncs;
+    m->types_prev.assign(types_host, types_host + N);
+    }
   }
 
   // ---- arena sizing
@@ -607,21 +658,91 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     saved[t].w = A.f(m->layers[t].fused ? (size_t)WR * 64 : (size_t)WR * m->layers[t].wn);
     saved[t].y = A.f((size_t)N * m->layers[t].gin);
   }
+  // topology-only work: rebuilt unless the cache holds it for exactly these index arrays
+  const snet_model::TopoKey key{NT, N, E, row_ptr, src, eperm, pairs ? w_row : nullptr};
+  const bool topo_hit = m->topo_cache && m->topo_valid && memcmp(&key, &m->topo_key, sizeof key) == 0;
   int32_t *tile_ptr = nullptr, *tile_node = nullptr;
   int64_t n_tiles = 0;
   if (any_fused && E > 0) {  // 16-edge tiles of the CSR segments: work list of the fused reverse kernels
-    tile_ptr = reinterpret_cast<int32_t *>(A.f((size_t)N + 64));
-    tile_node = reinterpret_cast<int32_t *>(A.f((size_t)N + (size_t)E / 16 + 64));
-    if ((rc = snet_edge_tiles(row_ptr, N, tile_ptr, tile_node, N + E / 16 + 1, &n_tiles, st))) return rc;
+    if (m->topo_cache) {
+      if (m->c_node_cap < (size_t)N + 64 || m->c_tile_cap < (size_t)N + (size_t)E / 16 + 64) {
+        if (m->c_tile_ptr) (void)hipFree(m->c_tile_ptr);
+        if (m->c_tile_node) (void)hipFree(m->c_tile_node);
+        m->c_tile_ptr = m->c_tile_node = nullptr;
+        m->c_node_cap = (size_t)N + 64;
+        m->c_tile_cap = (size_t)N + (size_t)E / 16 + 64;
+        SNET_REQUIRE(hipMalloc((void **)&m->c_tile_ptr, m->c_node_cap * 4) == hipSuccess &&
+                         hipMalloc((void **)&m->c_tile_node, m->c_tile_cap * 4) == hipSuccess, "snet_model_eval: alloc");
+      }
+      tile_ptr = m->c_tile_ptr;
+      tile_node = m->c_tile_node;
+    } else {
+      tile_ptr = reinterpret_cast<int32_t *>(A.f((size_t)N + 64));
+      tile_node = reinterpret_cast<int32_t *>(A.f((size_t)N + (size_t)E / 16 + 64));
+    }
+    if (topo_hit) {
+      n_tiles = m->c_n_tiles;
+    } else {
+      if ((rc = snet_edge_tiles(row_ptr, N, tile_ptr, tile_node, N + E / 16 + 1, &n_tiles, st))) return rc;
+      ++m->eval_syncs;   // (snet_edge_tiles reads the tile count back)
+      m->c_n_tiles = n_tiles;
+    }
   }
   int32_t *center_t = nullptr, *w_row_t = nullptr;  // edges grouped by source (transposed scalar convolution)
   float *sh_t = nullptr;
   if (any_transposed && E > 0) {
-    center_t = reinterpret_cast<int32_t *>(A.f((size_t)E + 64));
-    w_row_t = reinterpret_cast<int32_t *>(A.f((size_t)E + 64));
+    if (m->topo_cache) {
+      if (m->c_edge_cap < (size_t)E + 64) {
+        if (m->c_center_t) (void)hipFree(m->c_center_t);
+        if (m->c_w_row_t) (void)hipFree(m->c_w_row_t);
+        m->c_center_t = m->c_w_row_t = nullptr;
+        m->c_edge_cap = (size_t)E + 64;
+        SNET_REQUIRE(hipMalloc((void **)&m->c_center_t, m->c_edge_cap * 4) == hipSuccess &&
+                         hipMalloc((void **)&m->c_w_row_t, m->c_edge_cap * 4) == hipSuccess, "snet_model_eval: alloc");
+      }
+      center_t = m->c_center_t;
+      w_row_t = m->c_w_row_t;
+    } else {
+      center_t = reinterpret_cast<int32_t *>(A.f((size_t)E + 64));
+      w_row_t = reinterpret_cast<int32_t *>(A.f((size_t)E + 64));
+    }
     sh_t = A.f((size_t)E * nsh + 64);
-    if ((rc = snet_edges_by_source(row_ptr, N, eperm, pairs ? w_row : nullptr, E, center_t, w_row_t, st))) return rc;
-    if ((rc = snet_gather_rows(sh, eperm, sh_t, E, nsh, st))) return rc;
+    if (!topo_hit && (rc = snet_edges_by_source(row_ptr, N, eperm, pairs ? w_row : nullptr, E, center_t, w_row_t, st))) return rc;
+    if ((rc = snet_gather_rows(sh, eperm, sh_t, E, nsh, st))) return rc;   // (the harmonics change with the positions: every step)
+  }
+  // interior / boundary split: the library's own exchange (stream-safe) on a second stream, rows [0, n_int) have no ghost source
+  const bool lib_halo = has_halo && m->halo_fwd == &snet_halo_forward && m->halo_rev == &snet_halo_reverse;
+  const int64_t n_int = m->n_interior;
+  bool hsplit = lib_halo && n_int > 0 && n_int < N && E > 0 && any_fused && getenv("SNET_NO_HALO_SPLIT") == nullptr;
+  if (hsplit && m->halo_stream == nullptr) {
+    hsplit = hipStreamCreateWithFlags(&m->halo_stream, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&m->ev_h0, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&m->ev_h1, hipEventDisableTiming) == hipSuccess;
+  }
+  int32_t *tile_ptr_b = nullptr;   // boundary rows' tiles: tile_node + k, tile pointers re-based by -k
+  int64_t tile_k = 0;
+  if (hsplit) {
+    if (m->c_tile_ptr_b_cap < (size_t)N + 64) {
+      if (m->c_tile_ptr_b) (void)hipFree(m->c_tile_ptr_b);
+      m->c_tile_ptr_b = nullptr;
+      m->c_tile_ptr_b_cap = (size_t)N + 64;
+      SNET_REQUIRE(hipMalloc((void **)&m->c_tile_ptr_b, m->c_tile_ptr_b_cap * 4) == hipSuccess, "snet_model_eval: alloc");
+    }
+    tile_ptr_b = m->c_tile_ptr_b;
+    if (topo_hit) {
+      tile_k = m->c_tile_k;
+    } else {
+      int32_t k32 = 0;
+      SNET_REQUIRE(hipMemcpyAsync(&k32, tile_ptr + n_int, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                       hipStreamSynchronize(st) == hipSuccess, "snet_model_eval: tile readback failed");
+      ++m->eval_syncs;
+      tile_k = m->c_tile_k = k32;
+      if ((rc = snet_i32_shift(tile_ptr, -k32, tile_ptr_b, N + 1, st))) return rc;
+    }
+  }
+  if (m->topo_cache) {
+    m->topo_key = key;
+    m->topo_valid = true;
   }
   float *gw_buf[2] = {nullptr, nullptr};
   bool gw_busy[2] = {false, false};
@@ -657,11 +778,17 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
       }
       if ((rc = run_linear(m, L.si1, x, h, N, false, false, st))) return rc;
     }
-    if (t > 0 && has_halo)
-      if ((rc = m->halo_fwd(m->halo_user, h, NT, N, L.dx, stream))) {
+    const bool fsplit = hsplit && t > 0 && L.fused != nullptr;
+    if (t > 0 && has_halo) {
+      if (fsplit)  // the ghost rows travel on the halo stream while the hidden radial layers and the interior rows run
+        SNET_REQUIRE(hipEventRecord(m->ev_h0, st) == hipSuccess && hipStreamWaitEvent(m->halo_stream, m->ev_h0, 0) == hipSuccess,
+                     "snet_model_eval: stream ordering failed");
+      if ((rc = m->halo_fwd(m->halo_user, h, NT, N, L.dx, fsplit ? (void *)m->halo_stream : stream))) {
         snet::set_error("snet_model_eval: forward halo callback failed");
         return rc;
       }
+      if (fsplit) SNET_REQUIRE(hipEventRecord(m->ev_h1, m->halo_stream) == hipSuccess, "snet_model_eval: stream ordering failed");
+    }
     float *mid = A.f((size_t)N * L.dmid);
     if (E == 0) SNET_REQUIRE(hipMemsetAsync(mid, 0, (size_t)N * L.dmid * 4, st) == hipSuccess, "snet_model_eval: memset");
     else  // columns of pruned (unread) paths are never written by the tensor-product kernel: defined zeros
@@ -670,7 +797,12 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
                      "snet_model_eval: memset");
     if (L.fused) {  // w = h2 @ W2 is formed inside the tensor-product kernel
       if ((rc = snet_radial_mlp_hidden_fwd(L.mlp_plan, emb_w, WR, saved[t].w, st))) return rc;
-      if ((rc = snet_conv_fwd_fused(L.fused, h, sh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, N, L.conv_scale, mid, st)))
+      const int64_t na = fsplit ? n_int : 0;   // rows [0, na) before the exchange has landed, [na, N) after
+      if (na > 0 && (rc = snet_conv_fwd_fused(L.fused, h, sh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, na, L.conv_scale, mid, st)))
+        return rc;
+      if (fsplit) SNET_REQUIRE(hipStreamWaitEvent(st, m->ev_h1, 0) == hipSuccess, "snet_model_eval: stream ordering failed");
+      if ((rc = snet_conv_fwd_fused(L.fused, h, sh, saved[t].w, pairs ? w_row : nullptr, row_ptr + na, src, N - na, L.conv_scale,
+                                    mid + (size_t)na * L.dmid, st)))
         return rc;
     } else {
       if (ov)
@@ -718,21 +850,48 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
         x_max = A.f((size_t)NT);
         if ((rc = snet_row_absmax(saved[t].h, NT, L.dx, x_max, st))) return rc;
       }
-      if (E > 0 && (rc = snet_conv_bwd_fused(L.fused, saved[t].h, sh, dsh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src,
-                                             tile_ptr, tile_node, n_tiles, L.conv_scale, g_m, g_xe, g_h2,
-                                             tail ? emb : nullptr, tail ? g_emb : nullptr, g_vec, x_max, g_max, st)))
-        return rc;
+      auto bwd_tiles = [&](const int32_t *tp, const int32_t *tn, int64_t nt) -> int {
+        if (E <= 0 || nt <= 0) return 0;
+        return snet_conv_bwd_fused(L.fused, saved[t].h, sh, dsh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, tp, tn, nt,
+                                   L.conv_scale, g_m, g_xe, g_h2, tail ? emb : nullptr, tail ? g_emb : nullptr, g_vec, x_max, g_max, st);
+      };
+      const bool rsplit = hsplit && t > 0;
+      if (!rsplit && (rc = bwd_tiles(tile_ptr, tile_node, n_tiles))) return rc;
       if (t > 0) {
         float *g_h = A.f((size_t)NT * L.dx);
-        if (transposed) {
+        // source rows [a, b) of g_h: the transposed scalar convolution over the edges grouped by source, or the segment sum
+        auto gh_rows = [&](int64_t a, int64_t b) -> int {
+          if (b <= a) return 0;
+          if (transposed)
+            return snet_conv_fwd_fused(L.tfused, g_m, sh_t, saved[t].w, w_row_t, col_ptr + a, center_t, b - a, L.conv_scale,
+                                       g_h + (size_t)a * L.dx, st);
+          return snet_segment_sum_rows_chunked(g_xe, col_ptr + a, eperm, b - a, L.dx, L.gxe_chunks, g_h + (size_t)a * L.dx, st);
+        };
+        if (transposed)
           for (size_t i = 0; i + 1 < L.t_dead.size(); i += 2)
             SNET_REQUIRE(hipMemset2DAsync(g_h + L.t_dead[i], (size_t)L.dx * 4, 0, (size_t)L.t_dead[i + 1] * 4, (size_t)NT, st) ==
                              hipSuccess, "snet_model_eval: memset failed");
-          if ((rc = snet_conv_fwd_fused(L.tfused, g_m, sh_t, saved[t].w, w_row_t, col_ptr, center_t, NT, L.conv_scale, g_h, st)))
-            return rc;
-        } else if ((rc = snet_segment_sum_rows_chunked(g_xe, col_ptr, eperm, NT, L.dx, L.gxe_chunks, g_h, st))) {
-          return rc;
+        if (rsplit) {
+          // boundary tiles hold every edge with a ghost source: they go first, the ghost rows of g_h start travelling at once and
+          // the interior tiles / the local rows run under the exchange (the transposed convolution needs no tiles at all)
+          if (!transposed && (rc = bwd_tiles(tile_ptr_b, tile_node + tile_k, n_tiles - tile_k))) return rc;
+          if ((rc = gh_rows(N, NT))) return rc;
+          SNET_REQUIRE(hipEventRecord(m->ev_h0, st) == hipSuccess && hipStreamWaitEvent(m->halo_stream, m->ev_h0, 0) == hipSuccess,
+                       "snet_model_eval: stream ordering failed");
+          if ((rc = snet_halo_reverse_exchange(m->halo_user, g_h, NT, N, L.dx, m->halo_stream))) return rc;
+          SNET_REQUIRE(hipEventRecord(m->ev_h1, m->halo_stream) == hipSuccess, "snet_model_eval: stream ordering failed");
+          if ((rc = transposed ? bwd_tiles(tile_ptr, tile_node, n_tiles) : bwd_tiles(tile_ptr, tile_node, tile_k))) return rc;
+          if ((rc = gh_rows(0, N))) return rc;
+          if (!tail && (rc = snet_radial_mlp_hidden_bwd(L.mlp_plan, emb, g_h2, E, g_emb, st))) return rc;
+          if (L.sc.present())   // sc^T g_y does not read the ghost gradients: it runs under the exchange too
+            if ((rc = run_linear(m, L.sc, g_y, gx_next, N, true, false, st))) return rc;
+          SNET_REQUIRE(hipStreamWaitEvent(st, m->ev_h1, 0) == hipSuccess, "snet_model_eval: stream ordering failed");
+          if ((rc = snet_halo_reverse_accumulate(m->halo_user, g_h, L.dx, st))) return rc;
+          if ((rc = run_linear(m, L.si1, g_h, gx_next, N, true, L.sc.present(), st))) return rc;
+          std::swap(g_x, gx_next);
+          continue;
         }
+        if ((rc = gh_rows(0, NT))) return rc;
         if (has_halo)
           if ((rc = m->halo_rev(m->halo_user, g_h, NT, N, L.dx, stream))) {
             snet::set_error("snet_model_eval: reverse halo callback failed");

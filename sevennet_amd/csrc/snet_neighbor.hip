@@ -1,13 +1,17 @@
-// GPU neighbor list for fully periodic cells: the graph build that precedes the hot
-// path.  Same conventions as the reference's host graph build (sevenn/train/dataload.py:32-79, ASE
+// GPU neighbor list: the graph build that precedes the hot path.  Any mix of periodic and open axes,
+// any cell height (round 4: thin cells and molecules no longer fall back to the host list).  Same conventions as the reference's host graph build (sevenn/train/dataload.py:32-79, ASE
 // 'ijDS'): every ordered pair within the cutoff, no self edge, edge_vec = r_j - r_i + S.cell, computed
 // in fp64 and stored as fp32 (sevenn/util.py:174-196).  Output is the CSR-by-center layout the
 // convolution kernels consume, so no sort of the edge list is needed afterwards.
 //
-// Cell list in fractional coordinates: nb_k = floor(h_k / rc) bins along lattice direction k (h_k =
-// distance between opposite cell faces), so the 27 surrounding bins cover the cutoff sphere also for
-// triclinic cells.  With nb_k < 3 a bin is its own neighbour through different images: every (bin
-// offset) carries its own image shift, so images are distinct by construction (valid while h_k >= rc).
+// Cell list in fractional coordinates: nb_k = max(1, floor(h_k / rc)) bins along lattice direction k (h_k =
+// distance between opposite cell faces), searched over bin offsets -R_k .. R_k with R_k = ceil(rc / (h_k / nb_k)):
+// R_k = 1 (the 27 surrounding bins cover the cutoff sphere, also for triclinic cells) whenever h_k >= rc; a cell
+// THINNER than the cutoff has one bin and R_k = ceil(rc / h_k) > 1, i.e. it meets itself through several images.
+// Every bin offset carries its own image shift floor((b + d) / nb), so images are distinct by construction.
+// An OPEN (non-periodic) axis is binned over the fractional range the atoms span ([lo, hi], given by the caller),
+// its atoms are not wrapped and offsets that leave the range are skipped (reference: the padded cell of
+// sevenn/train/dataload.py:37-48 has the same effect).
 #include "snet_common.h"
 
 namespace {
@@ -16,6 +20,9 @@ struct Cell {
   double a[9];    // row-major lattice vectors
   double inv[9];  // inverse
   int nb[3];
+  int R[3];       // bin offsets searched on each side
+  int per[3];     // periodic axis?
+  double lo[3], inv_ext[3];  // open axes: fractional lower bound and 1 / extent of the occupied range
   double rc2;
 };
 
@@ -32,10 +39,17 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(Cell C, const double *__res
   int b[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const double fl = floor(f[k]);
-    wrap[3 * i + k] = (int)fl;
-    f[k] -= fl;
-    int q = (int)(f[k] * C.nb[k]);
+    int q;
+    if (C.per[k]) {
+      const double fl = floor(f[k]);
+      wrap[3 * i + k] = (int)fl;
+      f[k] -= fl;
+      q = (int)(f[k] * C.nb[k]);
+    } else {  // open axis: not wrapped, binned over the occupied range
+      wrap[3 * i + k] = 0;
+      q = (int)((f[k] - C.lo[k]) * C.inv_ext[k] * C.nb[k]);
+      q = q < 0 ? 0 : q;
+    }
     b[k] = q < C.nb[k] ? q : C.nb[k] - 1;
   }
   wpos[3 * i + 0] = f[0] * C.a[0] + f[1] * C.a[3] + f[2] * C.a[6];
@@ -62,15 +76,25 @@ __global__ __launch_bounds__(128) void nl_pair_kernel(Cell C, const double *__re
   const int bz = cid % C.nb[2], by = (cid / C.nb[2]) % C.nb[1], bx = cid / (C.nb[2] * C.nb[1]);
   int cnt = 0;
   int64_t out = FILL ? row_ptr[i] : 0;
-  for (int dx = -1; dx <= 1; ++dx) {
-    int cx = bx + dx, sx = 0;
-    if (cx < 0) { cx += C.nb[0]; sx = -1; } else if (cx >= C.nb[0]) { cx -= C.nb[0]; sx = 1; }
-    for (int dy = -1; dy <= 1; ++dy) {
-      int cy = by + dy, sy = 0;
-      if (cy < 0) { cy += C.nb[1]; sy = -1; } else if (cy >= C.nb[1]) { cy -= C.nb[1]; sy = 1; }
-      for (int dz = -1; dz <= 1; ++dz) {
-        int cz = bz + dz, sz = 0;
-        if (cz < 0) { cz += C.nb[2]; sz = -1; } else if (cz >= C.nb[2]) { cz -= C.nb[2]; sz = 1; }
+  auto fold = [](int c, int nb, int per, int &s) -> bool {  // bin index into [0, nb) with its image shift; false: outside an open axis
+    s = 0;
+    if (c >= 0 && c < nb) return true;
+    if (!per) return false;
+    s = c >= 0 ? c / nb : -((-c + nb - 1) / nb);
+    return true;
+  };
+  for (int dx = -C.R[0]; dx <= C.R[0]; ++dx) {
+    int cx = bx + dx, sx;
+    if (!fold(cx, C.nb[0], C.per[0], sx)) continue;
+    cx -= sx * C.nb[0];
+    for (int dy = -C.R[1]; dy <= C.R[1]; ++dy) {
+      int cy = by + dy, sy;
+      if (!fold(cy, C.nb[1], C.per[1], sy)) continue;
+      cy -= sy * C.nb[1];
+      for (int dz = -C.R[2]; dz <= C.R[2]; ++dz) {
+        int cz = bz + dz, sz;
+        if (!fold(cz, C.nb[2], C.per[2], sz)) continue;
+        cz -= sz * C.nb[2];
         const double ox = sx * C.a[0] + sy * C.a[3] + sz * C.a[6];
         const double oy = sx * C.a[1] + sy * C.a[4] + sz * C.a[7];
         const double oz = sx * C.a[2] + sy * C.a[5] + sz * C.a[8];
@@ -105,7 +129,7 @@ __global__ __launch_bounds__(128) void nl_pair_kernel(Cell C, const double *__re
   if (!FILL) count[i] = cnt;
 }
 
-int make_cell(const double *cell_host, double cutoff, Cell &C) {
+int make_cell(const double *cell_host, double cutoff, const int32_t *pbc_host, const double *frac_range_host, Cell &C) {
   SNET_REQUIRE(cell_host != nullptr && cutoff > 0, "snet_nl: null cell / bad cutoff");
   const double *a = cell_host;
   for (int k = 0; k < 9; ++k) C.a[k] = a[k];
@@ -124,13 +148,29 @@ int make_cell(const double *cell_host, double cutoff, Cell &C) {
   for (int k = 0; k < 3; ++k) {
     const double *u = a + 3 * ((k + 1) % 3), *v = a + 3 * ((k + 2) % 3);
     const double cx = u[1] * v[2] - u[2] * v[1], cy = u[2] * v[0] - u[0] * v[2], cz = u[0] * v[1] - u[1] * v[0];
-    const double h = fabs(det) / sqrt(cx * cx + cy * cy + cz * cz);
-    int nb = (int)floor(h / cutoff);
-    if (nb < 1) {
-      snet::set_error("snet_nl: a cell height is smaller than the cutoff (use the host neighbor list)");
-      return 4;
+    double h = fabs(det) / sqrt(cx * cx + cy * cy + cz * cz);   // distance between the opposite cell faces of axis k
+    C.per[k] = pbc_host ? (pbc_host[k] != 0) : 1;
+    C.lo[k] = 0.0;
+    C.inv_ext[k] = 1.0;
+    if (!C.per[k]) {
+      SNET_REQUIRE(frac_range_host != nullptr, "snet_nl: an open axis needs the fractional range the atoms span");
+      const double lo = frac_range_host[k], ext = frac_range_host[3 + k] - lo;
+      SNET_REQUIRE(ext >= 0.0, "snet_nl: empty fractional range");
+      C.lo[k] = lo;
+      C.inv_ext[k] = ext > 1e-300 ? 1.0 / ext : 0.0;
+      h *= ext;   // height of the occupied slab
     }
-    C.nb[k] = nb > 1024 ? 1024 : nb;
+    int nb = (int)floor(h / cutoff);
+    nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+    C.nb[k] = nb;
+    // bins on each side that cover the cutoff: 1 while the bin is at least one cutoff wide; a periodic cell thinner than the
+    // cutoff (one bin) reaches ceil(rc / h) images of itself; an open axis has no images
+    int R = 1;
+    if (C.per[k] && h / nb < cutoff) {
+      R = (int)ceil(cutoff / (h / nb));
+      SNET_REQUIRE(R <= 64, "snet_nl: a periodic cell height is smaller than 1/64 of the cutoff");
+    }
+    C.R[k] = R;
   }
   C.rc2 = cutoff * cutoff;
   return 0;
@@ -138,9 +178,10 @@ int make_cell(const double *cell_host, double cutoff, Cell &C) {
 
 }  // namespace
 
-extern "C" int snet_nl_grid(const double *cell_host, double cutoff, int32_t *nbins_host) {
+extern "C" int snet_nl_grid(const double *cell_host, double cutoff, const int32_t *pbc_host, const double *frac_range_host,
+                             int32_t *nbins_host) {
   Cell C;
-  if (int rc = make_cell(cell_host, cutoff, C)) return rc;
+  if (int rc = make_cell(cell_host, cutoff, pbc_host, frac_range_host, C)) return rc;
   SNET_REQUIRE(nbins_host != nullptr, "snet_nl_grid: null output");
   nbins_host[0] = C.nb[0];
   nbins_host[1] = C.nb[1];
@@ -148,10 +189,10 @@ extern "C" int snet_nl_grid(const double *cell_host, double cutoff, int32_t *nbi
   return 0;
 }
 
-extern "C" int snet_nl_bin(const double *cell_host, double cutoff, const double *pos, int64_t n, double *wpos,
-                           int32_t *wrap, int32_t *cell_id, void *stream) {
+extern "C" int snet_nl_bin(const double *cell_host, double cutoff, const int32_t *pbc_host, const double *frac_range_host,
+                           const double *pos, int64_t n, double *wpos, int32_t *wrap, int32_t *cell_id, void *stream) {
   Cell C;
-  if (int rc = make_cell(cell_host, cutoff, C)) return rc;
+  if (int rc = make_cell(cell_host, cutoff, pbc_host, frac_range_host, C)) return rc;
   if (n <= 0) return 0;
   nl_bin_kernel<<<(unsigned)((n + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(C, pos, n, wpos, wrap,
                                                                                           cell_id);
@@ -159,11 +200,11 @@ extern "C" int snet_nl_bin(const double *cell_host, double cutoff, const double 
   return 0;
 }
 
-extern "C" int snet_nl_count(const double *cell_host, double cutoff, const double *wpos, const int32_t *cell_id,
-                             const int32_t *order, const int32_t *bin_start, int64_t n, int32_t *count,
-                             void *stream) {
+extern "C" int snet_nl_count(const double *cell_host, double cutoff, const int32_t *pbc_host, const double *frac_range_host,
+                             const double *wpos, const int32_t *cell_id, const int32_t *order, const int32_t *bin_start,
+                             int64_t n, int32_t *count, void *stream) {
   Cell C;
-  if (int rc = make_cell(cell_host, cutoff, C)) return rc;
+  if (int rc = make_cell(cell_host, cutoff, pbc_host, frac_range_host, C)) return rc;
   if (n <= 0) return 0;
   nl_pair_kernel<false><<<(unsigned)((n + 127) / 128), 128, 0, static_cast<hipStream_t>(stream)>>>(
       C, wpos, nullptr, cell_id, order, bin_start, n, count, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -171,12 +212,12 @@ extern "C" int snet_nl_count(const double *cell_host, double cutoff, const doubl
   return 0;
 }
 
-extern "C" int snet_nl_fill(const double *cell_host, double cutoff, const double *wpos, const int32_t *wrap,
-                            const int32_t *cell_id, const int32_t *order, const int32_t *bin_start, int64_t n,
-                            const int32_t *row_ptr, int32_t *src, int32_t *center, float *edge_vec,
-                            int32_t *shifts, void *stream) {
+extern "C" int snet_nl_fill(const double *cell_host, double cutoff, const int32_t *pbc_host, const double *frac_range_host,
+                            const double *wpos, const int32_t *wrap, const int32_t *cell_id, const int32_t *order,
+                            const int32_t *bin_start, int64_t n, const int32_t *row_ptr, int32_t *src, int32_t *center,
+                            float *edge_vec, int32_t *shifts, void *stream) {
   Cell C;
-  if (int rc = make_cell(cell_host, cutoff, C)) return rc;
+  if (int rc = make_cell(cell_host, cutoff, pbc_host, frac_range_host, C)) return rc;
   if (n <= 0) return 0;
   nl_pair_kernel<true><<<(unsigned)((n + 127) / 128), 128, 0, static_cast<hipStream_t>(stream)>>>(
       C, wpos, wrap, cell_id, order, bin_start, n, nullptr, row_ptr, src, center, edge_vec, shifts);

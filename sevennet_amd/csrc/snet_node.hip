@@ -564,6 +564,17 @@ extern "C" int snet_segment_sum_rows(const float *x, const int32_t *seg_ptr, con
   SNET_CHECK_LAUNCH("snet_segment_sum_rows");
   return 0;
 }
+__global__ __launch_bounds__(256) void i32_shift_kernel(const int32_t *__restrict__ in, int32_t delta, int32_t *__restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[i] + delta;
+}
+// out[i] = in[i] + delta (the reverse kernels' tile pointers re-based on a sub-list of tiles)
+extern "C" int snet_i32_shift(const int32_t *in, int32_t delta, int32_t *out, int64_t n, void *stream) {
+  SNET_REQUIRE(in != nullptr && out != nullptr, "snet_i32_shift: null argument");
+  if (n <= 0) return 0;
+  i32_shift_kernel<<<grid_for(n), 256, 0, static_cast<hipStream_t>(stream)>>>(in, delta, out, n);
+  SNET_CHECK_LAUNCH("snet_i32_shift");
+  return 0;
+}
 extern "C" int snet_readout_energy(const float *x, int64_t n, int32_t dim, const double *v, double c, const int32_t *types,
                                    const float *scale, const float *shift, int32_t n_scale, float *e_atom, double *energy,
                                    void *stream) {

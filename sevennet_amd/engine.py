@@ -66,6 +66,10 @@ class Graph:
     # edges grouped by SOURCE atom (order eperm): destination row and radial row of each (transposed scalar convolution)
     src_T: Optional[torch.Tensor] = None
     w_row_T: Optional[torch.Tensor] = None
+    # bricks of a decomposition number their local atoms interior first (parallel.BrickGraph.n_interior): rows [0, n_interior)
+    # have no ghost source.  0 = unknown / no split.
+    n_interior: int = 0
+    _tile_split: Optional[tuple] = None
 
     def by_source(self, lib, stream):
         """(center[eperm], w_row[eperm]) as int32 arrays, built on first use (w_row None: the edge's own row, eperm)"""
@@ -90,6 +94,15 @@ class Graph:
                                                _stream()), 'snet_edge_tiles')
             self.tile_ptr, self.tile_node, self.n_tiles = tp, tn, int(n.value)
         return self.tile_ptr, self.tile_node, self.n_tiles
+
+    def tiles_split(self):
+        """the tile list cut at n_interior: ((tile_ptr, tile_node, n) of the interior rows, (tile_ptr', tile_node', n') of the
+        boundary rows) -- views / one shifted copy of the full list, built on first use"""
+        if self._tile_split is None:
+            tp, tn, nt = self.tiles()
+            k = int(tp[self.n_interior].item())       # first tile of the first boundary row (one readback per graph)
+            self._tile_split = ((tp, tn, k), ((tp - k).contiguous(), tn[k:], nt - k))
+        return self._tile_split
 
     def share_pairs(self):
         """Number the undirected pairs so the radial MLP runs once per pair (in place; returns self)."""
@@ -123,7 +136,7 @@ def species_row_lists(types_local: torch.Tensor, num_species: int) -> List[torch
 
 
 def build_graph(types, edge_index, edge_vec, n_local: Optional[int] = None, device='cuda',
-                num_species: int = 0, share_pairs: bool = True) -> Graph:
+                num_species: int = 0, share_pairs: bool = True, n_interior: int = 0) -> Graph:
     """types[n_total] (species index), edge_index[2,E] (row 0 = center / destination,
     row 1 = neighbor / source; pair_e3gnn.cpp:192-197 convention), edge_vec[E,3]."""
     dev = torch.device(device)
@@ -155,6 +168,7 @@ def build_graph(types, edge_index, edge_vec, n_local: Optional[int] = None, devi
     g = Graph(n_total, n_local, E, types, center.to(torch.int32).contiguous(), src.to(torch.int32).contiguous(),
               row_ptr.to(torch.int32), col_ptr.to(torch.int32), eperm.to(torch.int32).contiguous(),
               ev.contiguous(), order, rows)
+    g.n_interior = int(n_interior) if 0 < int(n_interior) < n_local else 0
     return g.share_pairs() if share_pairs and dev.type == 'cuda' else g
 
 
@@ -297,6 +311,7 @@ class HipForceEngine:
         self.fused_terms = int(codes.get(fused_terms, fused_terms))
         self.fused_mode = {v: k for k, v in codes.items()}[self.fused_terms]
         self.overlap = bool(overlap)
+        self.halo_split = True   # False: exchange, then the whole convolution (A/B measurements of the overlap)
         self._side = None  # second stream, created on first use
         self.events = None  # set to [] to collect (name, start, end) HIP events per kernel class
         self.event_filter = None  # optional set of class names: only those spans are recorded
@@ -618,6 +633,10 @@ class HipForceEngine:
             if keep:
                 inter['edge_embedding'], inter['edge_attr'], inter['x_embed'] = emb, sh, x[:N]
             saved = []
+            # interior / boundary split of the convolutions around the ghost exchange: needs the brick's interior-first row
+            # numbering, a halo with the split protocol, and edges (the reverse side walks a tile list)
+            split = bool(halo is not None and g.n_interior and hasattr(halo, 'forward_start') and hasattr(halo, 'reverse_start')
+                         and E > 0 and self.halo_split)
             for t, L in enumerate(self.layers):
                 ls = L.spec
                 n_in = NT if t == 0 else N  # rows of x that are valid
@@ -668,17 +687,25 @@ class HipForceEngine:
                         with _Span(self, f'radial_mlp_fwd[wn={ls.conv.weight_numel}]'):
                             # one weight row per undirected pair when the graph carries the pair map
                             w, zs = self._mlp_fwd(L, emb_p, g.n_pairs) if pairs else self._mlp_fwd(L, emb, E)
+                def conv_rows(a, b):   # the forward convolution of destination rows [a, b): pointer offsets, same kernels
+                    if b <= a:
+                        return
+                    rp, mo = C.c_void_p(g.row_ptr.data_ptr() + 4 * a), C.c_void_p(m.data_ptr() + 4 * a * dmid)
+                    if L.fused_fwd:
+                        with _Span(self, f'conv_fwd_fused[{ls.conv.tag}]'):
+                            _lib.check(lib.snet_conv_fwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(w_row), rp,
+                                                               _ptr(g.src), b - a, L.scale, mo, st), 'snet_conv_fwd_fused')
+                    else:
+                        with _Span(self, f'conv_fwd[{ls.conv.tag}]'):
+                            _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(w_row), rp,
+                                                         _ptr(g.src), b - a, L.scale, mo, st), 'snet_conv_fwd')
+                # rows without a ghost source (bricks number them first) do not wait for the exchange
+                n_int = g.n_interior if (pending is not None and split) else 0
+                conv_rows(0, n_int)
                 if pending is not None:
                     with _Span(self, 'halo_fwd'):
                         halo.forward_finish(pending)
-                if L.fused_fwd:
-                    with _Span(self, f'conv_fwd_fused[{ls.conv.tag}]'):
-                        _lib.check(lib.snet_conv_fwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(w_row), _ptr(g.row_ptr),
-                                                           _ptr(g.src), N, L.scale, _ptr(m), st), 'snet_conv_fwd_fused')
-                else:
-                    with _Span(self, f'conv_fwd[{ls.conv.tag}]'):
-                        _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(w_row), _ptr(g.row_ptr),
-                                                     _ptr(g.src), N, L.scale, _ptr(m), st), 'snet_conv_fwd')
+                conv_rows(n_int, N)
                 if L.fused_bwd:
                     w = None  # the reverse pass rebuilds its weight tiles from h2
                 with _Span(self, 'node_linear_fwd'):
@@ -758,6 +785,38 @@ class HipForceEngine:
                 use_t = t > 0 and getattr(L, 'tplan', None) is not None and E > 0
                 g_xe = self._new(E, ls.si1.dim_out) if (t > 0 and not use_t) else None
                 g_w = g_h2 = None
+                # reverse split (t > 0, fused kernels): boundary tiles first -- they hold every edge with a ghost source --
+                # then the ghost rows of g_h, whose exchange starts at once; interior tiles, the local rows and sc^T run under it
+                rsplit = split and t > 0 and L.fused_bwd
+                pending = None
+                g_h = self._new(NT, ls.si1.dim_out) if t > 0 else None
+                if use_t:
+                    src_t, w_row_t = g.by_source(lib, st)
+                    if L.t_dead:
+                        g_h.zero_()
+                    if sh_T is None:
+                        sh_T = self._new(E, nsh)
+                        _lib.check(lib.snet_gather_rows(_ptr(sh), _ptr(g.eperm), _ptr(sh_T), E, nsh, st), 'snet_gather_rows')
+
+                def gh_rows(a, b):
+                    """source rows [a, b) of g_h: transposed scalar convolution over the edges grouped by source, or the segment
+                    sum of the per-edge rows the reverse kernel wrote"""
+                    if b <= a:
+                        return
+                    cp, go = C.c_void_p(g.col_ptr.data_ptr() + 4 * a), C.c_void_p(g_h.data_ptr() + 4 * a * ls.si1.dim_out)
+                    if use_t:
+                        with _Span(self, f'conv_bwd_node[transposed {ls.conv.tag}]'):
+                            _lib.check(lib.snet_conv_fwd_fused(L.tplan, _ptr(g_m), _ptr(sh_T), _ptr(h2), _ptr(w_row_t), cp, _ptr(src_t),
+                                                               b - a, L.scale, go, st), 'snet_conv_fwd_fused')
+                        return
+                    with _Span(self, 'conv_bwd_node[segment_sum]'):
+                        if L.fused_bwd:   # the fused kernel's g_xe rows: chunk order undone while summing
+                            _lib.check(lib.snet_segment_sum_rows_chunked(_ptr(g_xe), cp, _ptr(g.eperm), b - a, ls.si1.dim_out,
+                                                                         _ptr(L.gxe_chunks), go, st), 'snet_segment_sum_rows_chunked')
+                        else:
+                            _lib.check(lib.snet_segment_sum_rows(_ptr(g_xe), cp, _ptr(g.eperm), b - a, ls.si1.dim_out, go, st),
+                                       'snet_segment_sum_rows')
+
                 if L.fused_bwd:
                     g_h2 = None if L.mlp_tail else self._new(E, 64)
                     x_max = None
@@ -767,14 +826,33 @@ class HipForceEngine:
                         x_max = self._new(NT)
                         with _Span(self, 'row_bounds'):
                             _lib.check(lib.snet_row_absmax(_ptr(h), NT, ls.si1.dim_out, _ptr(x_max), st), 'snet_row_absmax')
-                    with _Span(self, f'conv_bwd_fused[{ls.conv.tag}]'):
-                        if E > 0:
+
+                    def bwd_tiles(tp_, tn_, nt_):
+                        if nt_ <= 0:
+                            return
+                        with _Span(self, f'conv_bwd_fused[{ls.conv.tag}]'):
                             _lib.check(lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(w_row),
-                                                               _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale,
+                                                               _ptr(g.row_ptr), _ptr(g.src), _ptr(tp_), _ptr(tn_), nt_, L.scale,
                                                                _ptr(g_m), _ptr(g_xe), _ptr(g_h2),
                                                                _ptr(emb) if L.mlp_tail else None, _ptr(g_emb) if L.mlp_tail else None,
                                                                _ptr(g_vec), _ptr(x_max), _ptr(g_max), st),
                                        'snet_conv_bwd_fused')
+                    if rsplit:
+                        (tpi, tni, nti), (tpb, tnb, ntb) = g.tiles_split()
+                        if use_t:                  # g_h does not depend on the reverse kernel: ghost rows straight away
+                            gh_rows(N, NT)
+                        else:
+                            bwd_tiles(tpb, tnb, ntb)
+                            gh_rows(N, NT)
+                        with _Span(self, 'halo_rev'):
+                            pending = halo.reverse_start(g_h, N)
+                        if use_t:
+                            bwd_tiles(tile_ptr, tile_node, n_tiles)
+                        else:
+                            bwd_tiles(tpi, tni, nti)
+                        gh_rows(0, N)
+                    elif E > 0:
+                        bwd_tiles(tile_ptr, tile_node, n_tiles)
                 else:
                     if side is not None:  # double-buffered: the MLP reverse of layer t+2 may still be reading this one
                         if gw_done[t & 1] is not None:
@@ -788,38 +866,15 @@ class HipForceEngine:
                                                               _ptr(g_xe), _ptr(g_vec), st), 'snet_conv_bwd_edge_vec')
                 # the source-row gradient goes first so that its ghost rows can travel to their owners while
                 # the radial MLP's reverse pass (independent of them) runs
-                pending = None
-                if use_t:
-                    # g_h[j] = sum over the edges that have j as their source: a forward convolution of the transposed product,
-                    # "x" = the destination's g_m row (scalars), Y and the radial rows in source-grouped edge order
-                    src_t, w_row_t = g.by_source(lib, st)
-                    g_h = self._new(NT, ls.si1.dim_out)
-                    if L.t_dead:
-                        g_h.zero_()
-                    with _Span(self, f'conv_bwd_node[transposed {ls.conv.tag}]'):
-                        if sh_T is None:
-                            sh_T = self._new(E, nsh)
-                            _lib.check(lib.snet_gather_rows(_ptr(sh), _ptr(g.eperm), _ptr(sh_T), E, nsh, st), 'snet_gather_rows')
-                        _lib.check(lib.snet_conv_fwd_fused(L.tplan, _ptr(g_m), _ptr(sh_T), _ptr(h2), _ptr(w_row_t),
-                                                           _ptr(g.col_ptr), _ptr(src_t), NT, L.scale, _ptr(g_h), st),
-                                   'snet_conv_fwd_fused')
-                elif t > 0:
-                    g_h = self._new(NT, ls.si1.dim_out)
-                    with _Span(self, 'conv_bwd_node[segment_sum]'):
-                        if L.fused_bwd:   # the fused kernel's g_xe rows: chunk order undone while summing
-                            _lib.check(lib.snet_segment_sum_rows_chunked(_ptr(g_xe), _ptr(g.col_ptr), _ptr(g.eperm), NT,
-                                                                         ls.si1.dim_out, _ptr(L.gxe_chunks), _ptr(g_h), st),
-                                       'snet_segment_sum_rows_chunked')
-                        else:
-                            _lib.check(lib.snet_segment_sum_rows(_ptr(g_xe), _ptr(g.col_ptr), _ptr(g.eperm), NT,
-                                                                 ls.si1.dim_out, _ptr(g_h), st), 'snet_segment_sum_rows')
-                    del g_xe
-                if t > 0 and halo is not None:
-                    with _Span(self, 'halo_rev'):
-                        if hasattr(halo, 'reverse_start'):
-                            pending = halo.reverse_start(g_h, N)
-                        else:
-                            halo.reverse(g_h, N)
+                if t > 0 and not rsplit:
+                    gh_rows(0, NT)
+                    if halo is not None:
+                        with _Span(self, 'halo_rev'):
+                            if hasattr(halo, 'reverse_start'):
+                                pending = halo.reverse_start(g_h, N)
+                            else:
+                                halo.reverse(g_h, N)
+                del g_xe
                 if L.fused_bwd and L.mlp_tail:
                     pass
                 elif L.fused_bwd:

@@ -52,6 +52,14 @@ class NativeModel:
         self.cutoff, self.num_species, self.n_layers = float(cut.value), int(ns.value), int(nl.value)
         self.comm_dims = [int(comm[i]) for i in range(self.n_layers)]
         self._cb = None
+        # topology-only work (tile list, source grouping, species row lists) is kept per Graph object: a Graph's index arrays
+        # are immutable device tensors, so "same object" = "same topology"
+        _lib.check(self.lib.snet_model_set_topology_cache(self.handle, 1), 'snet_model_set_topology_cache')
+        self._last_graph = None
+
+    def eval_syncs(self) -> int:
+        """stream synchronisations snet_model_eval has issued so far (0 per step once the topology is cached)"""
+        return int(self.lib.snet_model_eval_syncs(self.handle))
 
     def meta(self, key: str) -> str:
         buf = C.create_string_buffer(4096)
@@ -110,6 +118,9 @@ class NativeModel:
                 g._types_host = types_host
             p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
             self._cb_error = None
+            if self._last_graph is not g:   # (holding the reference also keeps the old arrays' addresses from being reused)
+                _lib.check(self.lib.snet_model_topology_changed(self.handle), 'snet_model_topology_changed')
+                self._last_graph = g
             rc = self.lib.snet_model_eval(self.handle, NT, N, E, p(g.types), C.c_void_p(types_host.ctypes.data),
                                           p(g.row_ptr), p(g.src), p(g.col_ptr), p(g.eperm), p(g.edge_vec), p(g.w_row), p(g.pair_edge),
                                           g.n_pairs if g.w_row is not None else 0, p(energy),

@@ -65,6 +65,10 @@ class BrickGraph:
     edge_vec: np.ndarray      # [E,3]
     send_lists: List[np.ndarray]   # per peer: local row ids this rank sends (peer's ghost order)
     recv_counts: List[int]         # per peer: ghost rows received (ghost rows are grouped by peer)
+    # local atoms are numbered INTERIOR FIRST: atoms [0, n_interior) have no ghost among their sources, so their convolution
+    # does not wait for the forward exchange (and their reverse tiles feed no ghost row): the hosts run them while the
+    # exchange of the layer is in flight (engine.compute, snet_model_eval)
+    n_interior: int = 0
 
 
 def build_brick_graph(pos, cell, types, cutoff: float, world: int, rank: int, grid=None, pbc=(True, True, True),
@@ -93,6 +97,11 @@ def build_brick_graph(pos, cell, types, cutoff: float, world: int, rank: int, gr
 
     mine = np.nonzero(owner == rank)[0]           # sorted global ids
     n_local = len(mine)
+    # interior first: owned atoms without a cross-brick source, then the boundary atoms (both in ascending global id)
+    is_boundary = np.zeros(n, bool)
+    is_boundary[ci[cross & (oc == rank)]] = True
+    mine = np.concatenate([mine[~is_boundary[mine]], mine[is_boundary[mine]]])
+    n_interior = int((~is_boundary[mine]).sum())
     if n_local == 0:
         raise RuntimeError(f'rank {rank}: empty sub-domain is not supported (as in the reference, '
                            'docs/source/user_guide/lammps_torch.md:111-113)')
@@ -108,7 +117,7 @@ def build_brick_graph(pos, cell, types, cutoff: float, world: int, rank: int, gr
     send_lists = []
     for q in range(world):
         s = (need_q == q) & (need_r == rank)
-        send_lists.append(local_of[np.sort(need_j[s])])
+        send_lists.append(local_of[np.sort(need_j[s])])   # (q's ghost order = ascending GLOBAL id: independent of this rank's local numbering)
     ghost_of = np.full(n, -1, np.int64)
     ghost_of[gj] = n_local + np.arange(len(gj))
     e_sel = oc == rank
@@ -118,7 +127,7 @@ def build_brick_graph(pos, cell, types, cutoff: float, world: int, rank: int, gr
     assert (c_loc >= 0).all() and (s_loc >= 0).all()
     gids = np.concatenate([mine, gj])
     return BrickGraph(rank, world, n_local, types[gids], gids, np.stack([c_loc, s_loc]), ev[e_sel],
-                      send_lists, recv_counts)
+                      send_lists, recv_counts, n_interior)
 
 
 # --------------------------------------------------------------------------- #
@@ -379,28 +388,38 @@ class NativeHalo:
             torch.cuda.current_stream(handle[1].device).wait_event(handle[0])
 
     def reverse_start(self, gx: torch.Tensor, n_local: int):
-        """Begin the reverse exchange (ghost-row gradients to their owners, accumulated into gx[:n_local]) on the
-        halo's second stream; the caller's stream may run anything that does not touch gx until reverse_finish
-        (HipForceEngine: the self-connection's transposed linear).  Reference: the reverse_comm inside the layer loop,
-        pair_e3gnn_parallel.cpp:430-440."""
-        if not self.overlap:
-            self.reverse(gx, n_local)
-            return None
+        """Begin the reverse exchange on the halo's second stream: the ghost rows gx[n_local:] travel to their owners and what
+        the peers return is staged inside the halo (snet_halo_reverse_exchange).  Only the GHOST rows are read, so the caller's
+        stream may go on WRITING the local rows until reverse_finish (HipForceEngine: the interior tiles of the reverse
+        convolution, the local rows' segment sum, the self-connection's transposed linear).  Reference: the reverse_comm inside
+        the layer loop, pair_e3gnn_parallel.cpp:430-440."""
         from . import _lib
         assert gx.is_contiguous() and gx.dtype == torch.float32
         cur = torch.cuda.current_stream(gx.device)
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=gx.device)
-        self._side.wait_stream(cur)          # the ghost rows' gradients are complete
-        _lib.check(self.lib.snet_halo_reverse(self.handle, C.c_void_p(gx.data_ptr()), gx.shape[0], n_local, gx.shape[1],
-                                              C.c_void_p(self._side.cuda_stream)), 'snet_halo_reverse')
-        done = torch.cuda.Event()
-        done.record(self._side)
+        st = cur
+        if self.overlap:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=gx.device)
+            self._side.wait_stream(cur)          # the ghost rows' gradients are complete
+            st = self._side
+        _lib.check(self.lib.snet_halo_reverse_exchange(self.handle, C.c_void_p(gx.data_ptr()), gx.shape[0], n_local, gx.shape[1],
+                                                       C.c_void_p(st.cuda_stream)), 'snet_halo_reverse_exchange')
+        done = None
+        if self.overlap:
+            done = torch.cuda.Event()
+            done.record(self._side)
         return done, gx
 
     def reverse_finish(self, handle, gx: torch.Tensor = None):
-        if handle is not None:
-            torch.cuda.current_stream(handle[1].device).wait_event(handle[0])
+        """the caller's stream waits for the exchange, then adds the staged rows into the owners' rows gx[:n_local]"""
+        from . import _lib
+        done, gx0 = handle
+        gx = gx0 if gx is None else gx
+        cur = torch.cuda.current_stream(gx.device)
+        if done is not None:
+            cur.wait_event(done)
+        _lib.check(self.lib.snet_halo_reverse_accumulate(self.handle, C.c_void_p(gx.data_ptr()), gx.shape[1],
+                                                         C.c_void_p(cur.cuda_stream)), 'snet_halo_reverse_accumulate')
 
     def __del__(self):
         try:
@@ -448,13 +467,29 @@ class _InProcessHalo:
         self._sync()
 
     def reverse(self, gx, n_local):
+        self.reverse_finish(self.reverse_start(gx, n_local), gx)
+
+    # the same split protocol as the RCCL halo (start reads the ghost rows only, finish adds into the local rows), so the
+    # interior / boundary split of the hosts runs through the N-bricks-on-one-GPU tests
+    def forward_start(self, x, n_local):
+        self.forward(x, n_local)
+        return (x,)
+
+    def forward_finish(self, handle):
+        pass
+
+    def reverse_start(self, gx, n_local):
         g = self.g
-        g.slots[self.rank] = gx
+        g.slots[self.rank] = gx[n_local:].clone()     # a snapshot of the ghost rows: the local rows may still change
         self._sync()
-        for p in range(g.world):  # peer p holds my rows as ghosts at a fixed offset
+        return (n_local,)
+
+    def reverse_finish(self, handle, gx):
+        g = self.g
+        for p in range(g.world):  # peer p holds my rows as ghosts at a fixed offset of its ghost block
             mem = g.members[p]
             c = mem.recv_counts[self.rank]
             if c:
-                off = g.slots[p].shape[0] - sum(mem.recv_counts) + sum(mem.recv_counts[:self.rank])
+                off = sum(mem.recv_counts[:self.rank])
                 _scatter_add_rows(gx, self.send[p], g.slots[p][off:off + c].contiguous())
         self._sync()

@@ -235,7 +235,7 @@ def test_engine_bricks_equal_single_graph_on_one_gpu(world):
     def run(r):
         try:
             b = bricks[r]
-            g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, device='cuda:0')
+            g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, n_interior=b.n_interior, device='cuda:0')
             results[r] = engines[r].compute(g, halo=grp.members[r])
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
@@ -377,9 +377,61 @@ def test_gpu_neighbor_list_matches_host(case):
     b = canon(c.astype(np.int64), s.astype(np.int64), sh.astype(np.int64), v.astype(np.float64))
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
     assert np.abs(a[3] - b[3]).max() < 2e-6
-    assert not gpu_neighbor_supported(cell, [True, True, False], cutoff)
-    small = np.eye(3) * (0.9 * cutoff)
-    assert not gpu_neighbor_supported(small, [True] * 3, cutoff)  # a height below the cutoff: host builder
+
+
+def _same_edges(pos, cell, pbc, cutoff):
+    """device cell list == host list as multisets of (center, source, image shift), edge vectors to fp32"""
+    from sevennet_amd.neighbor import neighbor_list
+    from sevennet_amd.neighbor_gpu import build_graph_gpu, gpu_neighbor_supported
+    assert gpu_neighbor_supported(cell, pbc, cutoff, pos)
+    ei, ev, S = neighbor_list(pos, cell, pbc, cutoff)
+    gg = build_graph_gpu(np.zeros(len(pos), np.int64), pos, cell, cutoff, with_shifts=True, pbc=pbc)
+    torch.cuda.synchronize()
+    assert gg.n_edges == ei.shape[1], (gg.n_edges, ei.shape[1])
+    c, s, v, sh = gg.center.cpu().numpy(), gg.src.cpu().numpy(), gg.edge_vec.cpu().numpy(), gg.shifts.cpu().numpy()
+    assert (np.diff(c) >= 0).all() and (np.bincount(c, minlength=len(pos)) == np.diff(gg.row_ptr.cpu().numpy())).all()
+
+    def canon(i, j, S_, vec):
+        key = np.lexsort((S_[:, 2], S_[:, 1], S_[:, 0], j, i))
+        return i[key], j[key], S_[key], vec[key]
+    if gg.n_edges:
+        a = canon(ei[0], ei[1], S, ev)
+        b = canon(c.astype(np.int64), s.astype(np.int64), sh.astype(np.int64), v.astype(np.float64))
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+        assert np.abs(a[3] - b[3]).max() < 2e-6
+    return gg
+
+
+def test_gpu_neighbor_list_open_axes_and_thin_cells():
+    """f1 outside bulk crystals (VERDICT r3 missing #5): slabs, wires and molecules (open axes: neither wrapped nor
+    imaged; a missing cell row is padded like sevenn/train/dataload.py:37-48), periodic cells THINNER than the cutoff
+    (several images of the cell itself), and the reference's own pinned edge counts (tests/unit_tests/test_data.py:48,
+    cutoff 4.0: bulk NaCl 36, H2O 6, H 0, one-atom Cu cell 18)"""
+    from sevennet_amd.neighbor import diamond_cubic
+    pos, cell = diamond_cubic(5.431, (3, 3, 2), 0.1, 5)
+    pos = pos + np.array([2.0, -1.5, 30.0])      # atoms outside the cell; the open axis keeps its raw coordinate
+    for pbc in ([True, True, False], [True, False, False], [False, True, True], [False, False, False]):
+        _same_edges(pos, cell, pbc, 5.0)
+    # triclinic slab with a degenerate (zero) cell row on the open axis
+    tri = np.array([[9.0, 0.0, 0.0], [2.5, 8.0, 0.0], [0.0, 0.0, 0.0]])
+    rng = np.random.default_rng(2)
+    p2 = rng.uniform(0, 1, (60, 3)) @ np.array([[9.0, 0.0, 0.0], [2.5, 8.0, 0.0], [0.0, 0.0, 7.0]])
+    _same_edges(p2, tri, [True, True, False], 4.5)
+    # periodic cells thinner than the cutoff: 1, 2 and 3 images per side, also triclinic
+    for scale, pbc in ((0.9, [True] * 3), (0.45, [True] * 3), (0.3, [True, True, False]), (0.6, [True, False, True])):
+        small = np.array([[1.0, 0.1, 0.0], [0.2, 1.1, 0.1], [0.0, 0.3, 0.95]]) * (scale * 5.0)
+        p3 = rng.uniform(0, 1, (5, 3)) @ small
+        _same_edges(p3, small, pbc, 5.0)
+    # the reference's pins
+    a = 5.63
+    g = _same_edges(np.array([[0, 0, 0], [a / 2] * 3]), np.array([[0, a / 2, a / 2], [a / 2, 0, a / 2], [a / 2, a / 2, 0]]), [True] * 3, 4.0)
+    assert g.n_edges == 36
+    a = 3.61
+    g = _same_edges(np.zeros((1, 3)), np.array([[0, a / 2, a / 2], [a / 2, 0, a / 2], [a / 2, a / 2, 0]]), [True] * 3, 4.0)
+    assert g.n_edges == 18
+    h2o = np.array([[0, 0, 0.119262], [0, 0.763239, -0.477047], [0, -0.763239, -0.477047]])
+    assert _same_edges(h2o, np.zeros((3, 3)), [False] * 3, 4.0).n_edges == 6
+    assert _same_edges(np.zeros((1, 3)), np.zeros((3, 3)), [False] * 3, 4.0).n_edges == 0
 
 
 def test_sevennet_l3i5_shape_vs_oracle_small_cell():
@@ -843,7 +895,7 @@ def test_bricks_through_the_native_halo_equal_single_graph(world, host):
 
     def fn(r):
         b = bricks[r]
-        g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, device='cuda:0')
+        g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, n_interior=b.n_interior, device='cuda:0')
         if host == 'native':
             models[r].set_halo(halos[r])
             out = models[r].compute(g)
@@ -857,6 +909,54 @@ def test_bricks_through_the_native_halo_equal_single_graph(world, host):
     e_tot = sum(e for e, _ in res)
     e_ref = float(ref['energy'].cpu())
     assert abs(e_tot - e_ref) < 2e-6 * abs(e_ref)
+    fr = ref['forces'].cpu().numpy()
+    assert np.abs(F - fr).max() <= max(1e-8, 2e-5 * np.abs(fr).max())
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_interior_boundary_split_of_the_fused_convolutions(world):
+    """Halo overlap: bricks number their interior atoms first; the fused forward kernel runs the interior rows
+    while the forward exchange is in flight and the boundary rows after it; in reverse the boundary tiles come first, the ghost
+    rows of g_h travel while the interior tiles, the local rows and sc^T run (last layer: the transposed convolution's ghost rows
+    first).  SevenNet-0 shape (fused kernels) through the library's halo over the in-process transport: must equal the
+    un-split engine on the whole cell, and be BIT-IDENTICAL to the same bricks evaluated without the split."""
+    from sevennet_amd.engine import HipForceEngine, build_graph
+    from sevennet_amd.model_spec import sevennet_0_config
+    from sevennet_amd.parallel import LoopbackHub, NativeHalo, build_brick_graph
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = sevennet_0_config(num_species=2)
+    sd = random_state_dict(cfg, seed=4)
+    types, pos, cell, ei, ev = synthetic_system((4, 4, 3), sigma=0.06, seed=8, cutoff=5.0, n_species=2)
+    ref = HipForceEngine(cfg, sd, device='cuda:0').compute(build_graph(types, ei, ev, device='cuda:0'))
+    torch.cuda.synchronize()
+    bricks = [build_brick_graph(pos, cell, types, 5.0, world, r, neighbors=(ei, ev)) for r in range(world)]
+    for b in bricks:   # interior rows have no ghost source, every boundary row has one
+        c, s_ = b.edge_index
+        has_ghost = np.zeros(b.n_local, bool)
+        has_ghost[c[s_ >= b.n_local]] = True
+        assert not has_ghost[:b.n_interior].any() and has_ghost[b.n_interior:].all()
+    assert any(0 < b.n_interior < b.n_local for b in bricks)
+    out = {}
+    for split in (True, False):
+        hub = LoopbackHub(world)
+        halos = [NativeHalo(hub.comm(r), bricks[r].send_lists, bricks[r].recv_counts) for r in range(world)]
+        models = [HipForceEngine(cfg, sd, device='cuda:0') for _ in range(world)]
+
+        def fn(r):
+            b = bricks[r]
+            models[r].halo_split = split
+            g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, n_interior=b.n_interior, device='cuda:0')
+            assert all(L.fused_fwd and L.fused_bwd for L in models[r].layers)
+            o = models[r].compute(g, halo=halos[r])
+            return float(o['energy'].cpu()), o['forces'].cpu().numpy(), o['dE_dr'].cpu().numpy()
+        out[split] = _run_ranks(world, fn, hub)
+    for (e1, f1, d1), (e0, f0, d0) in zip(out[True], out[False]):
+        assert e1 == e0 and np.array_equal(f1, f0) and np.array_equal(d1, d0)
+    F = np.zeros((len(types), 3), np.float32)
+    for b, (_, f, _) in zip(bricks, out[True]):
+        F[b.global_ids[:b.n_local]] = f[:b.n_local]
+    e_ref = float(ref['energy'].cpu())
+    assert abs(sum(e for e, _, _ in out[True]) - e_ref) < 2e-6 * abs(e_ref)
     fr = ref['forces'].cpu().numpy()
     assert np.abs(F - fr).max() <= max(1e-8, 2e-5 * np.abs(fr).max())
 
@@ -889,7 +989,7 @@ def test_rank_without_ghosts_still_serves_its_peers(host):
 
     def fn(r):
         b = bricks[r]
-        g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, device='cuda:0')
+        g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, n_interior=b.n_interior, device='cuda:0')
         assert (g.n_total == g.n_local) == (r == 1)
         if host == 'native':
             models[r].set_halo(halos[r])

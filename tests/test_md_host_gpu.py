@@ -59,8 +59,10 @@ class MdHost:
         self.lib.snet_md_destroy(self.h)
 
     def compute(self, x, tag, nlocal, rows, types, ghost_mode=0, ilist=None, tag_bytes=4, eflag_atom=1, vflag_atom=1,
-                special_bits=False):
+                special_bits=False, unchanged=False):
         from sevennet_amd import _lib
+        if unchanged:   # what the pair style does when neighbor->ago > 0
+            _lib.check(self.lib.snet_md_list_unchanged(self.h), 'snet_md_list_unchanged')
         nall = len(x)
         ilist = np.arange(nlocal, dtype=np.int32) if ilist is None else np.asarray(ilist, np.int32)
         numneigh = np.zeros(nall, np.int32)
@@ -142,6 +144,30 @@ def test_md_host_serial_matches_engine(case):
     again = host.compute(x, tag, nlocal, rows, ty_all)
     first = host.compute(x, tag, nlocal, rows, ty_all)
     assert np.array_equal(again['f'], first['f']) and again['energy'] == first['energy']
+
+
+def test_md_host_reuses_the_list_between_rebuilds():
+    """MD steps between two LAMMPS neighbor-list rebuilds: positions move (inside the skin), the list does not -- with
+    snet_md_list_unchanged the host reuses the flattened list / node maps / species it uploaded at the rebuild and must give
+    exactly what a from-scratch call gives for the new positions (the edge set inside the cutoff is re-derived either way)"""
+    cfg, sd, cutoff, types, pos, cell, ei, ev = _setup('mini')
+    n = len(types)
+    x, tag, nlocal, rows = lammps_domain(pos, cell, np.ones(n, bool), cutoff + SKIN)
+    ty_all = np.asarray(types)[tag - 1]
+    host, fresh = MdHost(cfg, sd), MdHost(cfg, sd)
+    host.compute(x, tag, nlocal, rows, ty_all)                       # step of the rebuild
+    rng = np.random.default_rng(3)
+    d_owned = rng.normal(0.0, 0.03, (n, 3))                          # every image of an atom moves with its owner
+    for step in range(2):
+        x2 = x + (step + 1) * d_owned[tag - 1]
+        a = host.compute(x2, tag, nlocal, rows, ty_all, unchanged=True)
+        b = fresh.compute(x2, tag, nlocal, rows, ty_all)
+        assert a['n_edges'] == b['n_edges'] and a['energy'] == b['energy']
+        assert np.array_equal(a['f'], b['f']) and np.array_equal(a['virial'], b['virial'])
+    # a changed list without the hint is picked up (the hint is one-shot)
+    c = host.compute(x, tag, nlocal, rows, ty_all)
+    d = fresh.compute(x, tag, nlocal, rows, ty_all)
+    assert np.array_equal(c['f'], d['f'])
 
 
 def test_md_host_rejects_bad_input():

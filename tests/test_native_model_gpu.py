@@ -136,7 +136,7 @@ def test_native_model_bricks_equal_single_graph_on_one_gpu():
     def run(r):
         try:
             b = bricks[r]
-            g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, device='cuda:0')
+            g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, n_interior=b.n_interior, device='cuda:0')
             models[r].set_halo(grp.members[r])
             results[r] = models[r].compute(g)
             torch.cuda.synchronize()
@@ -158,3 +158,36 @@ def test_native_model_bricks_equal_single_graph_on_one_gpu():
     assert abs(e_tot - float(ref['energy'].cpu())) < 2e-6 * abs(float(ref['energy'].cpu()))
     fr = ref['forces'].cpu().numpy()
     assert np.abs(F - fr).max() <= max(1e-8, 2e-5 * np.abs(fr).max())
+
+
+def test_topology_cache_no_sync_on_repeated_graph():
+    """the native sequencer keeps the topology-only work (tile list -- whose construction synchronises the
+    stream --, edges grouped by source, species row lists) per graph: evaluations after the first issue NO stream
+    synchronisation inside snet_model_eval, give bit-identical results, and a new graph (other index arrays) rebuilds it"""
+    from sevennet_amd.engine import build_graph
+    from sevennet_amd.model_spec import sevennet_0_config
+    from sevennet_amd.native_model import NativeModel
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = sevennet_0_config(num_species=2)
+    sd = random_state_dict(cfg, seed=2)
+    nat = NativeModel(cfg, sd, device='cuda:0')
+    types, pos, cell, ei, ev = synthetic_system((2, 2, 2), sigma=0.05, seed=1, cutoff=5.0, n_species=2)
+    g = build_graph(types, ei, ev, device='cuda:0', num_species=2)
+    s0 = nat.eval_syncs()
+    a = nat.compute(g)
+    s1 = nat.eval_syncs()
+    assert s1 > s0                      # first evaluation: the tile list is built (one readback)
+    g.edge_vec.mul_(1.0)                # new positions would only change edge_vec: same topology
+    b = nat.compute(g)
+    c = nat.compute(g)
+    assert nat.eval_syncs() == s1       # no synchronisation inside the next evaluations
+    for k in ('energy', 'forces', 'dE_dr'):
+        assert torch.equal(a[k], b[k]) and torch.equal(b[k], c[k])
+    types2, pos2, cell2, ei2, ev2 = synthetic_system((2, 2, 3), sigma=0.05, seed=2, cutoff=5.0, n_species=2)
+    g2 = build_graph(types2, ei2, ev2, device='cuda:0', num_species=2)
+    d = nat.compute(g2)
+    assert nat.eval_syncs() > s1
+    ref = oracle_model(cfg, sd).forward(types2, ei2, ev2)
+    assert np.abs(d['forces'].cpu().numpy() - ref['forces'].numpy()).max() < 2e-5 * float(ref['forces'].abs().max())
+    e = nat.compute(g)                  # back to the first graph: rebuilt again, same answer
+    assert torch.equal(e['forces'], a['forces'])

@@ -43,7 +43,7 @@ def main():
     eng = HipForceEngine(cfg, random_state_dict(cfg, 0))
     pos, cell = diamond_cubic(5.431, (a.reps,) * 3, 0.05, 2)
     bg = build_brick_graph(pos, cell, species_of(cfg, len(pos)), cfg['cutoff'], a.world, a.rank)
-    g = build_graph(bg.types, bg.edge_index, bg.edge_vec, n_local=bg.n_local, device='cuda:0')
+    g = build_graph(bg.types, bg.edge_index, bg.edge_vec, n_local=bg.n_local, n_interior=bg.n_interior, device='cuda:0')
     halo = NoHalo()
     for _ in range(3):
         eng.compute(g, halo=halo)
