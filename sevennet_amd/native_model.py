@@ -120,6 +120,8 @@ class NativeModel:
             self._cb_error = None
             if self._last_graph is not g:   # (holding the reference also keeps the old arrays' addresses from being reused)
                 _lib.check(self.lib.snet_model_topology_changed(self.handle), 'snet_model_topology_changed')
+                # bricks number their interior rows first: the sequencer overlaps them with the library halo's exchange
+                _lib.check(self.lib.snet_model_set_interior(self.handle, int(getattr(g, 'n_interior', 0) or 0)), 'snet_model_set_interior')
                 self._last_graph = g
             rc = self.lib.snet_model_eval(self.handle, NT, N, E, p(g.types), C.c_void_p(types_host.ctypes.data),
                                           p(g.row_ptr), p(g.src), p(g.col_ptr), p(g.eperm), p(g.edge_vec), p(g.w_row), p(g.pair_edge),

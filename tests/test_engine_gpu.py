@@ -936,22 +936,28 @@ def test_interior_boundary_split_of_the_fused_convolutions(world):
         has_ghost[c[s_ >= b.n_local]] = True
         assert not has_ghost[:b.n_interior].any() and has_ghost[b.n_interior:].all()
     assert any(0 < b.n_interior < b.n_local for b in bricks)
+    from sevennet_amd.native_model import NativeModel
     out = {}
-    for split in (True, False):
+    for split in (True, False, 'native'):
         hub = LoopbackHub(world)
         halos = [NativeHalo(hub.comm(r), bricks[r].send_lists, bricks[r].recv_counts) for r in range(world)]
-        models = [HipForceEngine(cfg, sd, device='cuda:0') for _ in range(world)]
+        models = [NativeModel(cfg, sd) if split == 'native' else HipForceEngine(cfg, sd, device='cuda:0') for _ in range(world)]
 
         def fn(r):
             b = bricks[r]
-            models[r].halo_split = split
             g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, n_interior=b.n_interior, device='cuda:0')
-            assert all(L.fused_fwd and L.fused_bwd for L in models[r].layers)
-            o = models[r].compute(g, halo=halos[r])
+            if split == 'native':      # the C++ sequencer: same split on its own second stream (snet_model_set_interior)
+                models[r].set_halo(halos[r])
+                o = models[r].compute(g)
+            else:
+                models[r].halo_split = split
+                assert all(L.fused_fwd and L.fused_bwd for L in models[r].layers)
+                o = models[r].compute(g, halo=halos[r])
             return float(o['energy'].cpu()), o['forces'].cpu().numpy(), o['dE_dr'].cpu().numpy()
         out[split] = _run_ranks(world, fn, hub)
-    for (e1, f1, d1), (e0, f0, d0) in zip(out[True], out[False]):
+    for (e1, f1, d1), (e0, f0, d0), (e2, f2, d2) in zip(out[True], out[False], out['native']):
         assert e1 == e0 and np.array_equal(f1, f0) and np.array_equal(d1, d0)
+        assert e1 == e2 and np.array_equal(f1, f2) and np.array_equal(d1, d2)   # both hosts bit for bit
     F = np.zeros((len(types), 3), np.float32)
     for b, (_, f, _) in zip(bricks, out[True]):
         F[b.global_ids[:b.n_local]] = f[:b.n_local]

@@ -17,3 +17,8 @@ d=json.loads(open('gpurun_out/${TAG}_bench_${m}_n1.json').read()); r=d['roofline
 print('$m', d['ms_per_step'], d['value'], r['avg_ms'], r['frac'])"
 done
 timeout 900 bash tools/gpu/rccl_world1_soak.sh > gpurun_out/${TAG}_soak.log 2>&1; echo "soak rc=$?"; tail -5 gpurun_out/${TAG}_soak.log
+# SQ-level counters of the fused kernels (SQ_WAIT_ANY share, issue share, matrix-pipe share)
+timeout 900 bash tools/gpu/sq_counters.sh > gpurun_out/${TAG}_sq.log 2>&1; echo "sq_counters rc=$?"
+cp gpurun_out/sq/summary.txt gpurun_out/${TAG}_pmc_sq_fused_kernels.txt 2>/dev/null
+timeout 300 python tools/md_host_cost.py > gpurun_out/${TAG}_md_host_cost.txt 2>&1; tail -3 gpurun_out/${TAG}_md_host_cost.txt
+for w in 2 4 8; do timeout 300 python tools/brick_cost.py --world $w 2>&1 | grep -v amdgpu.ids | tail -2; done | tee gpurun_out/${TAG}_brick_costs.txt

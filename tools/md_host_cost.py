@@ -71,8 +71,10 @@ def main():
     P = lambda arr: C.c_void_p(arr.ctypes.data)  # noqa: E731
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def call():
+    def call(unchanged=False):
         f[:] = 0.0
+        if unchanged:   # what the pair style says between two LAMMPS list rebuilds (neighbor->ago > 0)
+            _lib.check(lib.snet_md_list_unchanged(host.h), 'snet_md_list_unchanged')
         _lib.check(lib.snet_md_compute(host.h, n, P(ilist), P(numneigh), C.cast(first, C.c_void_p), nall, P(xx), P(ty), P(tg), 4,
                                        P(tmap), 1, 0, 0, 1, 0, P(f), C.cast(C.byref(eng), C.c_void_p), P(vir), None, None,
                                        None, C.byref(nn), C.byref(ne), st), 'snet_md_compute')
@@ -83,7 +85,14 @@ def main():
         t0 = time.perf_counter()
         call()
         ts.append(time.perf_counter() - t0)
+    tu = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        call(True)
+        tu.append(time.perf_counter() - t0)
     print(f'edges inside the cutoff: {ne.value}; max |f| {np.abs(f).max():.4f}')
+    print(f'snet_md_compute per call BETWEEN list rebuilds (snet_md_list_unchanged: positions only travel): median '
+          f'{np.median(tu) * 1e3:.1f} ms, min {min(tu) * 1e3:.1f} ms')
     print(f'snet_md_compute per call (host flatten + H2D + GPU graph build + model + D2H): median {np.median(ts) * 1e3:.1f} ms, '
           f'min {min(ts) * 1e3:.1f} ms')
 
