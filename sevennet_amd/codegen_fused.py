@@ -120,6 +120,29 @@ def _emit_staging(A, lines: str):
     A('  };')
 
 
+def _emit_staging_groups(A):
+    """grouped form (one workgroup barrier per GROUP of up to GLN sub-steps): stage_load(s, n, b) requests the fragment lines of
+    sub-steps s .. s + n - 1 (consecutive in the stream), stage_store(n, b) parks them in slab[b]"""
+    A('  constexpr int NSTG = (GLN * LPS * 64 + NTH - 1) / NTH;')
+    A('  u32x4 st[GLDS ? 1 : NSTG];')
+    A('  auto stage_load = [&](int s, int n, int b) {')
+    A('    if constexpr (GLDS) {')
+    A('      for (int l = wave; l < n * LPS; l += NWV)')
+    A('        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(slabs + (size_t)s * (LPS * 64) + l * 64 + lane),')
+    A('                                         (__attribute__((address_space(3))) void *)(&slab[b][l * 64]), 16, 0, 0);')
+    A('    } else {')
+    A('#pragma unroll')
+    A('      for (int i = 0; i < NSTG; ++i) if (tid + NTH * i < n * LPS * 64) st[i] = slabs[(size_t)s * (LPS * 64) + tid + NTH * i];')
+    A('    }')
+    A('  };')
+    A('  auto stage_store = [&](int n, int b) {')
+    A('    if constexpr (!GLDS) {')
+    A('#pragma unroll')
+    A('      for (int i = 0; i < NSTG; ++i) if (tid + NTH * i < n * LPS * 64) slab[b][tid + NTH * i] = st[i];')
+    A('    }')
+    A('  };')
+
+
 def reverse_plan(p):
     """Nonzero pattern the reverse tensor-product body walks: per x component a, per output component c,
     the spherical-harmonic components b it couples with and C[a,b,c] (incl. the sqrt(2 l3 + 1) path norm)."""
@@ -312,15 +335,29 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  // diag: always 0 in production (bit 0 also serves as the opaque branch condition around the tensor-product bodies);')
     A('  // kernel-tuning builds: 1 skip the tensor product, 2 skip the g_h2 products, 4 skip the w products, 8 skip the')
     A('  // g_out loads, 16 skip the g_xe stores -- timing decomposition, results are then garbage')
-    A('  constexpr int LPS = 8 * NT, NTH = 64 * NWV, NST = (LPS * 64 + NTH - 1) / NTH;  // 1-KB fragment lines per sub-step')
-    A('  __shared__ u32x4 slab[2][LPS * 64];')
+    # Barrier groups (round 4, SNET_CODEGEN_OPTS=bgrp=<n>): the sub-steps of a block are walked in groups of up to BG; one slab of
+    # GLN sub-steps is staged and one workgroup barrier paid per GROUP instead of per sub-step (BG = 1: the round-3 form)
+    BG = max(1, int(OPTS.get('bgrp', 1)))
+    _bs0, _ = schedule_bwd(spec)
+    _ngp = max((sum(2 * p_.l3 + 1 for _, p_ in b_['cat'].paths) * b_['U'] + 15) // 16 * 16 for b_ in _bs0)
+    while BG > 1 and 2 * min(BG, max(len(b_['steps']) for b_ in _bs0)) * 8 * 2 * 1024 + 8 * (2 * _ngp * 64 + NSH * 64) > 150 * 1024:
+        BG -= 1   # the slabs of one 8-wave workgroup per CU must fit the LDS beside the waves' private buffers
+    GLN = min(BG, max(len(b_['steps']) for b_ in _bs0))
+    if GLN == 1:
+        BG = 1
+    A(f'  constexpr int LPS = 8 * NT, NTH = 64 * NWV, NST = (LPS * 64 + NTH - 1) / NTH, GLN = {GLN};  // 1-KB fragment lines per sub-step; sub-steps per slab')
+    A('  __shared__ u32x4 slab[2][GLN * LPS * 64];')
     A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
     A('  const int j = lane & 15, g = lane >> 4;')
     # Prologue order: every load is requested as soon as its address is known -- the first weight slab at once, the
     # node's g_out entries with the row pointers, the first source rows with h2 -- so the tile pays four dependent
     # memory latencies (tile -> node -> edge -> rows) instead of seven before its first matrix product.
-    _emit_staging(A, 'LPS')
-    A('  stage_load(0, 0);')
+    if BG > 1:
+        _emit_staging_groups(A)
+        A(f'  stage_load(0, {min(BG, len(_bs0[0]["steps"]))}, 0);')
+    else:
+        _emit_staging(A, 'LPS')
+        A('  stage_load(0, 0);')
     A('  const int t_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
     A('  const bool live = t_raw < n_tiles;')
     A('  const int t = __builtin_amdgcn_readfirstlane(live ? t_raw : n_tiles - 1);  // idle waves shadow the last tile, stores masked')
@@ -363,7 +400,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     _budget -= 24   # margin: the estimate is a lower bound of what hipcc's allocator ends up with
     XPF = VMORD and len(bsched) > 1 and _live + _xp_regs + 8 <= _budget and not OPTS.get('noxpf')
     # the hoisted slab request keeps the staging registers live across the block boundary: same budget rule
-    HOIST = VMORD and _live + 16 + 8 <= _budget and not OPTS.get('nohoist')
+    HOIST = VMORD and _live + 16 + 8 <= _budget and not OPTS.get('nohoist') and BG == 1   # (grouped staging requests a whole block ahead anyway)
     A(f'  constexpr int NGP = {NGP}, NK = {NK}, NSUB = {NSB};   // NSUB: sub-steps of the reverse kernel\'s weight stream')
     A('  __shared__ __attribute__((aligned(16))) float s_g[NWV][2][NGP * 16];')
     A('  f32x4 gpre[NK];')
@@ -452,7 +489,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('#pragma unroll')
     A('  for (int k = 0; k < NSH; ++k) gy[k] = 0.f;')
     emit_g_park('  ', 0, '0')
-    A('  stage_store(0);')
+    A('  stage_store(0);' if BG == 1 else f'  stage_store({min(BG, len(bsched[0]["steps"]))}, 0);')
     A('  __syncthreads();')
     if HOIST:
         A('  if (1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(1, 1);   // the first block\'s first sub-step does not request its slab itself')
@@ -487,6 +524,16 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A(f'  const float *xs{ci + 1}p = x + (size_t)s_src * DX + {cat_n.x_off} + 4 * g;')
             A(f'  f32x4 xp{ci + 1}[{U_n}][{d1_n}];')
         A(f'  for (int cb = 0; cb < {ncb}; ++cb) {{')
+        groups = [bs['steps'][i:i + BG] for i in range(0, len(bs['steps']), BG)]   # barrier groups of this block (BG = 1: one per sub-step)
+
+        def next_group_size(gi):
+            """C expression: number of sub-steps of the group that follows group gi of this block in the stream (0 at its end)"""
+            if gi + 1 < len(groups):
+                return str(len(groups[gi + 1]))
+            after = min(BG, len(bsched[ci + 1]['steps'])) if ci + 1 < len(bsched) else 0
+            return f'(cb + 1 < {ncb} ? {len(groups[0])} : {after})' if ncb > 1 else str(after)
+        if BG > 1:   # the slab of the group after this block's first one: requested before the gathers of the block top, a group ahead
+            A(f'    stage_load(sidx + {len(groups[0])}, ' + ('(diag & 32) ? 0 : ' if exp else '') + f'{next_group_size(0)}, buf ^ 1);')
         A(f'    f32x4 (&xr)[{U}][{d1}] = xr{ci};')
         A(f'    f32x4 gx[{U}][{d1}];')
         for u in range(U):
@@ -520,12 +567,16 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             emit_g_loads('    ', ci + 1, '0')
         for si_, (ta, tb) in enumerate(bs['steps']):
             A('    {')
-            if not (HOIST and si_ == 0):   # (first sub-step of a block: requested at the end of the previous block / the prologue)
+            gi_, pos_ = si_ // BG, si_ % BG       # barrier group of this sub-step and its place inside it
+            if BG > 1:
+                if pos_ == 0 and gi_ > 0:         # (group 0: requested at the block top)
+                    A(f'      stage_load(sidx + {len(groups[gi_])}, ' + ('(diag & 32) ? 0 : ' if exp else '') + f'{next_group_size(gi_)}, buf ^ 1);')
+            elif not (HOIST and si_ == 0):   # (first sub-step of a block: requested at the end of the previous block / the prologue)
                 A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, buf ^ 1);')
             # hipcc's machine scheduler, left alone, sinks the prefetch loads next to their use (zero overlap) and
             # interleaves the phases until ~200 VGPRs spill: pin the prefetch at the top and fence the phases
             A('      __builtin_amdgcn_sched_barrier(0);')
-            A('      const u32x4 *sl = slab[buf];')
+            A('      const u32x4 *sl = slab[buf]' + (f' + {pos_} * (LPS * 64);' if BG > 1 else ';'))
             A('      f32x4 gw0 = f32x4{0.f, 0.f, 0.f, 0.f}, gw1 = gw0;')
             # kernel-tuning knobs, both measured neutral on MI355X (SevenNet-0 middle layer): wfirst = both tiles' weight
             # products before the first tensor-product body (6.38 vs 6.26 ms); gpf = the g-part fragments requested
@@ -603,9 +654,15 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A('        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
                 A('        ga[m] = mfma16_split<NT, F16>(a, b, ga[m]);')
             A('      }')
-            A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_store(buf ^ 1);')
-            A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
-            A('      buf ^= 1;')
+            if BG > 1:
+                if pos_ == len(groups[gi_]) - 1:   # last sub-step of its group: park the next group's slab, one barrier
+                    A(f'      stage_store(' + ('(diag & 32) ? 0 : ' if exp else '') + f'{next_group_size(gi_)}, buf ^ 1);')
+                    A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
+                    A('      buf ^= 1;')
+            else:
+                A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_store(buf ^ 1);')
+                A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
+                A('      buf ^= 1;')
             A('      ++sidx;')
             A('    }')
         if HOIST:   # the next block's first sub-step: its slab request goes out BEFORE this block's stores
@@ -1132,13 +1189,15 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
             A(f'  if (nt == 4 && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
     def bwd_lds(nt, nwv):
-        return 2 * 8 * nt * 1024 + nwv * (2 * NGP * 64 + NSH * 64)
+        return 2 * GLN * 8 * nt * 1024 + nwv * (2 * NGP * 64 + NSH * 64)
 
     def bwd_cfg(nt):
         # measured on MI355X (SevenNet-0 middle layer): three 4-wave workgroups per CU (LDS <= 53 KB each, <= 168
         # VGPRs) beat two; when the slab does not leave room for three, two 4-wave workgroups at 256 VGPRs
         if 'fnwv' in OPTS:
             return def_b
+        if GLN > 1 and bwd_lds(nt, 8) <= 150 * 1024:   # grouped staging: one 8-wave workgroup per CU shares the GLN-sub-step slabs
+            return (8, 0, 2)
         # first interaction layer (scalar inputs only, one x block): one 8-wave workgroup sharing each slab beats three
         # 4-wave ones (in the step: 1.76 vs 2.01 ms).  NOT the last layer's shape (three one-path x blocks): 8 waves
         # win its stand-alone timing (3.21 vs 3.46 ms) but lose inside the step with the hidden-layer tail (4.04 vs 3.53)
