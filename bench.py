@@ -136,6 +136,40 @@ def kernel_model(ls, n_nodes, n_edges, mlp_tail=False, nb=8):
     }
 
 
+def scheduled_work(eng, graph):
+    """Arithmetic one evaluation of THIS rank's graph schedules, from the engine's own tables: matrix-core flops as issued (each
+    low-precision product of a split counted) and the vector-pipe flops of the sparse tensor products (forward + reverse)."""
+    from sevennet_amd.codegen import _path_terms
+    E, N, NT = graph.n_edges, graph.n_local, graph.n_total
+    P = graph.n_pairs if graph.w_row is not None else E
+    terms = {1: 1, 2: 3, 3: 6, 4: 3}[eng.fused_terms]
+    mfma = valu = 0.0
+    for t, L in enumerate(eng.layers):
+        ls = L.spec
+        wn, d = ls.conv.weight_numel, ls.mlp_dims
+        mfma += 2.0 * P * (d[0] * d[1] + d[1] * d[2]) * 6                      # hidden radial layers, forward (bf16x6)
+        mfma += 2.0 * E * 64 * wn * terms                                      # w = h2 W2 inside the forward kernel
+        mfma += 2.0 * 2.0 * E * 64 * wn * terms                                # reverse: w again and g_h2 += g_w W2^T
+        mfma += 2.0 * E * (2 * d[0] * d[1] + 2 * d[1] * d[2]) * terms          # hidden-layer tail of the reverse kernel
+        if getattr(L, 'tplan', None) is not None:
+            mfma += 2.0 * E * 64 * wn * terms                                  # transposed scalar convolution (last layer)
+        for lin in (L.sc, L.si1, L.si2):
+            if lin is None or (t == 0 and lin is not L.si2 and eng.h0_table is not None):
+                continue                                                       # (layer 0: species tables, no GEMM)
+            rows = N
+            f = sum((2 * b.l + 1) * b.mul_in * b.mul_out for b in lin.spec.blocks if b.species <= 0)
+            mfma += 2.0 * rows * f * 6 * (1 if t == 0 else 2)                  # forward + transposed (layer 0: forward only)
+        for p in ls.conv.paths:
+            tr = _path_terms(p)
+            nnz, pab, pac = len(tr), len({(a_, b_) for a_, b_, _, _ in tr}), len({(a_, c_) for a_, _, c_, _ in tr})
+            d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
+            valu += E * p.mul * (2.0 * nnz + pab + 2.0 * d3)                   # forward body per (edge, channel)
+            valu += E * (2.0 * nnz + p.mul * (4.0 * pac + 5.0 * d1))           # reverse body: V per edge, P / s per (a, c), 3 per a
+            if getattr(L, 'tplan', None) is not None:
+                valu += E * p.mul * (2.0 * nnz + pab + 2.0 * d1)               # transposed convolution of the same paths
+    return dict(mfma=mfma, valu=valu)
+
+
 def cpu_model_name():
     try:
         with open('/proc/cpuinfo') as f:
@@ -421,15 +455,28 @@ def main():
         dist.all_reduce(e_total)
     roof['kernel_ms_per_step'] = {k: round(v / n_break, 4) for k, v in sorted(totals.items(), key=lambda kv: -kv[1])}
     roof['avg_ms_source'] = 'HIP events inside the timed steps' if len(timed_dom) else 'HIP events of an untimed pass of the same kernels (native host)'
-    # whole step against SURVEY.md 8(d)'s algorithmic work: bytes at the HBM peak, flops at the fp32 matrix peak
+    # whole step: SURVEY.md 8(d)'s algorithmic BYTES against the HBM peak, and the arithmetic the engine actually SCHEDULES (pruned
+    # paths, sparse Clebsch-Gordan tensors, split-precision products counted once per matrix-core product issued) against the
+    # pipes it runs on.  SURVEY's dense-CG fp32 FLOP count is kept as information only: divided into a step that runs the dense
+    # contractions as low-precision splits on the 2.5-PF pipe and prunes unread paths it gave "fractions" above 1.
     if a.model in STEP_WORK:
         sb, sf = (v * n_atoms for v in STEP_WORK[a.model])
         t = dt / a.steps * world   # GPU-seconds per step
-        roof['step'] = dict(bytes=sb, flops=sf, frac_hbm=sb / t / (HBM_PEAK_GBS * 1e9), frac_mfma=sf / t / (MFMA_F32_PEAK_TF * 1e12),
-                            floor_ms=max(sb / (HBM_PEAK_GBS * 1e9), sf / (MFMA_F32_PEAK_TF * 1e12)) * 1e3,
-                            note='SURVEY.md 8(d): 0.992 MB and 44.5 MFLOP per atom-step for SevenNet-0 (fwd + reverse, no cache '
-                                 'credit, radial weights not materialised); fractions of 8 TB/s and of the 157.3 TFLOP/s fp32 '
-                                 'matrix peak over the measured step time')
+        sched = scheduled_work(eng, graph)
+        valu_peak = 256 * 64 * 2 * 2.4e9   # 256 CUs x 64 fp32 lanes x FMA x 2.4 GHz (non-packed): 78.6 TFLOP/s
+        roof['step'] = dict(bytes=sb, frac_hbm=sb / t / (HBM_PEAK_GBS * 1e9), floor_ms_hbm=sb / (HBM_PEAK_GBS * 1e9) * 1e3,
+                            mfma_flops_issued=sched['mfma'], valu_flops=sched['valu'],
+                            frac_mfma_issued=sched['mfma'] * world / t / (MFMA_BF16_PEAK_TF * 1e12),
+                            frac_valu=sched['valu'] * world / t / valu_peak,
+                            flops_survey_dense_fp32=sf,
+                            note='bytes: SURVEY.md 8(d) per atom-step (fwd + reverse, no cache credit, radial weights not '
+                                 'materialised) over 8 TB/s.  mfma_flops_issued: every 16x16x32 / 32x32x16 product the kernels issue '
+                                 '(in-kernel W2 products x3 for f16x3, node linears and hidden radial layers x6 for bf16x6) over the '
+                                 '2.5 PFLOP/s dense f16 / bf16 peak.  valu_flops: the sparse tensor-product arithmetic as generated '
+                                 '(forward: nnz(C) FMAs + pair products per channel; reverse: Clebsch-Gordan tensor contracted with the '
+                                 'harmonics per edge, two FMAs per nonzero (a, c) pair and three per x component per channel) over '
+                                 '78.6 TFLOP/s (256 CUs x 64 lanes x FMA x 2.4 GHz).  flops_survey_dense_fp32 = SURVEY.md 8(d)\'s '
+                                 'dense-CG count, for reference only.')
 
     # ghost exchange of this rank per step: L-1 forward (width dx_t) + L-1 reverse exchanges + one force fold; bytes = rows
     # sent + received; time = HIP-event brackets around the exchange calls (with the split exchange the brackets cover
