@@ -543,11 +543,14 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             for u in range(U_n):
                 for m in range(d1_n):
                     A(f'{ind}xp{ci + 1}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci + 1}p + {16 * u + m * cat_n.mul});')
+        NOXN = bool(OPTS.get('noxn'))   # kernel-tuning: no register prefetch of the next block's source rows (they are requested
+        #                                 at the end of the block instead, straight into xr): 4 U d1 registers fewer, latency left to occupancy
         if ncb > 1:
             A(f'    if (cb + 1 < {ncb}' + (' && !(diag & 64)' if exp else '') + ') {')
             for u in range(U):
                 for m in range(d1):
-                    A(f'      xn{ci}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {16 * U} * (cb + 1) + {16 * u + m * cat.mul});')
+                    if not NOXN:
+                        A(f'      xn{ci}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {16 * U} * (cb + 1) + {16 * u + m * cat.mul});')
             if XPF and ci + 1 < len(bsched):
                 A('    } else {')
                 emit_next_xblock_rows('      ')
@@ -691,7 +694,13 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             emit_g_park('    ', ci + 1, 'gbuf ^ 1')
         A('    gbuf ^= 1;')
         A('    __builtin_amdgcn_wave_barrier();')
-        if ncb > 1:
+        if ncb > 1 and NOXN:
+            A(f'    if (cb + 1 < {ncb}) {{')
+            for u in range(U):
+                for m in range(d1):
+                    A(f'      xr{ci}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {16 * U} * (cb + 1) + {16 * u + m * cat.mul});')
+            A('    }')
+        elif ncb > 1:
             A('#pragma unroll')
             A(f'    for (int u = 0; u < {U}; ++u)')
             A('#pragma unroll')
