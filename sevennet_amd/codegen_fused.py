@@ -543,7 +543,11 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             for u in range(U_n):
                 for m in range(d1_n):
                     A(f'{ind}xp{ci + 1}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci + 1}p + {16 * u + m * cat_n.mul});')
-        NOXN = bool(OPTS.get('noxn'))   # kernel-tuning: no register prefetch of the next block's source rows (they are requested
+        # x blocks with 2 l + 1 >= noxn get no register prefetch of the next block's source rows.  Default: the l = 3 blocks of the
+        # shapes that sit at 256 registers (round 4: with the prefetch those kernels spilled 15 .. 33 registers, and a spill reload
+        # waits for every older gather; without it 0 .. 7, l3i5 middle layer 11.22 -> 11.02 ms).  SNET_CODEGEN_OPTS=noxn=<d1> overrides
+        _noxn = int(OPTS.get('noxn', 7 if _live > 200 else 0))
+        NOXN = _noxn > 0 and d1 >= _noxn   # (they are requested
         #                                 at the end of the block instead, straight into xr): 4 U d1 registers fewer, latency left to occupancy
         if ncb > 1:
             A(f'    if (cb + 1 < {ncb}' + (' && !(diag & 64)' if exp else '') + ') {')

@@ -570,6 +570,32 @@ def test_bench_multi_rank_path_dry_run():
         assert abs(many['config']['energy'] - one['config']['energy']) <= 1e-9 * abs(one['config']['energy'])
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: real RCCL at world size 2')
+def test_bench_two_ranks_real_rccl():
+    """the day a box has two GPUs this runs `bench.py --gpus 2` on REAL RCCL (one rank per GPU, the library's own
+    send / recv groups over xGMI, interior / boundary split around every exchange, both hosts): the total energy must equal the
+    single-process one and the line must carry the halo fields.  Skipped on the one-GPU boxes of this pool."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['--reps', '8', '--steps', '2', '--warmup', '1', '--no-cpu-baseline']
+
+    def run(cmd):
+        r = subprocess.run(cmd, cwd=root, env=dict(os.environ), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    one = run([sys.executable, 'bench.py'] + common)
+    for host in ('python', 'native'):
+        two = run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                   '--master-port', '29631', 'bench.py', '--gpus', '2', '--host', host] + common)
+        assert two['n_gpus'] == 2 and two['config']['atoms'] == one['config']['atoms'] and two['config']['edges'] == one['config']['edges']
+        assert abs(two['config']['energy'] - one['config']['energy']) <= 1e-9 * abs(one['config']['energy'])
+        assert 'RCCL' in two['config']['halo'] and two['config']['halo_exchanges_per_step'] == 9
+        assert two['config']['halo_exposed_ms'] is not None
+
+
 MD_FMAX = 8.0  # eV/A: largest force component of the MD-scale parity systems
 
 
