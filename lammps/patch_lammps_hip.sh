@@ -1,5 +1,5 @@
 #!/bin/bash
-# Add the engine-backed pair styles `e3gnn` and `e3gnn/parallel` to a LAMMPS source tree.
+# Add the engine-backed pair styles `e3gnn`, `e3gnn/parallel` and `d3` to a LAMMPS source tree.
 #
 #   bash lammps/patch_lammps_hip.sh <lammps_root> [<dir holding libsnet_hip.so>] [<cxx_standard>]
 #
@@ -42,8 +42,8 @@ mkdir -p "$backup_dir"
 cp "$lammps_root/cmake/CMakeLists.txt" "$backup_dir/CMakeLists.txt"
 
 # 1. the pair styles and the C ABI they call
-cp "$SCRIPT_DIR"/pair_e3gnn_hip.{h,cpp} "$lammps_root/src/"
-cp "$SCRIPT_DIR/../include/snet_hip.h" "$lammps_root/src/"
+cp "$SCRIPT_DIR"/pair_e3gnn_hip.{h,cpp} "$SCRIPT_DIR"/pair_d3_hip.{h,cpp} "$lammps_root/src/"
+cp "$SCRIPT_DIR/../include/snet_hip.h" "$SCRIPT_DIR/../include/snet_d3_ref.h" "$lammps_root/src/"
 
 # 2. cmake: C++ standard, HIP runtime, libsnet_hip.so (with an rpath so that `lmp` finds it)
 sed -i "s/set(CMAKE_CXX_STANDARD 11)/set(CMAKE_CXX_STANDARD $cxx_standard)/" "$lammps_root/cmake/CMakeLists.txt"
@@ -59,6 +59,6 @@ set_property(TARGET lammps APPEND PROPERTY BUILD_RPATH "$lib_dir")
 set_property(TARGET lammps APPEND PROPERTY INSTALL_RPATH "$lib_dir")
 EOF2
 
-echo "Patched $lammps_root: pair styles e3gnn and e3gnn/parallel (libsnet_hip.so from $lib_dir)."
+echo "Patched $lammps_root: pair styles e3gnn, e3gnn/parallel and d3 (libsnet_hip.so from $lib_dir)."
 echo "Build:  cd $lammps_root && mkdir -p build && cd build && cmake ../cmake -DCMAKE_CXX_COMPILER=hipcc -DBUILD_MPI=yes && make -j"
 echo "Model:  python -m sevennet_amd.deploy <checkpoint.pth> -o model.snet    (pair_coeff * * model.snet <elements>)"

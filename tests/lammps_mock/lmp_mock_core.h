@@ -31,11 +31,18 @@ class Memory {
 };
 class Atom {
  public:
+  long natoms;
   int nlocal, nghost, ntypes;
   double **x, **f;
   int *type;
   tagint *tag;
   int tag_consecutive();
+};
+class Domain {
+ public:
+  int xperiodic, yperiodic, zperiodic;
+  double boxlo[3], boxhi[3];
+  double xy, xz, yz;
 };
 class Comm {
  public:
@@ -79,6 +86,7 @@ class Pointers {
   Comm *&comm;
   Force *&force;
   Neighbor *&neighbor;
+  Domain *&domain;
   MPI_Comm &world;
 };
 }  // namespace LAMMPS_NS

@@ -32,6 +32,23 @@ def test_pair_style_sources_type_check_against_mock_lammps():
         assert re.search(r'\b' + fn + r'\(', api), fn
 
 
+@pytest.mark.skipif(shutil.which('g++') is None, reason='needs g++')
+def test_pair_style_d3_type_checks_against_mock_lammps():
+    """lammps/pair_d3_hip.{h,cpp}: the reference's `pair_style d3` grammar (pair_d3.cu:261-285,644-656) over the library's
+    `pair_*` D3 binding -- parses and type-checks against the mock; every library function it calls is declared"""
+    import re
+    r = subprocess.run(['g++', '-std=c++17', '-fsyntax-only', '-Wall', '-I', os.path.join(ROOT, 'tests', 'lammps_mock'),
+                        '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'lammps', 'pair_d3_hip.cpp')],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert [ln for ln in r.stderr.splitlines() if 'pair_d3_hip' in ln and ('warning' in ln or 'error' in ln)] == []
+    assert 'PairStyle(d3, PairD3Hip)' in open(os.path.join(ROOT, 'lammps', 'pair_d3_hip.h')).read()
+    c = open(os.path.join(ROOT, 'lammps', 'pair_d3_hip.cpp')).read()
+    api = open(os.path.join(ROOT, 'include', 'snet_d3_ref.h')).read() + open(os.path.join(ROOT, 'include', 'snet_hip.h')).read()
+    for fn in sorted(set(re.findall(r'\b(pair_(?:init|set_atom|set_domain|run_settings|run_coeff|run_compute|get_energy|get_force|get_stress|fin)|snet_[a-z0-9_]+)\(', c))):
+        assert re.search(r'\b' + fn + r'\(', api), fn
+
+
 def test_patch_script_on_a_lammps_shaped_tree(tmp_path):
     lmp = tmp_path / 'lammps'
     (lmp / 'cmake').mkdir(parents=True)
@@ -43,7 +60,7 @@ def test_patch_script_on_a_lammps_shaped_tree(tmp_path):
     script = os.path.join(ROOT, 'lammps', 'patch_lammps_hip.sh')
     r = subprocess.run(['bash', script, str(lmp), str(libdir)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    for f in ('pair_e3gnn_hip.h', 'pair_e3gnn_hip.cpp', 'snet_hip.h'):
+    for f in ('pair_e3gnn_hip.h', 'pair_e3gnn_hip.cpp', 'pair_d3_hip.h', 'pair_d3_hip.cpp', 'snet_hip.h', 'snet_d3_ref.h'):
         assert (lmp / 'src' / f).exists(), f
     cm = (lmp / 'cmake' / 'CMakeLists.txt').read_text()
     assert 'set(CMAKE_CXX_STANDARD 17)' in cm and 'libsnet_hip.so' in cm and 'find_package(hip REQUIRED)' in cm
