@@ -201,6 +201,14 @@ int snet_fused_plan_create(const snet_conv_plan *plan, const snet_mlp_plan *mlp,
 void snet_fused_plan_destroy(snet_fused_plan *plan);
 int snet_edge_tiles(const int32_t *row_ptr, int64_t n_dst, int32_t *tile_ptr, int32_t *tile_node, int64_t tile_capacity,
                     int64_t *n_tiles, void *stream);
+/* Packed work list (reverse kernels whose snet_fused_plan_tile_mode() is 1 -- every shape whose registers hold a second
+ * row's g_out entries; the lmax-3 shapes keep the per-row tiles of snet_edge_tiles, mode 0): a tile is a window of <= 16 CONSECUTIVE CSR edges of
+ * the destination rows [node_begin, node_end) that touches at most two rows.  tile_e0[n_tiles + 1] (first edge of every
+ * tile, then the end of the last) goes where the reverse kernel takes tile_ptr, tile_nodes[2 n_tiles] (row of the tile's
+ * first / last edge) where it takes tile_node.  (node_end - node_begin) + n_edges / 16 tiles always suffice. */
+int snet_edge_tiles_packed(const int32_t *row_ptr, int64_t node_begin, int64_t node_end, int32_t *tile_e0,
+                           int32_t *tile_nodes, int64_t tile_capacity, int64_t *n_tiles, void *stream);
+int snet_fused_plan_tile_mode(const snet_fused_plan *plan);
 /* Scalar-output shapes (every path (l, l -> 0): the last interaction layer): the source-row gradient
  *   g_x[j] = sum over the edges e that have j as their source of  w_e * T * Y(e) * g_out[center(e)]
  * is itself a uvu convolution -- shape `tag` (x = the g_out row, out = g_x), radial weights W2 with column c scaled by

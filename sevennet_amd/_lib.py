@@ -127,6 +127,8 @@ SIGNATURES = {
     'snet_model_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32), C.c_int32]),
     'snet_model_meta': (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32]),
+    'snet_edge_tiles_packed': (C.c_int, [c_i32p, C.c_int64, C.c_int64, c_i32p, c_i32p, C.c_int64, C.POINTER(C.c_int64), c_stream]),
+    'snet_fused_plan_tile_mode': (C.c_int, [C.c_void_p]),
     'snet_i32_shift': (C.c_int, [c_i32p, C.c_int32, c_i32p, C.c_int64, c_stream]),
     'snet_model_set_interior': (C.c_int, [C.c_void_p, C.c_int64]),
     'snet_model_set_topology_cache': (C.c_int, [C.c_void_p, C.c_int32]),

@@ -338,8 +338,16 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     # Barrier groups (round 4, SNET_CODEGEN_OPTS=bgrp=<n>): the sub-steps of a block are walked in groups of up to BG; one slab of
     # GLN sub-steps is staged and one workgroup barrier paid per GROUP instead of per sub-step (BG = 1: the round-3 form)
     BG = max(1, int(OPTS.get('bgrp', 1)))
+    # Packed tiles (SNET_CODEGEN_OPTS=xtile=1): a tile is a window of <= 16 consecutive CSR edges that may run from one destination
+    # node (A) into the next one that has edges (B); snet_edge_tiles_packed writes tile_ptr[t] = first edge, tile_node[2t .. 2t+1] = A, B.
+    # The wave keeps BOTH nodes' g_out entries in its LDS buffer and every edge lane reads its own node's set.
+    # Chosen per shape: the second node's prefetched entries cost 4 NK more registers, which the lmax-3 shapes (at 256 already) do
+    # not have (round 4: 20 .. 2400 spilled registers with it; estimate 227 .. 243 against 195 for the largest shape that fits); SNET_CODEGEN_OPTS=xtile=0 / 1 forces it.
     _bs0, _ = schedule_bwd(spec)
     _ngp = max((sum(2 * p_.l3 + 1 for _, p_ in b_['cat'].paths) * b_['U'] + 15) // 16 * 16 for b_ in _bs0)
+    _live2 = 12 * max(2 * c_.l1 + 1 for c_ in cats) + 32 + NSH + 8 * (_ngp // 16) + 16 + 4 * max(2 * p_.l3 + 1 for p_ in spec.paths) + 35
+    XT = bool(int(OPTS['xtile'])) if 'xtile' in OPTS else _live2 <= 200
+    GS = 2 if XT else 1
     while BG > 1 and 2 * min(BG, max(len(b_['steps']) for b_ in _bs0)) * 8 * 2 * 1024 + 8 * (2 * _ngp * 64 + NSH * 64) > 150 * 1024:
         BG -= 1   # the slabs of one 8-wave workgroup per CU must fit the LDS beside the waves' private buffers
     GLN = min(BG, max(len(b_['steps']) for b_ in _bs0))
@@ -361,7 +369,12 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  const int t_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
     A('  const bool live = t_raw < n_tiles;')
     A('  const int t = __builtin_amdgcn_readfirstlane(live ? t_raw : n_tiles - 1);  // idle waves shadow the last tile, stores masked')
-    A('  const int node = __builtin_amdgcn_readfirstlane(tile_node[t]);')
+    if XT:
+        A('  const int node = __builtin_amdgcn_readfirstlane(tile_node[2 * t]);       // A: the node of the tile\'s first edge')
+        A('  const int node_b = __builtin_amdgcn_readfirstlane(tile_node[2 * t + 1]);  // B: the node of its last edge (= A for most tiles of a long segment)')
+        A('  const bool two = node_b != node;')
+    else:
+        A('  const int node = __builtin_amdgcn_readfirstlane(tile_node[t]);')
     # The node's g_out entries of one (x block, 16-channel tile) are shared by the 16 edge lanes of a group.  They
     # are fetched ONCE per wave, one block ahead, by one or two 16-byte loads per lane (lane L: channels 4 (L & 3)
     # .. +3 of entry 16 k + (L >> 2); vector-memory instructions, not bytes, are what this kernel runs out of),
@@ -384,7 +397,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     _gl0 = [[1 for u in range(bs_['U']) for _, p_ in bs_['cat'].paths for _ in range(2 * p_.l3 + 1)] for bs_ in bsched]
     _ngp0 = max((len(g_) + 15) // 16 * 16 for g_ in _gl0)
     if 2 * 8 * 2 * 1024 + 4 * (2 * _ngp0 * 64 + spec.irreps_sh.dim * 64) <= 53 * 1024 and \
-            12 * max(2 * c_.l1 + 1 for c_ in cats) + 32 + spec.irreps_sh.dim + 4 * (_ngp0 // 16) + 16 + 4 * max(2 * p_.l3 + 1 for p_ in spec.paths) + 35 <= 168:
+            12 * max(2 * c_.l1 + 1 for c_ in cats) + 32 + spec.irreps_sh.dim + 4 * GS * (_ngp0 // 16) + 16 + 4 * max(2 * p_.l3 + 1 for p_ in spec.paths) + 35 <= (160 if XT else 168):
         GUNC = GUNC and bool(OPTS.get('gunc3'))   # three-waves-per-SIMD shapes (168 registers): the unpredicated form spilled 9 there
     glists = [[(pi, m3, u) for u in range(bs['U']) for pi, p in bs['cat'].paths for m3 in range(2 * p.l3 + 1)] for bs in bsched]
     NGP = max((len(gl) + 15) // 16 * 16 for gl in glists)   # rows of the LDS buffer (padded to 16 entries per load)
@@ -394,17 +407,25 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     # spilled 200+ registers with it)
     _maxd1 = max(2 * c_.l1 + 1 for c_ in cats)
     _maxd3 = max(2 * p_.l3 + 1 for p_ in spec.paths)
-    _live = 12 * _maxd1 + 32 + NSH + 4 * NK + 16 + 4 * _maxd3 + 35
-    _budget = 168 if (2 * 8 * 2 * 1024 + 4 * (2 * NGP * 64 + NSH * 64) <= 53 * 1024 and _live <= 168) else 256
+    _live = 12 * _maxd1 + 32 + NSH + 4 * GS * NK + 16 + 4 * _maxd3 + 35
+    _budget = 168 if (2 * 8 * 2 * 1024 + 4 * (2 * NGP * 64 + NSH * 64) <= 53 * 1024 and _live <= (160 if XT else 168)) else 256
     _xp_regs = max([4 * b_['U'] * (2 * b_['cat'].l1 + 1) for b_ in bsched[1:]] or [0])
     _budget -= 24   # margin: the estimate is a lower bound of what hipcc's allocator ends up with
     XPF = VMORD and len(bsched) > 1 and _live + _xp_regs + 8 <= _budget and not OPTS.get('noxpf')
     # the hoisted slab request keeps the staging registers live across the block boundary: same budget rule
     HOIST = VMORD and _live + 16 + 8 <= _budget and not OPTS.get('nohoist') and BG == 1   # (grouped staging requests a whole block ahead anyway)
     A(f'  constexpr int NGP = {NGP}, NK = {NK}, NSUB = {NSB};   // NSUB: sub-steps of the reverse kernel\'s weight stream')
-    A('  __shared__ __attribute__((aligned(16))) float s_g[NWV][2][NGP * 16];')
-    A('  f32x4 gpre[NK];')
-    A('  const float *gnode = g_out + (size_t)((diag & 256) ? (node & 63) : node) * DOUT + 4 * (lane & 3);')
+    if XT:
+        # (one buffer per node, not two per block parity: the entries of the next block are parked after this block's last read, and a
+        # wave's LDS operations execute in order)
+        A('  __shared__ __attribute__((aligned(16))) float s_g[NWV][2][NGP * 16];')
+        A('  f32x4 gpre[NK], gpre_b[NK];')
+        A('  const float *gnode = g_out + (size_t)node * DOUT + 4 * (lane & 3);')
+        A('  const float *gnode_b = g_out + (size_t)node_b * DOUT + 4 * (lane & 3);')
+    else:
+        A('  __shared__ __attribute__((aligned(16))) float s_g[NWV][2][NGP * 16];')
+        A('  f32x4 gpre[NK];')
+        A('  const float *gnode = g_out + (size_t)((diag & 256) ? (node & 63) : node) * DOUT + 4 * (lane & 3);')
     for ci, gl in enumerate(glists):   # per-lane offsets of the entries this lane fetches (-1: none)
         for k in range((len(gl) + 15) // 16):
             # (vmord: padding entries load offset 0 unconditionally -- their LDS rows are never read -- instead of a predicated
@@ -424,25 +445,42 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             sc_ = ' * scale' if not GRAW else ''
             pred = '' if GUNC else f'(goff{ci}_{k} < 0) ? f32x4{{0.f, 0.f, 0.f, 0.f}} : '
             A(f'{ind}gpre[{k}] = {dg}{pred}*reinterpret_cast<const f32x4 *>(gnode + goff{ci}_{k} + {16 * U_} * ({cb_expr})){sc_};')
+        if XT:   # node B's entries: a wave-uniform branch, most tiles of a long segment have one node
+            A(f'{ind}if (two) {{')
+            for k in range((len(gl) + 15) // 16):
+                A(f'{ind}  gpre_b[{k}] = {dg}{pred}*reinterpret_cast<const f32x4 *>(gnode_b + goff{ci}_{k} + {16 * U_} * ({cb_expr})){sc_};')
+            A(f'{ind}}}')
 
     def emit_g_park(ind, ci, buf_expr):
         gl = glists[ci]
         for k in range((len(gl) + 15) // 16):
             sc_ = ' * scale' if GRAW else ''
-            A(f'{ind}*reinterpret_cast<f32x4 *>(&s_g[wave][{buf_expr}][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]) = gpre[{k}]{sc_};')
+            A(f'{ind}*reinterpret_cast<f32x4 *>(&s_g[wave][{"0" if XT else buf_expr}][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]) = gpre[{k}]{sc_};')
+        if XT:
+            A(f'{ind}if (two) {{')
+            for k in range((len(gl) + 15) // 16):
+                A(f'{ind}  *reinterpret_cast<f32x4 *>(&s_g[wave][1][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]) = gpre_b[{k}]{sc_};')
+            A(f'{ind}}}')
 
     def g_row(ci, pi, m3, u):
         return glists[ci].index((pi, m3, u))
 
     emit_g_loads('  ', 0, '0')
-    A('  const int e0 = row_ptr[node] + 16 * (t - tile_ptr[node]);')
-    A('  const int cnt = min(16, row_ptr[node + 1] - e0);')
+    if XT:
+        A('  const int e0 = tile_ptr[t];')
+        A('  const int cnt = tile_ptr[t + 1] - e0;')
+        A('  const int e_b = two ? row_ptr[node + 1] : 0x7fffffff;   // first edge of node B')
+    else:
+        A('  const int e0 = row_ptr[node] + 16 * (t - tile_ptr[node]);')
+        A('  const int cnt = min(16, row_ptr[node + 1] - e0);')
     A('  const bool valid = live && j < cnt;')
     A('  const int e = e0 + min(j, cnt - 1);')
+    if XT:
+        A('  const int in_b = e >= e_b ? 1 : 0;')
     A('  const int s_src = src[e];')
     A('  const int wr = w_row ? w_row[e] : e;')
     A('  float x_bound = 0.f;')
-    A('  if constexpr (F16) x_bound = tail.x_max[s_src] * tail.g_max[node];')
+    A('  if constexpr (F16) x_bound = tail.x_max[s_src] * tail.g_max[' + ('in_b ? node_b : node' if XT else 'node') + '];')
     _c0, _U0 = cats[0], bsched[0]['U']
     _d0 = 2 * _c0.l1 + 1
     A(f'  const float *xs0 = x + (size_t)s_src * DX + {_c0.x_off} + 4 * g;')
@@ -561,7 +599,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A('    }')
         elif XPF and ci + 1 < len(bsched):
             emit_next_xblock_rows('    ')
-        A('    const float *gl_ = &s_g[wave][gbuf][4 * g];')
+        A('    const float *gl_ = &s_g[wave][' + ('in_b' if XT else 'gbuf') + '][4 * g];')
         # next block's g_out entries: this x block's next block, or the first block of the next x block
         if ncb > 1:
             A(f'    if (cb + 1 < {ncb}) {{')
@@ -1223,8 +1261,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         # with spills, 6.43 at two waves without)
         maxd1 = max(2 * c.l1 + 1 for c in cats)
         maxd3 = max(2 * p.l3 + 1 for p in spec.paths)
-        live = 12 * maxd1 + 32 + NSH + 4 * NK + 16 + 4 * maxd3 + 35
-        if bwd_lds(nt, 4) <= 53 * 1024 and live <= 168:
+        live = 12 * maxd1 + 32 + NSH + 4 * GS * NK + 16 + 4 * maxd3 + 35
+        if bwd_lds(nt, 4) <= 53 * 1024 and live <= (160 if XT else 168):   # (packed tiles: 164 estimated spilled 20 at 168)
             return (4, 0, 3)
         if bwd_lds(nt, 4) <= 80 * 1024:
             return (4, 0, 2)
@@ -1281,7 +1319,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         cond = f' (nt == {nt_})' if kw != 'else' else ''
         A(f'  {kw}{cond} launch_fwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
     A('}')
-    A(f'const snet::FusedKernels kernels = {{"{tag}", DX, DOUT, NSH, WN, NS, SUB_COLS, {len(cols_rev)}, SUB_COLS_B, GXE_CHUNK, launch_bwd, launch_fwd}};')
+    A(f'const snet::FusedKernels kernels = {{"{tag}", DX, DOUT, NSH, WN, NS, SUB_COLS, {len(cols_rev)}, SUB_COLS_B, GXE_CHUNK, launch_bwd, launch_fwd, {1 if XT else 0}}};')
     A('const snet::FusedRegistrar registrar(&kernels);')
     A('}  // namespace')
     return '\n'.join(L) + '\n'

@@ -142,6 +142,7 @@ int snet_conv_fused_available(const snet_conv_plan *plan) {
   return plan != nullptr && snet::find_fused(plan->k->tag) != nullptr;
 }
 
+
 int snet_fused_plan_create(const snet_conv_plan *plan, const snet_mlp_plan *mlp, int32_t terms, snet_fused_plan **out) {
   SNET_REQUIRE(plan != nullptr && mlp != nullptr && out != nullptr, "snet_fused_plan_create: null argument");
   SNET_REQUIRE(terms >= 1 && terms <= 4,
@@ -168,6 +169,7 @@ int snet_fused_plan_create(const snet_conv_plan *plan, const snet_mlp_plan *mlp,
   *out = new snet_fused_plan{k, terms, dev, dev_b, hid, {exps[0], exps[1], exps[2]}};
   return 0;
 }
+int snet_fused_plan_tile_mode(const snet_fused_plan *p) { return p ? p->k->tile_mode : 0; }
 void snet_fused_plan_destroy(snet_fused_plan *p) {
   if (!p) return;
   if (p->slabs) (void)hipFree(p->slabs);

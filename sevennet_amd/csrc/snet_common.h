@@ -97,6 +97,7 @@ struct FusedKernels {
   // forward: out[n_dst, dout]
   void (*fwd)(int nt, const float *x, const float *sh, const float *h2, const int32_t *w_row, const int32_t *row_ptr,
               const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, int w2_exp, hipStream_t st);
+  int tile_mode;  // work list of bwd: 0 = per-node tiles (snet_edge_tiles), 1 = packed tiles (snet_edge_tiles_packed)
 };
 void register_fused(const FusedKernels *k);
 const FusedKernels *find_fused(const char *tag);

@@ -277,6 +277,77 @@ extern "C" int snet_edge_tiles(const int32_t *row_ptr, int64_t n_dst, int32_t *t
                          static_cast<hipStream_t>(stream));
 }
 
+// ---- packed tiles: windows of <= 16 consecutive CSR edges that span at most two destination nodes -----------------
+// One thread walks a group of TILE_GROUP consecutive nodes greedily (a tile ends after 16 edges, at the end of the second
+// node it touches, or at the end of the group), so the groups are independent: count, scan, fill.
+namespace {
+constexpr int TILE_GROUP = 8;
+template <bool FILL>
+__global__ void packed_tiles_kernel(const int32_t *__restrict__ row_ptr, int64_t node_begin, int64_t node_end,
+                                    int32_t *__restrict__ cnt, const int32_t *__restrict__ base,
+                                    int32_t *__restrict__ tile_e0, int32_t *__restrict__ tile_nodes) {
+  const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n_groups = (node_end - node_begin + TILE_GROUP - 1) / TILE_GROUP;
+  if (gi > n_groups) return;
+  if (gi == n_groups) {   // sentinel: the count array's last entry / the end of the last tile
+    if (FILL) tile_e0[base[n_groups]] = row_ptr[node_end];
+    else cnt[n_groups] = 0;
+    return;
+  }
+  const int a = (int)(node_begin + gi * TILE_GROUP), b = (int)min((int64_t)a + TILE_GROUP, node_end);
+  const int32_t *rp = row_ptr + a;   // (a few cached words per thread)
+  const int n_in = b - a, e_end = rp[n_in];
+  int e = rp[0], n0 = 0, k = FILL ? base[gi] : 0;
+  const int k0 = k;
+  while (e < e_end) {
+    while (rp[n0 + 1] <= e) ++n0;                       // node of edge e
+    int n1 = n0 + 1;
+    while (n1 < n_in && rp[n1 + 1] == rp[n1]) ++n1;     // next node of the group that has edges
+    const int lim = n1 < n_in ? rp[n1 + 1] : rp[n0 + 1];
+    const int end = min(e + 16, lim);
+    if (FILL) {
+      tile_e0[k] = e;
+      tile_nodes[2 * k] = a + n0;
+      tile_nodes[2 * k + 1] = end > rp[n0 + 1] ? a + n1 : a + n0;
+    }
+    ++k;
+    e = end;
+  }
+  if (!FILL) cnt[gi] = k - k0;
+}
+}  // namespace
+
+extern "C" int snet_edge_tiles_packed(const int32_t *row_ptr, int64_t node_begin, int64_t node_end, int32_t *tile_e0,
+                                      int32_t *tile_nodes, int64_t tile_capacity, int64_t *n_tiles, void *stream) {
+  SNET_REQUIRE(row_ptr && tile_e0 && tile_nodes && n_tiles, "snet_edge_tiles_packed: null argument");
+  SNET_REQUIRE(node_begin >= 0 && node_end >= node_begin && node_end < (1LL << 31) - 1, "snet_edge_tiles_packed: bad node range");
+  *n_tiles = 0;
+  if (node_end == node_begin) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static thread_local TileScratch S;  // grow-only, one per host thread: cnt = [counts | offsets]
+  const int64_t ng = (node_end - node_begin + TILE_GROUP - 1) / TILE_GROUP;
+  SNET_REQUIRE(S.cnt.ensure(2 * (ng + 1)), "snet_edge_tiles_packed: allocation failed");
+  int32_t *cnt = S.cnt.p, *base = S.cnt.p + ng + 1;
+  const unsigned grid = (unsigned)((ng + 1 + 127) / 128);
+  packed_tiles_kernel<false><<<grid, 128, 0, st>>>(row_ptr, node_begin, node_end, cnt, nullptr, nullptr, nullptr);
+  SNET_CHECK_LAUNCH("packed_tiles_kernel");
+  size_t bytes = 0;
+  SNET_REQUIRE(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cnt, base, (int)(ng + 1), st) == hipSuccess,
+               "snet_edge_tiles_packed: scan sizing failed");
+  SNET_REQUIRE(S.tmp.ensure(bytes), "snet_edge_tiles_packed: allocation failed");
+  bytes = S.tmp.cap;
+  SNET_REQUIRE(hipcub::DeviceScan::ExclusiveSum(S.tmp.p, bytes, cnt, base, (int)(ng + 1), st) == hipSuccess,
+               "snet_edge_tiles_packed: scan failed");
+  int32_t nt = 0;
+  SNET_REQUIRE(hipMemcpyAsync(&nt, base + ng, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess,
+               "snet_edge_tiles_packed: readback failed");
+  *n_tiles = nt;
+  SNET_REQUIRE(nt <= tile_capacity, "snet_edge_tiles_packed: capacity too small ((node_end - node_begin) + n_edges / 16 tiles always suffice)");
+  packed_tiles_kernel<true><<<grid, 128, 0, st>>>(row_ptr, node_begin, node_end, nullptr, base, tile_e0, tile_nodes);
+  SNET_CHECK_LAUNCH("packed_tiles_kernel");
+  return 0;
+}
+
 struct snet_md_host {
   snet_model *model = nullptr;
   DevBuf<double> x;

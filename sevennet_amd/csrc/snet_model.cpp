@@ -133,6 +133,7 @@ struct Layer {
   snet_conv_plan *tconv = nullptr;
   snet_mlp_plan *tmlp = nullptr;
   snet_fused_plan *tfused = nullptr;
+  int tile_mode = 0;   // work list of the fused reverse kernel: 0 = per-row tiles, 1 = packed (snet_fused_plan_tile_mode)
   std::vector<int32_t> t_dead;       // (offset, length) column ranges of g_h it leaves unwritten
   Linear sc, si1, si2;
   std::vector<snet_gate_seg> segs;
@@ -253,6 +254,10 @@ struct snet_model {
   int32_t *c_tile_ptr_b = nullptr;   // tile pointers re-based on the boundary rows' sub-list
   size_t c_tile_ptr_b_cap = 0;
   int64_t c_tile_k = 0;              // first tile of the first boundary row
+  // packed tiles (snet_edge_tiles_packed): one list, the interior rows' tiles [0, k) in front of the boundary rows'
+  int32_t *c_ptile_e0 = nullptr, *c_ptile_nodes = nullptr;
+  size_t c_ptile_cap = 0;
+  int64_t c_pn_tiles = 0, c_ptile_k = 0;
   std::vector<int32_t> types_prev;  // species of the local atoms the cached row lists were built from
   int64_t eval_syncs = 0;           // stream synchronisations issued inside snet_model_eval so far (tests / tools)
   // second stream for the radial MLPs (graphs of at most OVERLAP_MAX_EDGES edges, see engine.py)
@@ -347,6 +352,7 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
         snet_fused_plan_create(L.conv, L.mlp_plan, SNET_FUSED_TERMS_DEFAULT, &L.fused))
       good = false;
     if (good && L.fused) {
+      L.tile_mode = snet_fused_plan_tile_mode(L.fused);
       std::vector<int32_t> cp((size_t)L.dx / 16);
       good = snet_fused_plan_gxe_chunks(L.fused, cp.data(), (int32_t)cp.size()) == 0 &&
              hipMalloc((void **)&L.gxe_chunks, cp.size() * 4) == hipSuccess &&
@@ -466,7 +472,8 @@ extern "C" void snet_model_destroy(snet_model *m) {
   if (m->halo_stream) (void)hipStreamDestroy(m->halo_stream);
   for (hipEvent_t e : {m->ev_h0, m->ev_h1}) if (e) (void)hipEventDestroy(e);
   for (void *d : {(void *)m->embed, (void *)m->scale, (void *)m->shift, (void *)m->h0_table, (void *)m->sc0_table, (void *)m->ro_v, (void *)m->c_tile_ptr, (void *)m->c_tile_node,
-                  (void *)m->c_center_t, (void *)m->c_w_row_t, (void *)m->c_tile_ptr_b, (void *)m->arena.base, (void *)m->species_rows})
+                  (void *)m->c_center_t, (void *)m->c_w_row_t, (void *)m->c_tile_ptr_b, (void *)m->c_ptile_e0, (void *)m->c_ptile_nodes, (void *)m->arena.base,
+                  (void *)m->species_rows})
     if (d) (void)hipFree(d);
   delete m;
 }
@@ -553,9 +560,11 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
                "snet_model_eval: w_row needs pair_edge and 0 < n_pairs <= n_edges");
   const int64_t WR = pairs ? n_pairs : E;  // rows of each layer's radial-weight matrix
   bool any_fused = false, any_transposed = false;
+  bool need_tiles[2] = {false, false};   // per work-list format of the fused reverse kernels
   for (auto &L : m->layers) {
     any_fused |= L.fused != nullptr;
     any_transposed |= L.tfused != nullptr;
+    if (L.fused) need_tiles[L.tile_mode != 0] = true;
   }
   // the second stream only carries the separate radial-MLP kernels (same policy as engine.py)
   bool ov = m->overlap && E > 0 && E <= OVERLAP_MAX_EDGES && !any_fused;
@@ -624,7 +633,8 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   size_t wn_max = 0;
   for (auto &L : m->layers) wn_max = wn_max > (size_t)L.wn ? wn_max : (size_t)L.wn;
   if (ov) { add((size_t)E * wn_max); add((size_t)E * wn_max); }  // g_w double buffer (its reader runs on the side stream)
-  if (any_fused) { add((size_t)N + 64); add((size_t)N + (size_t)E / 16 + 64); }  // tile_ptr, tile_node
+  if (need_tiles[0]) { add((size_t)N + 64); add((size_t)N + (size_t)E / 16 + 64); }  // tile_ptr, tile_node
+  if (need_tiles[1]) { add((size_t)N + (size_t)E / 16 + 64); add(2 * ((size_t)N + (size_t)E / 16 + 64)); }  // packed: tile_e0, tile_nodes
   if (any_transposed) { add((size_t)E + 64); add((size_t)E + 64); add((size_t)E * nsh + 64); }  // center_t, w_row_t, sh_t
   add((size_t)NT * dmax * 2 + 256); add((size_t)N * (m->ro1.dim_out + 8) * 2); add(trans + 64 * 1024);
   need += 1 << 20;
@@ -661,9 +671,18 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   // topology-only work: rebuilt unless the cache holds it for exactly these index arrays
   const snet_model::TopoKey key{NT, N, E, row_ptr, src, eperm, pairs ? w_row : nullptr};
   const bool topo_hit = m->topo_cache && m->topo_valid && memcmp(&key, &m->topo_key, sizeof key) == 0;
+  // interior / boundary split: the library's own exchange (stream-safe) on a second stream, rows [0, n_int) have no ghost source
+  const bool lib_halo = has_halo && m->halo_fwd == &snet_halo_forward && m->halo_rev == &snet_halo_reverse;
+  const int64_t n_int = m->n_interior;
+  bool hsplit = lib_halo && n_int > 0 && n_int < N && E > 0 && any_fused && getenv("SNET_NO_HALO_SPLIT") == nullptr;
+  if (hsplit && m->halo_stream == nullptr) {
+    hsplit = hipStreamCreateWithFlags(&m->halo_stream, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&m->ev_h0, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&m->ev_h1, hipEventDisableTiming) == hipSuccess;
+  }
   int32_t *tile_ptr = nullptr, *tile_node = nullptr;
   int64_t n_tiles = 0;
-  if (any_fused && E > 0) {  // 16-edge tiles of the CSR segments: work list of the fused reverse kernels
+  if (need_tiles[0] && E > 0) {  // 16-edge tiles of the CSR segments: work list of the fused reverse kernels
     if (m->topo_cache) {
       if (m->c_node_cap < (size_t)N + 64 || m->c_tile_cap < (size_t)N + (size_t)E / 16 + 64) {
         if (m->c_tile_ptr) (void)hipFree(m->c_tile_ptr);
@@ -688,6 +707,45 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
       m->c_n_tiles = n_tiles;
     }
   }
+  // packed tiles: built per row range when the step is split (no tile straddles the cut; the interior list's end sentinel is the
+  // first boundary tile's first edge, so the two lists are one)
+  int32_t *ptile_e0 = nullptr, *ptile_nodes = nullptr;
+  int64_t pn_tiles = 0, ptile_k = 0;
+  if (need_tiles[1] && E > 0) {
+    const size_t cap = (size_t)N + (size_t)E / 16 + 2;
+    if (m->topo_cache) {
+      if (m->c_ptile_cap < cap) {
+        if (m->c_ptile_e0) (void)hipFree(m->c_ptile_e0);
+        if (m->c_ptile_nodes) (void)hipFree(m->c_ptile_nodes);
+        m->c_ptile_e0 = m->c_ptile_nodes = nullptr;
+        m->c_ptile_cap = cap + cap / 8 + 64;
+        SNET_REQUIRE(hipMalloc((void **)&m->c_ptile_e0, (m->c_ptile_cap + 1) * 4) == hipSuccess &&
+                         hipMalloc((void **)&m->c_ptile_nodes, m->c_ptile_cap * 8) == hipSuccess, "snet_model_eval: alloc");
+      }
+      ptile_e0 = m->c_ptile_e0;
+      ptile_nodes = m->c_ptile_nodes;
+    } else {
+      ptile_e0 = reinterpret_cast<int32_t *>(A.f((size_t)N + (size_t)E / 16 + 64));
+      ptile_nodes = reinterpret_cast<int32_t *>(A.f(2 * ((size_t)N + (size_t)E / 16 + 64)));
+    }
+    if (topo_hit) {
+      pn_tiles = m->c_pn_tiles;
+      ptile_k = m->c_ptile_k;
+    } else {
+      const int64_t cut = n_int > 0 && n_int < N ? n_int : 0;   // (whether or not this evaluation is split: one tiling per graph, like engine.py)
+      int64_t nb = 0;
+      if (cut > 0) {
+        if ((rc = snet_edge_tiles_packed(row_ptr, 0, cut, ptile_e0, ptile_nodes, (int64_t)cap, &ptile_k, st))) return rc;
+        ++m->eval_syncs;   // (the builder reads the tile count back)
+      }
+      if ((rc = snet_edge_tiles_packed(row_ptr, cut, N, ptile_e0 + ptile_k, ptile_nodes + 2 * ptile_k, (int64_t)cap - ptile_k, &nb, st)))
+        return rc;
+      ++m->eval_syncs;
+      pn_tiles = ptile_k + nb;
+      m->c_pn_tiles = pn_tiles;
+      m->c_ptile_k = ptile_k;
+    }
+  }
   int32_t *center_t = nullptr, *w_row_t = nullptr;  // edges grouped by source (transposed scalar convolution)
   float *sh_t = nullptr;
   if (any_transposed && E > 0) {
@@ -710,18 +768,9 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     if (!topo_hit && (rc = snet_edges_by_source(row_ptr, N, eperm, pairs ? w_row : nullptr, E, center_t, w_row_t, st))) return rc;
     if ((rc = snet_gather_rows(sh, eperm, sh_t, E, nsh, st))) return rc;   // (the harmonics change with the positions: every step)
   }
-  // interior / boundary split: the library's own exchange (stream-safe) on a second stream, rows [0, n_int) have no ghost source
-  const bool lib_halo = has_halo && m->halo_fwd == &snet_halo_forward && m->halo_rev == &snet_halo_reverse;
-  const int64_t n_int = m->n_interior;
-  bool hsplit = lib_halo && n_int > 0 && n_int < N && E > 0 && any_fused && getenv("SNET_NO_HALO_SPLIT") == nullptr;
-  if (hsplit && m->halo_stream == nullptr) {
-    hsplit = hipStreamCreateWithFlags(&m->halo_stream, hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&m->ev_h0, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&m->ev_h1, hipEventDisableTiming) == hipSuccess;
-  }
   int32_t *tile_ptr_b = nullptr;   // boundary rows' tiles: tile_node + k, tile pointers re-based by -k
   int64_t tile_k = 0;
-  if (hsplit) {
+  if (hsplit && need_tiles[0]) {
     if (m->c_tile_ptr_b_cap < (size_t)N + 64) {
       if (m->c_tile_ptr_b) (void)hipFree(m->c_tile_ptr_b);
       m->c_tile_ptr_b = nullptr;
@@ -856,7 +905,9 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
                                    L.conv_scale, g_m, g_xe, g_h2, tail ? emb : nullptr, tail ? g_emb : nullptr, g_vec, x_max, g_max, st);
       };
       const bool rsplit = hsplit && t > 0;
-      if (!rsplit && (rc = bwd_tiles(tile_ptr, tile_node, n_tiles))) return rc;
+      const bool packed = L.tile_mode != 0;
+      auto bwd_all = [&]() -> int { return packed ? bwd_tiles(ptile_e0, ptile_nodes, pn_tiles) : bwd_tiles(tile_ptr, tile_node, n_tiles); };
+      if (!rsplit && (rc = bwd_all())) return rc;
       if (t > 0) {
         float *g_h = A.f((size_t)NT * L.dx);
         // source rows [a, b) of g_h: the transposed scalar convolution over the edges grouped by source, or the segment sum
@@ -874,13 +925,14 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
         if (rsplit) {
           // boundary tiles hold every edge with a ghost source: they go first, the ghost rows of g_h start travelling at once and
           // the interior tiles / the local rows run under the exchange (the transposed convolution needs no tiles at all)
-          if (!transposed && (rc = bwd_tiles(tile_ptr_b, tile_node + tile_k, n_tiles - tile_k))) return rc;
+          if (!transposed && (rc = packed ? bwd_tiles(ptile_e0 + ptile_k, ptile_nodes + 2 * ptile_k, pn_tiles - ptile_k)
+                                          : bwd_tiles(tile_ptr_b, tile_node + tile_k, n_tiles - tile_k))) return rc;
           if ((rc = gh_rows(N, NT))) return rc;
           SNET_REQUIRE(hipEventRecord(m->ev_h0, st) == hipSuccess && hipStreamWaitEvent(m->halo_stream, m->ev_h0, 0) == hipSuccess,
                        "snet_model_eval: stream ordering failed");
           if ((rc = snet_halo_reverse_exchange(m->halo_user, g_h, NT, N, L.dx, m->halo_stream))) return rc;
           SNET_REQUIRE(hipEventRecord(m->ev_h1, m->halo_stream) == hipSuccess, "snet_model_eval: stream ordering failed");
-          if ((rc = transposed ? bwd_tiles(tile_ptr, tile_node, n_tiles) : bwd_tiles(tile_ptr, tile_node, tile_k))) return rc;
+          if ((rc = transposed ? bwd_all() : packed ? bwd_tiles(ptile_e0, ptile_nodes, ptile_k) : bwd_tiles(tile_ptr, tile_node, tile_k))) return rc;
           if ((rc = gh_rows(0, N))) return rc;
           if (!tail && (rc = snet_radial_mlp_hidden_bwd(L.mlp_plan, emb, g_h2, E, g_emb, st))) return rc;
           if (L.sc.present())   // sc^T g_y does not read the ghost gradients: it runs under the exchange too

@@ -70,6 +70,7 @@ class Graph:
     # have no ghost source.  0 = unknown / no split.
     n_interior: int = 0
     _tile_split: Optional[tuple] = None
+    _tiles_packed: Optional[tuple] = None
 
     def by_source(self, lib, stream):
         """(center[eperm], w_row[eperm]) as int32 arrays, built on first use (w_row None: the edge's own row, eperm)"""
@@ -80,8 +81,33 @@ class Graph:
                        'snet_edges_by_source')
         return self.src_T, self.w_row_T
 
-    def tiles(self):
-        """(tile_ptr, tile_node, n_tiles), built on first use"""
+    def _packed_tiles(self):
+        """packed tiles (snet_edge_tiles_packed): ONE list, built per row range when the graph has an interior / boundary cut
+        (no tile straddles it, and the tile of the cut's sentinel is the first boundary tile) -> (tile_e0, tile_nodes, n, k)"""
+        lib = _lib.load()
+        dev = self.edge_vec.device
+        cut = self.n_interior if 0 < self.n_interior < self.n_local else 0
+        with torch.cuda.device(dev):
+            cap = self.n_local + self.n_edges // 16 + 2
+            tp = torch.empty(cap + 1, dtype=torch.int32, device=dev)
+            tn = torch.empty(2 * cap, dtype=torch.int32, device=dev)
+            k = 0
+            n = C.c_int64()
+            if cut:
+                _lib.check(lib.snet_edge_tiles_packed(_ptr(self.row_ptr), 0, cut, _ptr(tp), _ptr(tn), cap, C.byref(n), _stream()),
+                           'snet_edge_tiles_packed')
+                k = int(n.value)
+            _lib.check(lib.snet_edge_tiles_packed(_ptr(self.row_ptr), cut, self.n_local, C.c_void_p(tp.data_ptr() + 4 * k),
+                                                  C.c_void_p(tn.data_ptr() + 8 * k), cap - k, C.byref(n), _stream()),
+                       'snet_edge_tiles_packed')
+        return tp, tn, k + int(n.value), k
+
+    def tiles(self, mode: int = 0):
+        """(tile_ptr, tile_node, n_tiles) of one reverse kernel's work-list format (snet_fused_plan_tile_mode), built on first use"""
+        if mode == 1:
+            if self._tiles_packed is None:
+                self._tiles_packed = self._packed_tiles()
+            return self._tiles_packed[:3]
         if self.tile_ptr is None:
             lib = _lib.load()
             dev = self.edge_vec.device
@@ -95,9 +121,13 @@ class Graph:
             self.tile_ptr, self.tile_node, self.n_tiles = tp, tn, int(n.value)
         return self.tile_ptr, self.tile_node, self.n_tiles
 
-    def tiles_split(self):
+    def tiles_split(self, mode: int = 0):
         """the tile list cut at n_interior: ((tile_ptr, tile_node, n) of the interior rows, (tile_ptr', tile_node', n') of the
         boundary rows) -- views / one shifted copy of the full list, built on first use"""
+        if mode == 1:
+            tp, tn, nt = self.tiles(1)
+            k = self._tiles_packed[3]
+            return (tp, tn, k), (tp[k:], tn[2 * k:], nt - k)
         if self._tile_split is None:
             tp, tn, nt = self.tiles()
             k = int(tp[self.n_interior].item())       # first tile of the first boundary row (one readback per graph)
@@ -398,6 +428,7 @@ class HipForceEngine:
                     L.gxe_chunks = torch.tensor(list(cp), dtype=torch.int32, device=self.dev)
                 L.fused_fwd = L.fplan is not None and fused in ('auto', True, 'fwd')
                 L.fused_bwd = L.fplan is not None and fused in ('auto', True, 'bwd')
+                L.tile_mode = int(self.lib.snet_fused_plan_tile_mode(L.fplan)) if L.fplan is not None else 0
                 # scalar-output layer (the last one): its source-row gradient as a forward convolution of the transposed
                 # product over the edges grouped by source -- gathers dout floats per edge instead of writing and
                 # re-reading a dx-float g_xe row (model_spec.transposed_scalar_conv)
@@ -602,7 +633,10 @@ class HipForceEngine:
             side = None
             w_ready = {}
             any_fused = any(L.fused_fwd or L.fused_bwd for L in self.layers)
-            tile_ptr, tile_node, n_tiles = g.tiles() if any(L.fused_bwd for L in self.layers) and E > 0 else (None, None, 0)
+            if E > 0:   # work lists of the fused reverse kernels (the topology's only device sync: built once per Graph)
+                for L in self.layers:
+                    if L.fused_bwd:
+                        g.tiles(L.tile_mode)
             if self.overlap and E <= self.OVERLAP_MAX_EDGES and not any_fused and all(L.fused_mlp for L in self.layers):
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=self.dev)
@@ -838,7 +872,7 @@ class HipForceEngine:
                                                                _ptr(g_vec), _ptr(x_max), _ptr(g_max), st),
                                        'snet_conv_bwd_fused')
                     if rsplit:
-                        (tpi, tni, nti), (tpb, tnb, ntb) = g.tiles_split()
+                        (tpi, tni, nti), (tpb, tnb, ntb) = g.tiles_split(L.tile_mode)
                         if use_t:                  # g_h does not depend on the reverse kernel: ghost rows straight away
                             gh_rows(N, NT)
                         else:
@@ -847,12 +881,12 @@ class HipForceEngine:
                         with _Span(self, 'halo_rev'):
                             pending = halo.reverse_start(g_h, N)
                         if use_t:
-                            bwd_tiles(tile_ptr, tile_node, n_tiles)
+                            bwd_tiles(*g.tiles(L.tile_mode))
                         else:
                             bwd_tiles(tpi, tni, nti)
                         gh_rows(0, N)
                     elif E > 0:
-                        bwd_tiles(tile_ptr, tile_node, n_tiles)
+                        bwd_tiles(*g.tiles(L.tile_mode))
                 else:
                     if side is not None:  # double-buffered: the MLP reverse of layer t+2 may still be reading this one
                         if gw_done[t & 1] is not None:

@@ -345,6 +345,56 @@ def _fused_case(model, layer, seed, pairs):
                 W2=(torch.randn(64, wn, generator=g) / 8).contiguous())
 
 
+
+def _packed_tiles_expected(row_ptr, lo, hi, group=8):
+    """restatement of snet_edge_tiles_packed: greedy windows of <= 16 consecutive edges over <= 2 rows, per group of rows"""
+    rp = [int(v) for v in row_ptr]
+    e0, nodes = [], []
+    for a in range(lo, hi, group):
+        b = min(a + group, hi)
+        e, n0 = rp[a], a
+        while e < rp[b]:
+            while rp[n0 + 1] <= e:
+                n0 += 1
+            n1 = n0 + 1
+            while n1 < b and rp[n1 + 1] == rp[n1]:
+                n1 += 1
+            lim = rp[n1 + 1] if n1 < b else rp[n0 + 1]
+            end = min(e + 16, lim)
+            e0.append(e)
+            nodes += [n0, n1 if end > rp[n0 + 1] else n0]
+            e = end
+    return e0 + [rp[hi]], nodes
+
+
+def _work_list(L, lib, fplan, rp, row_ptr_cpu, N, E, dev):
+    """the reverse kernel's tile list in the format its plan asks for, checked against the format's definition"""
+    n_tiles = C.c_int64()
+    deg = (row_ptr_cpu[1:] - row_ptr_cpu[:-1]).long()
+    if lib.snet_fused_plan_tile_mode(fplan) == 1:
+        cap = N + E // 16 + 1
+        tile_ptr = torch.full((cap + 1,), -1, dtype=torch.int32, device=dev)
+        tile_node = torch.full((2 * cap,), -1, dtype=torch.int32, device=dev)
+        L.check(lib.snet_edge_tiles_packed(_p(rp), 0, N, _p(tile_ptr), _p(tile_node), cap, C.byref(n_tiles), None))
+        e0, nodes = _packed_tiles_expected(row_ptr_cpu, 0, N)
+        nt = n_tiles.value
+        assert nt == len(e0) - 1 <= int(((deg + 15) // 16).sum())
+        assert tile_ptr.cpu()[:nt + 1].tolist() == e0 and tile_node.cpu()[:2 * nt].tolist() == nodes
+        center = torch.repeat_interleave(torch.arange(N), deg)
+        for t in range(nt):   # every edge once, <= 16 per tile, all of them in row A or row B
+            assert 0 < e0[t + 1] - e0[t] <= 16
+            assert set(center[e0[t]:e0[t + 1]].tolist()) == set(nodes[2 * t:2 * t + 2])
+        return tile_ptr, tile_node, n_tiles
+    tile_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    cap = N + E // 16 + 1
+    tile_node = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+    L.check(lib.snet_edge_tiles(_p(rp), N, _p(tile_ptr), _p(tile_node), cap, C.byref(n_tiles), None))
+    assert n_tiles.value == int(((deg + 15) // 16).sum())
+    assert torch.equal(tile_ptr.cpu()[1:].long(), torch.cumsum((deg + 15) // 16, 0))
+    assert torch.equal(tile_node.cpu()[:n_tiles.value].long(), torch.repeat_interleave(torch.arange(N), (deg + 15) // 16))
+    return tile_ptr, tile_node, n_tiles
+
+
 @pytest.mark.parametrize('model,layer,pairs,terms,gscale', [
     ('sevennet_0', 0, False, 3, 1.0), ('sevennet_0', 1, True, 3, 1.0), ('sevennet_0', 4, True, 3, 1.0),
     ('sevennet_0', 1, False, 2, 1.0), ('sevennet_0', 1, True, 1, 1.0), ('sevennet_l3i5', 1, True, 3, 1.0),
@@ -393,15 +443,7 @@ def test_conv_fused_matches_separate_kernels(model, layer, pairs, terms, gscale)
     L.check(lib.snet_radial_mlp_hidden_fwd(mlp, _p(emb), R, _p(h2), None))
     out = torch.full((N, dout), float('nan'), device=dev)
     L.check(lib.snet_conv_fwd_fused(fplan, _p(x), _p(sh), _p(h2), _p(wr), _p(rp), _p(sr), N, scale, _p(out), None))
-    tile_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
-    cap = N + E // 16 + 1
-    tile_node = torch.full((cap,), -1, dtype=torch.int32, device=dev)
-    n_tiles = C.c_int64()
-    L.check(lib.snet_edge_tiles(_p(rp), N, _p(tile_ptr), _p(tile_node), cap, C.byref(n_tiles), None))
-    deg = (c['row_ptr'][1:] - c['row_ptr'][:-1]).long()
-    assert n_tiles.value == int(((deg + 15) // 16).sum())
-    assert torch.equal(tile_ptr.cpu()[1:].long(), torch.cumsum((deg + 15) // 16, 0))
-    assert torch.equal(tile_node.cpu()[:n_tiles.value].long(), torch.repeat_interleave(torch.arange(N), (deg + 15) // 16))
+    tile_ptr, tile_node, n_tiles = _work_list(L, lib, fplan, rp, c['row_ptr'], N, E, dev)
     g_xe = torch.full((E, dx), float('nan'), device=dev)
     g_h2 = torch.full((E, 64), float('nan'), device=dev)
     # row maxima the fp16-operand mode (terms = 4) bounds each edge's g_w with; other modes ignore them

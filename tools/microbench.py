@@ -89,7 +89,7 @@ def main():
     st = _stream()
     h2 = rnd(E, 64)
     g_h2 = rnd(E, 64)
-    tile_ptr, tile_node, n_tiles = g.tiles()
+    tile_ptr, tile_node, n_tiles = g.tiles(int(lib.snet_fused_plan_tile_mode(L.fplan)) if L.fplan is not None else 0)
     x_max, g_max = h.abs().amax(1).contiguous(), g_m.abs().amax(1).contiguous()   # bounds of the fp16-operand mode
     gy_r, y_r, sc_r = rnd(N, ls.si2.dim_out), rnd(N, ls.gate.irreps_in.dim), rnd(N, ls.gate.irreps_in.dim)
     xo_r = rnd(N, ls.gate.irreps_out.dim)
