@@ -342,11 +342,14 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     # node (A) into the next one that has edges (B); snet_edge_tiles_packed writes tile_ptr[t] = first edge, tile_node[2t .. 2t+1] = A, B.
     # The wave keeps BOTH nodes' g_out entries in its LDS buffer and every edge lane reads its own node's set.
     # Chosen per shape: the second node's prefetched entries cost 4 NK more registers, which the lmax-3 shapes (at 256 already) do
-    # not have (round 4: 20 .. 2400 spilled registers with it; estimate 227 .. 243 against 195 for the largest shape that fits); SNET_CODEGEN_OPTS=xtile=0 / 1 forces it.
+    # not have (round 4: 20 .. 2400 spilled registers with it; estimate 227 .. 243 against 195 for the largest shape that fits).  Nor
+    # where the g_out entries are most of a block's vector-memory instructions or the shape would leave three waves per SIMD for two
+    # (same box, in the step: first layer ecc5d202727d 1.69 -> 2.03 ms, last layer 005c575f8ec2 1.50 -> 1.63 ms with packed tiles; the
+    # middle layers 5.64 -> 5.24 ms).  SNET_CODEGEN_OPTS=xtile=0 / 1 forces it.
     _bs0, _ = schedule_bwd(spec)
     _ngp = max((sum(2 * p_.l3 + 1 for _, p_ in b_['cat'].paths) * b_['U'] + 15) // 16 * 16 for b_ in _bs0)
     _live2 = 12 * max(2 * c_.l1 + 1 for c_ in cats) + 32 + NSH + 8 * (_ngp // 16) + 16 + 4 * max(2 * p_.l3 + 1 for p_ in spec.paths) + 35
-    XT = bool(int(OPTS['xtile'])) if 'xtile' in OPTS else _live2 <= 200
+    XT = bool(int(OPTS['xtile'])) if 'xtile' in OPTS else (_live2 <= 200 and _live2 - 4 * (_ngp // 16) > 168 and len(cats) > 1)
     GS = 2 if XT else 1
     while BG > 1 and 2 * min(BG, max(len(b_['steps']) for b_ in _bs0)) * 8 * 2 * 1024 + 8 * (2 * _ngp * 64 + NSH * 64) > 150 * 1024:
         BG -= 1   # the slabs of one 8-wave workgroup per CU must fit the LDS beside the waves' private buffers
