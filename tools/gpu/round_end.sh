@@ -4,9 +4,11 @@
 # tools/collect_profiles.sh <tag>, bench lines of the lmax-3 shapes, the world-1 RCCL soak.
 set -o pipefail
 TAG=${1:-r04}
+if [ -z "$SKIP_TESTS" ]; then   # (SKIP_TESTS=1: the suite already ran on this tree in an earlier call)
 bash tools/gpu/tests_only.sh
 echo "tests_only rc=$?" | tee -a gpurun_out/tests.log
 cp gpurun_out/tests.log gpurun_out/${TAG}_gpu_tests.txt
+fi
 timeout 1500 bash tools/collect_profiles.sh $TAG > gpurun_out/${TAG}_collect.log 2>&1; echo "collect_profiles rc=$?"
 tail -2 gpurun_out/${TAG}_collect.log | cut -c1-300
 for m in sevennet_l3i5 sevennet_mf_ompa; do
