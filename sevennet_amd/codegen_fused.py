@@ -421,7 +421,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     if XT:
         # (one buffer per node, not two per block parity: the entries of the next block are parked after this block's last read, and a
         # wave's LDS operations execute in order)
-        A('  __shared__ __attribute__((aligned(16))) float s_g[NWV][2][NGP * 16];')
+        A(f'  __shared__ __attribute__((aligned(16))) float s_g[NWV][2][NGP * 16 + {int(OPTS.get("gpad", 16))}];   // (+ 16: the two sets of a (row, group) read on disjoint banks)')
         A('  f32x4 gpre[NK], gpre_b[NK];')
         A('  const float *gnode = g_out + (size_t)node * DOUT + 4 * (lane & 3);')
         A('  const float *gnode_b = g_out + (size_t)node_b * DOUT + 4 * (lane & 3);')
@@ -1243,7 +1243,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
             A(f'  if (nt == 4 && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
     def bwd_lds(nt, nwv):
-        return 2 * GLN * 8 * nt * 1024 + nwv * (2 * NGP * 64 + NSH * 64)
+        return 2 * GLN * 8 * nt * 1024 + nwv * (2 * NGP * 64 + (128 if XT else 0) + NSH * 64)
 
     def bwd_cfg(nt):
         # measured on MI355X (SevenNet-0 middle layer): three 4-wave workgroups per CU (LDS <= 53 KB each, <= 168
