@@ -367,6 +367,56 @@ def _packed_tiles_expected(row_ptr, lo, hi, group=8):
     return e0 + [rp[hi]], nodes
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('pattern', ['crystal28', 'zeros_and_ones', 'long_rows', 'random', 'single_row', 'all_empty'])
+def test_packed_tiles_builder_matches_its_definition(pattern):
+    """snet_edge_tiles_packed against the greedy restatement above: every edge in exactly one tile, <= 16 edges and <= 2 rows per tile,
+    rows with no edges skipped, sub-ranges [lo, hi) carry global row ids and chain into one list (tile_e0[k] is both the end of the
+    first list and the start of the second: how the interior / boundary split of a brick uses it)"""
+    L, lib = _lib()
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(5)
+    N = 203
+    deg = {'crystal28': torch.full((N,), 28), 'zeros_and_ones': torch.randint(0, 2, (N,), generator=g),
+           'long_rows': torch.randint(0, 3, (N,), generator=g) * 37 + torch.randint(0, 2, (N,), generator=g),
+           'random': torch.randint(0, 41, (N,), generator=g), 'single_row': torch.tensor([45]),
+           'all_empty': torch.zeros(N, dtype=torch.long)}[pattern].long()
+    N = len(deg)
+    row_ptr = torch.zeros(N + 1, dtype=torch.int32)
+    row_ptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
+    E = int(row_ptr[-1])
+    rp = row_ptr.to(dev)
+    center = torch.repeat_interleave(torch.arange(N), deg)
+
+    def build(lo, hi, cap=None):
+        cap = cap if cap is not None else (hi - lo) + E // 16 + 1
+        te = torch.full((cap + 1,), -7, dtype=torch.int32, device=dev)
+        tn = torch.full((2 * max(cap, 1),), -7, dtype=torch.int32, device=dev)
+        n = C.c_int64(-1)
+        L.check(lib.snet_edge_tiles_packed(_p(rp), lo, hi, _p(te), _p(tn), cap, C.byref(n), None))
+        torch.cuda.synchronize()
+        return te.cpu().tolist(), tn.cpu().tolist(), n.value
+
+    for lo, hi in ((0, N), (0, N // 3), (N // 3, N), (7 % N, max(7 % N, N - 5))):
+        te, tn, nt = build(lo, hi)
+        e0, nodes = _packed_tiles_expected(row_ptr, lo, hi)
+        assert nt == len(e0) - 1
+        if hi > lo:
+            assert te[:nt + 1] == e0 and tn[:2 * nt] == nodes
+        assert te[nt + 1:] == [-7] * (len(te) - nt - 1)          # nothing written past the sentinel
+        covered = []
+        for t in range(nt):
+            assert 0 < e0[t + 1] - e0[t] <= 16
+            rows = set(center[e0[t]:e0[t + 1]].tolist())
+            assert rows == set(nodes[2 * t:2 * t + 2]) and nodes[2 * t] <= nodes[2 * t + 1]
+            covered += list(range(e0[t], e0[t + 1]))
+        assert covered == list(range(int(row_ptr[lo]), int(row_ptr[hi])))
+        assert nt <= int(((deg[lo:hi] + 15) // 16).sum())           # never more tiles than the per-row list
+    if E > 0 and N > 3:   # capacity is checked, not overrun
+        with pytest.raises(RuntimeError, match='capacity'):
+            build(0, N, cap=max(1, len(_packed_tiles_expected(row_ptr, 0, N)[0]) - 2))
+
+
 def _work_list(L, lib, fplan, rp, row_ptr_cpu, N, E, dev):
     """the reverse kernel's tile list in the format its plan asks for, checked against the format's definition"""
     n_tiles = C.c_int64()
