@@ -1216,7 +1216,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         combos = [default]
         if exp:
             cand = ((4, 0, 2), (8, 0, 2), (8, 1, 2), (4, 0, 3), (12, 0, 3), (12, 1, 3)) if fwd else \
-                ((4, 0, 2), (8, 0, 2), (8, 1, 2), (4, 0, 3), (4, 1, 3), (12, 0, 3), (12, 1, 3), (8, 1, 4))
+                ((4, 0, 2), (8, 0, 2), (8, 1, 2), (4, 0, 3), (4, 1, 3), (12, 0, 3), (12, 1, 3), (8, 1, 4), (8, 0, 4), (8, 0, 3))
             combos += [v for v in cand if v != default]
         return combos
 

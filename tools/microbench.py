@@ -161,7 +161,7 @@ def main():
     for name, fn in ops.items():
         if a.only and a.only not in name:
             continue
-        if a.fv and 'fused[' in name:
+        if a.fv and 'fused' in name and '[' in name:
             for v in a.fv.split(';'):
                 todo.append((f'{name} fv={v}', fn, v))
         else:
