@@ -302,9 +302,21 @@ def main():
         use_native = a.halo == 'native' or (a.halo == 'auto' and backend == 'nccl')
         if use_native:
             from sevennet_amd.parallel import NativeHalo, RcclComm
-            rccl_comm = RcclComm(world, rank)
-            halo = NativeHalo(rccl_comm, bg.send_lists, bg.recv_counts, overlap=not a.no_halo_overlap)
-        else:
+            ok = 1
+            try:
+                rccl_comm = RcclComm(world, rank)
+                halo = NativeHalo(rccl_comm, bg.send_lists, bg.recv_counts, overlap=not a.no_halo_overlap)
+            except Exception as exc:   # the library's own communicator could not be made on this rank: say so, decide together
+                print(f'[bench rank {rank}] native RCCL halo unavailable ({exc}); asking for the torch.distributed exchange', file=sys.stderr)
+                ok = 0
+            if a.halo == 'auto' and world > 1:   # every rank must use the same transport
+                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    use_native, halo = False, None
+            elif not ok:
+                raise SystemExit('--halo native: the RCCL communicator of libsnet_hip.so could not be created')
+        if not use_native:
             halo = HaloExchange(bg.send_lists, bg.recv_counts, dev)
         ne = torch.tensor([graph.n_edges], device=dev, dtype=torch.int64)
         dist.all_reduce(ne)
