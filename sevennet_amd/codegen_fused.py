@@ -1199,7 +1199,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A(f'          float *o = onode + ooff{ci}_{gi}_{k} + 16 * ct;')
                 A(f'          f32x4 v = *reinterpret_cast<const f32x4 *>(&s_o[wave][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]);')
                 A('          if (pass) v += *reinterpret_cast<const f32x4 *>(o);')
-                A('          *reinterpret_cast<f32x4 *>(o) = v;')
+                A('          *reinterpret_cast<f32x4 *>(o) = v;')   # (streaming stores here: measured neutral, round 4)
                 A('        }')
             A('        if (n_next) stage_store(n_next, buf ^ 1);')
             A('        __syncthreads();')
