@@ -61,18 +61,13 @@ __global__ __launch_bounds__(NTH) void d3_cn_kernel(const double *__restrict__ x
   if (threadIdx.x == 0) cn[i] = acc;
 }
 
-// C6_ij(CN_i, CN_j) and dC6_ij / dCN_i: Gaussian-weighted average over the reference grid (L = exp(K3 ((CN_i - a)^2 + (CN_j - b)^2)))
-__global__ void d3_c6_kernel(const double *__restrict__ cn, const int32_t *__restrict__ type, const int32_t *__restrict__ mxc,
-                             const double *__restrict__ ref, int n, int nt, double *__restrict__ c6, double *__restrict__ dc6) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= (int64_t)n * n) return;
-  const int i = (int)(k / n), j = (int)(k - (int64_t)i * n);
-  const int ti = type[i], tj = type[j];
-  const double cni = cn[i], cnj = cn[j];
-  const double *g = ref + ((size_t)ti * nt + tj) * (MAXREF * MAXREF * 3);
+// C6_ij(CN_i, CN_j) and dC6_ij / dCN_i: Gaussian-weighted average over the reference grid (L = exp(K3 ((CN_i - a)^2 + (CN_j - b)^2))).
+// Evaluated where it is used (d3_pair_kernel), once per (i, j, chunk of images): no [n, n] tables in memory (the reference keeps
+// n (n + 1) / 2 fp32 entries, pair_d3.cu; the 16 n^2 bytes of fp64 tables this file kept until round 4 would have been 160 GB at 100 k atoms)
+__device__ __forceinline__ void d3_c6(double cni, double cnj, const double *__restrict__ g, int mxi, int mxj, double &c6, double &dc6) {
   double num = 0.0, den = 0.0, dnum = 0.0, dden = 0.0, rmin = 1e300, cmin = 0.0;
-  for (int a = 0; a < mxc[ti]; ++a)
-    for (int b = 0; b < mxc[tj]; ++b) {
+  for (int a = 0; a < mxi; ++a)
+    for (int b = 0; b < mxj; ++b) {
       const double *e = g + (a * MAXREF + b) * 3;
       if (e[0] <= 0.0) continue;
       const double rr = (e[1] - cni) * (e[1] - cni) + (e[2] - cnj) * (e[2] - cnj);
@@ -85,12 +80,11 @@ __global__ void d3_c6_kernel(const double *__restrict__ cn, const int32_t *__res
       dden += dw;
     }
   if (den > 1e-99) {
-    const double c = num / den;
-    c6[k] = c;
-    dc6[k] = (dnum - c * dden) / den;
+    c6 = num / den;
+    dc6 = (dnum - c6 * dden) / den;
   } else {  // all weights underflow: the nearest reference value, no CN dependence (reference :833-837)
-    c6[k] = cmin;
-    dc6[k] = 0.0;
+    c6 = cmin;
+    dc6 = 0.0;
   }
 }
 
@@ -117,30 +111,45 @@ __device__ __forceinline__ void d3_phi(const Func &F, double r2, double r42, dou
 // strain derivative share s_i[ab] = -1/2 sum C6 phi' d_a d_b / r
 __global__ __launch_bounds__(NTH) void d3_pair_kernel(const double *__restrict__ x, const double *__restrict__ tau, int n, int T,
                                                       int t_zero, const double *__restrict__ r2r4, const double *__restrict__ r0ab,
-                                                      const int32_t *__restrict__ type, int nt, const double *__restrict__ c6,
-                                                      const double *__restrict__ dc6, double vdw_cut, Func F,
+                                                      const int32_t *__restrict__ type, int nt, const double *__restrict__ cn,
+                                                      const int32_t *__restrict__ mxc, const double *__restrict__ ref, int t_chunks,
+                                                      double vdw_cut, Func F,
                                                       double *__restrict__ e_atom, double *__restrict__ f, double *__restrict__ dedcn,
                                                       double *__restrict__ s_atom) {
   __shared__ double sh[4];
   const int i = blockIdx.x;
   const double xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2], q_i = r2r4[i];
   double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0, dc = 0.0, s[6] = {0, 0, 0, 0, 0, 0};
-  const int64_t total = (int64_t)n * T;
+  // work item = (atom j, chunk of the T images): C6_ij is evaluated once per item; t_chunks = 1 for large n, more for small cells whose
+  // many images would otherwise leave most of the block's threads without an atom j
+  const int ti = type[i], ch = (T + t_chunks - 1) / t_chunks;
+  const double cni = cn[i];
+  const int64_t total = (int64_t)n * t_chunks;
   for (int64_t k = threadIdx.x; k < total; k += NTH) {
-    const int j = (int)(k / T), t = (int)(k - (int64_t)j * T);
-    if (j == i && t == t_zero) continue;
-    const double dx = x[3 * j] - xi + tau[3 * t], dy = x[3 * j + 1] - yi + tau[3 * t + 1], dz = x[3 * j + 2] - zi + tau[3 * t + 2];
-    const double r2 = dx * dx + dy * dy + dz * dz;
-    if (r2 > vdw_cut) continue;
-    double phi, dphi;
-    d3_phi(F, r2, q_i * r2r4[j], r0ab[(size_t)type[i] * nt + type[j]], phi, dphi);
-    const double c = c6[(size_t)i * n + j];
-    e -= 0.5 * c * phi;
-    dc -= phi * dc6[(size_t)i * n + j];
-    const double g = c * dphi / sqrt(r2);   // C6 phi' / r
-    if (j != i) { fx -= g * dx; fy -= g * dy; fz -= g * dz; }
-    s[0] -= 0.5 * g * dx * dx; s[1] -= 0.5 * g * dy * dy; s[2] -= 0.5 * g * dz * dz;
-    s[3] -= 0.5 * g * dx * dy; s[4] -= 0.5 * g * dx * dz; s[5] -= 0.5 * g * dy * dz;
+    const int j = (int)(k / t_chunks), t_beg = (int)(k - (int64_t)j * t_chunks) * ch, t_end = min(T, t_beg + ch);
+    const int tj = type[j];
+    const double xj = x[3 * j] - xi, yj = x[3 * j + 1] - yi, zj = x[3 * j + 2] - zi;
+    const double r42 = q_i * r2r4[j], r0 = r0ab[(size_t)ti * nt + tj];
+    double c = 0.0, dcv = 0.0;
+    bool have_c6 = false;
+    for (int t = t_beg; t < t_end; ++t) {
+      if (j == i && t == t_zero) continue;
+      const double dx = xj + tau[3 * t], dy = yj + tau[3 * t + 1], dz = zj + tau[3 * t + 2];
+      const double r2 = dx * dx + dy * dy + dz * dz;
+      if (r2 > vdw_cut) continue;
+      if (!have_c6) {
+        d3_c6(cni, cn[j], ref + ((size_t)ti * nt + tj) * (MAXREF * MAXREF * 3), mxc[ti], mxc[tj], c, dcv);
+        have_c6 = true;
+      }
+      double phi, dphi;
+      d3_phi(F, r2, r42, r0, phi, dphi);
+      e -= 0.5 * c * phi;
+      dc -= phi * dcv;
+      const double g = c * dphi / sqrt(r2);   // C6 phi' / r
+      if (j != i) { fx -= g * dx; fy -= g * dy; fz -= g * dz; }
+      s[0] -= 0.5 * g * dx * dx; s[1] -= 0.5 * g * dy * dy; s[2] -= 0.5 * g * dz * dz;
+      s[3] -= 0.5 * g * dx * dy; s[4] -= 0.5 * g * dx * dz; s[5] -= 0.5 * g * dy * dz;
+    }
   }
   e = block_sum(e, sh); fx = block_sum(fx, sh); fy = block_sum(fy, sh); fz = block_sum(fz, sh); dc = block_sum(dc, sh);
   for (int q = 0; q < 6; ++q) s[q] = block_sum(s[q], sh);
@@ -223,7 +232,7 @@ struct snet_d3 {
   // results
   double energy = 0.0, stress[9] = {0};
   std::vector<double> forces, cn;
-  Dev<double> d_x, d_tv, d_tc, d_rcov, d_r2r4, d_r0, d_ref, d_cn, d_c6, d_dc6, d_e, d_f, d_dedcn, d_s;
+  Dev<double> d_x, d_tv, d_tc, d_rcov, d_r2r4, d_r0, d_ref, d_cn, d_e, d_f, d_dedcn, d_s;
   Dev<int32_t> d_type, d_mxc;
 };
 
@@ -359,14 +368,13 @@ int snet_d3_compute(snet_d3 *d, void *stream) {
   for (int i = 0; i < n; ++i) { rcov[i] = d->rcov[d->z[i] - 1]; r2r4[i] = d->r2r4[d->z[i] - 1]; }
   bool ok = d->d_x.put(x, st) && d->d_tv.put(tv, st) && d->d_tc.put(tc, st) && d->d_rcov.put(rcov, st) && d->d_r2r4.put(r2r4, st) &&
             d->d_r0.put(r0, st) && d->d_ref.put(ref, st) && d->d_type.put(type, st) && d->d_mxc.put(mxc, st) &&
-            d->d_cn.ensure(n) && d->d_c6.ensure((size_t)n * n) && d->d_dc6.ensure((size_t)n * n) && d->d_e.ensure(n) &&
+            d->d_cn.ensure(n) && d->d_e.ensure(n) &&
             d->d_f.ensure(3 * (size_t)n) && d->d_dedcn.ensure(n) && d->d_s.ensure(6 * (size_t)n);
   SNET_REQUIRE(ok, "snet_d3_compute: device allocation / upload failed");
   d3_cn_kernel<<<n, NTH, 0, st>>>(d->d_x.p, d->d_tc.p, n, Tc, zc, d->d_rcov.p, d->cn_cut, d->d_cn.p);
-  d3_c6_kernel<<<(unsigned)(((int64_t)n * n + 255) / 256), 256, 0, st>>>(d->d_cn.p, d->d_type.p, d->d_mxc.p, d->d_ref.p, n, nt,
-                                                                         d->d_c6.p, d->d_dc6.p);
-  d3_pair_kernel<<<n, NTH, 0, st>>>(d->d_x.p, d->d_tv.p, n, Tv, zv, d->d_r2r4.p, d->d_r0.p, d->d_type.p, nt, d->d_c6.p, d->d_dc6.p,
-                                    d->vdw_cut, d->func, d->d_e.p, d->d_f.p, d->d_dedcn.p, d->d_s.p);
+  const int t_chunks = std::max(1, std::min(Tv, (4 * NTH + n - 1) / n));   // >= 4 work items per thread where the images allow it
+  d3_pair_kernel<<<n, NTH, 0, st>>>(d->d_x.p, d->d_tv.p, n, Tv, zv, d->d_r2r4.p, d->d_r0.p, d->d_type.p, nt, d->d_cn.p, d->d_mxc.p,
+                                    d->d_ref.p, t_chunks, d->vdw_cut, d->func, d->d_e.p, d->d_f.p, d->d_dedcn.p, d->d_s.p);
   d3_cn_force_kernel<<<n, NTH, 0, st>>>(d->d_x.p, d->d_tc.p, n, Tc, zc, d->d_rcov.p, d->cn_cut, d->d_dedcn.p, d->d_f.p, d->d_s.p);
   SNET_CHECK_LAUNCH("snet_d3_compute");
   std::vector<double> e(n), s(6 * (size_t)n);
