@@ -35,3 +35,24 @@ def synthetic_system(n_rep=(2, 2, 2), a=5.431, sigma=0.05, seed=0, cutoff=5.0, n
     rng = np.random.default_rng(seed + 1)
     types = rng.integers(0, n_species, len(pos)) if n_species > 1 else np.zeros(len(pos), np.int64)
     return types, pos, cell, ei, ev
+
+
+def packed_tiles_expected(row_ptr, lo, hi, group=8):
+    """restatement of snet_edge_tiles_packed: greedy windows of <= 16 consecutive edges over <= 2 rows, per group of rows"""
+    rp = [int(v) for v in row_ptr]
+    e0, nodes = [], []
+    for a in range(lo, hi, group):
+        b = min(a + group, hi)
+        e, n0 = rp[a], a
+        while e < rp[b]:
+            while rp[n0 + 1] <= e:
+                n0 += 1
+            n1 = n0 + 1
+            while n1 < b and rp[n1 + 1] == rp[n1]:
+                n1 += 1
+            lim = rp[n1 + 1] if n1 < b else rp[n0 + 1]
+            end = min(e + 16, lim)
+            e0.append(e)
+            nodes += [n0, n1 if end > rp[n0 + 1] else n0]
+            e = end
+    return e0 + [rp[hi]], nodes

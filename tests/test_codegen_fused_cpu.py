@@ -106,3 +106,35 @@ def test_reverse_schedule_sub_step_counts_of_sevennet_0():
     (a single x block) keeps 16"""
     counts = {tag: len(codegen_fused.schedule_bwd(FUSABLE[tag])[1]) for tag in ('22d6a77ad5ac', '005c575f8ec2', 'ecc5d202727d')}
     assert counts == {'22d6a77ad5ac': 30, '005c575f8ec2': 7, 'ecc5d202727d': 16}
+
+
+def test_packed_tile_definition_properties():
+    """the greedy packed-tile list (tests/helpers.packed_tiles_expected, what snet_edge_tiles_packed is checked against on the GPU):
+    every edge in exactly one tile, at most 16 edges and two rows per tile, never more tiles than the per-row list, the 28-neighbour
+    crystal loses no lane (7 tiles per 4 rows), and lists of adjacent row ranges chain into one list"""
+    import random
+    from helpers import packed_tiles_expected
+    rnd = random.Random(11)
+    for trial in range(60):
+        n = rnd.randint(1, 70)
+        kind = trial % 4
+        deg = [28] * n if kind == 0 else [rnd.choice([0, 0, 1, 2, 3]) for _ in range(n)] if kind == 1 else \
+            [rnd.randint(0, 45) for _ in range(n)] if kind == 2 else [rnd.choice([0, 16, 17, 32, 5]) for _ in range(n)]
+        rp = [0]
+        for d in deg:
+            rp.append(rp[-1] + d)
+        center = [i for i, d in enumerate(deg) for _ in range(d)]
+        cut = rnd.randint(0, n)
+        for lo, hi in ((0, n), (0, cut), (cut, n)):
+            e0, nodes = packed_tiles_expected(rp, lo, hi)
+            nt = len(e0) - 1
+            assert len(nodes) == 2 * nt and e0[0] == rp[lo] and e0[-1] == rp[hi]
+            for t in range(nt):
+                assert 0 < e0[t + 1] - e0[t] <= 16
+                assert set(center[e0[t]:e0[t + 1]]) == set(nodes[2 * t:2 * t + 2])
+            assert nt <= sum((d + 15) // 16 for d in deg[lo:hi])
+        a, na = packed_tiles_expected(rp, 0, cut)
+        b, nb = packed_tiles_expected(rp, cut, n)
+        assert a[-1] == b[0]                      # the interior list's sentinel is the boundary list's first edge
+        if kind == 0 and n % 4 == 0:
+            assert len(packed_tiles_expected(rp, 0, n)[0]) - 1 == 7 * n // 4

@@ -3,6 +3,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
+from helpers import packed_tiles_expected
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -346,27 +347,6 @@ def _fused_case(model, layer, seed, pairs):
 
 
 
-def _packed_tiles_expected(row_ptr, lo, hi, group=8):
-    """restatement of snet_edge_tiles_packed: greedy windows of <= 16 consecutive edges over <= 2 rows, per group of rows"""
-    rp = [int(v) for v in row_ptr]
-    e0, nodes = [], []
-    for a in range(lo, hi, group):
-        b = min(a + group, hi)
-        e, n0 = rp[a], a
-        while e < rp[b]:
-            while rp[n0 + 1] <= e:
-                n0 += 1
-            n1 = n0 + 1
-            while n1 < b and rp[n1 + 1] == rp[n1]:
-                n1 += 1
-            lim = rp[n1 + 1] if n1 < b else rp[n0 + 1]
-            end = min(e + 16, lim)
-            e0.append(e)
-            nodes += [n0, n1 if end > rp[n0 + 1] else n0]
-            e = end
-    return e0 + [rp[hi]], nodes
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize('pattern', ['crystal28', 'zeros_and_ones', 'long_rows', 'random', 'single_row', 'all_empty'])
 def test_packed_tiles_builder_matches_its_definition(pattern):
@@ -399,7 +379,7 @@ def test_packed_tiles_builder_matches_its_definition(pattern):
 
     for lo, hi in ((0, N), (0, N // 3), (N // 3, N), (7 % N, max(7 % N, N - 5))):
         te, tn, nt = build(lo, hi)
-        e0, nodes = _packed_tiles_expected(row_ptr, lo, hi)
+        e0, nodes = packed_tiles_expected(row_ptr, lo, hi)
         assert nt == len(e0) - 1
         if hi > lo:
             assert te[:nt + 1] == e0 and tn[:2 * nt] == nodes
@@ -414,7 +394,7 @@ def test_packed_tiles_builder_matches_its_definition(pattern):
         assert nt <= int(((deg[lo:hi] + 15) // 16).sum())           # never more tiles than the per-row list
     if E > 0 and N > 3:   # capacity is checked, not overrun
         with pytest.raises(RuntimeError, match='capacity'):
-            build(0, N, cap=max(1, len(_packed_tiles_expected(row_ptr, 0, N)[0]) - 2))
+            build(0, N, cap=max(1, len(packed_tiles_expected(row_ptr, 0, N)[0]) - 2))
 
 
 def _work_list(L, lib, fplan, rp, row_ptr_cpu, N, E, dev):
@@ -426,7 +406,7 @@ def _work_list(L, lib, fplan, rp, row_ptr_cpu, N, E, dev):
         tile_ptr = torch.full((cap + 1,), -1, dtype=torch.int32, device=dev)
         tile_node = torch.full((2 * cap,), -1, dtype=torch.int32, device=dev)
         L.check(lib.snet_edge_tiles_packed(_p(rp), 0, N, _p(tile_ptr), _p(tile_node), cap, C.byref(n_tiles), None))
-        e0, nodes = _packed_tiles_expected(row_ptr_cpu, 0, N)
+        e0, nodes = packed_tiles_expected(row_ptr_cpu, 0, N)
         nt = n_tiles.value
         assert nt == len(e0) - 1 <= int(((deg + 15) // 16).sum())
         assert tile_ptr.cpu()[:nt + 1].tolist() == e0 and tile_node.cpu()[:2 * nt].tolist() == nodes
