@@ -224,6 +224,12 @@ struct snet_model {
   std::vector<float> coeffs;
   float *embed = nullptr, *scale = nullptr, *shift = nullptr;
   double *ro_v = nullptr, ro_c = 0.0;  // folded readout vector (device) and constant
+  // `readout_as_fcn` (nn/linear.py:145-180): x -> act(x W0) cst -> ... -> e on exact fp32 GEMMs, like engine.py
+  std::vector<int> fcn_dims;            // empty: folded two-linear readout
+  std::vector<float *> fcn_w, fcn_wt;   // W_i [d_i, d_{i+1}] and its transpose (device)
+  int fcn_act = 0;
+  float fcn_cst = 1.f;
+  double *one_d = nullptr;              // {1.0}: snet_readout_grad with it writes scale[type] (the seed of the reverse pass)
   float *h0_table = nullptr, *sc0_table = nullptr;  // [n_species, dx0], [n_species, gin0]: layer 0's SI1(x) / sc(x) per species
   float scale0 = 1.f;
   std::vector<Layer> layers;
@@ -313,7 +319,7 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
   Reader r{static_cast<const unsigned char *>(blob), static_cast<const unsigned char *>(blob) + n_bytes};
   char magic[8];
   r.get(magic, 8);
-  SNET_REQUIRE(r.ok && memcmp(magic, "SNETMDL3", 8) == 0, "snet_model_load: not a .snet model file of this version (SNETMDL3)");
+  SNET_REQUIRE(r.ok && memcmp(magic, "SNETMDL4", 8) == 0, "snet_model_load: not a .snet model file of this version (SNETMDL4)");
   auto *m = new snet_model;
   bool good = false;
   try {
@@ -390,7 +396,9 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
     }
     m->layers.push_back(L);
   }
-  good = good && read_linear(r, m->ro1) && read_linear(r, m->ro2);
+  const int ro_kind = good ? r.i32() : 0;
+  good = good && r.ok && (ro_kind == 0 || ro_kind == 1);
+  if (good && ro_kind == 0) good = read_linear(r, m->ro1) && read_linear(r, m->ro2);
   if (good) {  // layer 0's species-only rows SI1(x), sc(x): fp64-evaluated tables (model_spec.species_only_tables)
     const int dx0 = r.i32(), gin0 = r.i32();
     good = r.ok && dx0 == m->layers[0].dx && (gin0 == 0 || gin0 == m->layers[0].gin) && (gin0 != 0) == m->layers[0].sc.present();
@@ -399,7 +407,31 @@ extern "C" int snet_model_load_memory(const void *blob, int64_t n_bytes, snet_mo
       good = r.ok && dev_upload(h0, &m->h0_table) && dev_upload(sc0, &m->sc0_table);
     }
   }
-  if (good) {  // folded readout: e_i = x_i . v + c (model_spec.folded_readout)
+  if (good && ro_kind == 1) {
+    const int nl = r.i32();
+    good = r.ok && nl >= 1 && nl <= 16;
+    for (int i = 0; good && i <= nl; ++i) {
+      m->fcn_dims.push_back(r.i32());
+      good = r.ok && m->fcn_dims.back() >= 1 && m->fcn_dims.back() <= (1 << 16);
+    }
+    m->fcn_act = good ? r.i32() : 0;
+    m->fcn_cst = good ? r.f32() : 1.f;
+    good = good && r.ok && m->fcn_act >= 0 && m->fcn_act < snet::N_ACT && m->fcn_dims.front() == m->layers.back().dout && m->fcn_dims.back() == 1;
+    for (int i = 0; good && i < nl; ++i) {
+      const int di = m->fcn_dims[i], dn = m->fcn_dims[i + 1];
+      std::vector<float> w = r.farr((size_t)di * dn), wt((size_t)di * dn);
+      for (int a = 0; a < di && r.ok; ++a)
+        for (int b = 0; b < dn; ++b) wt[(size_t)b * di + a] = w[(size_t)a * dn + b];
+      float *dw = nullptr, *dwt = nullptr;
+      good = r.ok && dev_upload(w, &dw) && dev_upload(wt, &dwt);
+      m->fcn_w.push_back(dw);
+      m->fcn_wt.push_back(dwt);
+    }
+    const double one = 1.0;
+    good = good && hipMalloc((void **)&m->one_d, 8) == hipSuccess && hipMemcpy(m->one_d, &one, 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (good) m->ro1.dim_in = m->fcn_dims.front();
+  }
+  if (good && ro_kind == 0) {  // folded readout: e_i = x_i . v + c (model_spec.folded_readout)
     const int d_ro = r.i32();
     m->ro_c = r.f64();
     good = r.ok && d_ro == m->ro1.dim_in && d_ro == m->layers.back().dout;
@@ -455,6 +487,9 @@ extern "C" void snet_model_destroy(snet_model *m) {
     }
     if (L.bias) (void)hipFree(L.bias);
   };
+  for (float *w : m->fcn_w) if (w) (void)hipFree(w);
+  for (float *w : m->fcn_wt) if (w) (void)hipFree(w);
+  if (m->one_d) (void)hipFree(m->one_d);
   for (auto &L : m->layers) {
     snet_fused_plan_destroy(L.fused);
     snet_fused_plan_destroy(L.tfused);
@@ -637,6 +672,9 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   if (need_tiles[1]) { add((size_t)N + (size_t)E / 16 + 64); add(2 * ((size_t)N + (size_t)E / 16 + 64)); }  // packed: tile_e0, tile_nodes
   if (any_transposed) { add((size_t)E + 64); add((size_t)E + 64); add((size_t)E * nsh + 64); }  // center_t, w_row_t, sh_t
   add((size_t)NT * dmax * 2 + 256); add((size_t)N * (m->ro1.dim_out + 8) * 2); add(trans + 64 * 1024);
+  for (size_t i = 0; i + 1 < m->fcn_dims.size(); ++i) {   // readout_as_fcn: z_i, a_i forward, the gradient rows in reverse
+    add((size_t)N * m->fcn_dims[i + 1] + 64); add((size_t)N * m->fcn_dims[i + 1] + 64); add((size_t)N * m->fcn_dims[i] + 64);
+  }
   need += 1 << 20;
   if (m->arena.cap < need) {
     if (m->arena.base) (void)hipFree(m->arena.base);
@@ -868,12 +906,40 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   }
   A.off = mark;
   float *ea = e_atom ? e_atom : A.f((size_t)N + 64);
-  if ((rc = snet_readout_energy(x, N, m->ro1.dim_in, m->ro_v, m->ro_c, types, m->scale, m->shift, m->n_scale, ea, energy, st)))
-    return rc;
-
-  // ---------------- reverse: dE/dx of the folded readout = scale[type] * v
-  float *g_x = x2, *gx_next = x;  // the forward features are dead: x / x2 ping-pong as gradient rows
-  if ((rc = snet_readout_grad(m->ro_v, m->ro1.dim_in, types, m->scale, m->n_scale, N, g_x, st))) return rc;
+  float *g_x = x2, *gx_next = x;  // the forward features are dead after the readout: x / x2 ping-pong as gradient rows
+  if (!m->fcn_dims.empty()) {
+    // `readout_as_fcn`: the same launches, in the same order, as engine.py (exact fp32 GEMMs, activation kernels): bit-identical hosts
+    const std::vector<int> &d = m->fcn_dims;
+    const int nl = (int)d.size() - 1;
+    std::vector<float *> zs;
+    const float *a = x;
+    float *z = nullptr;
+    for (int i = 0; i < nl; ++i) {
+      z = A.f((size_t)N * d[i + 1] + 64);
+      if ((rc = snet_gemm(a, m->fcn_w[i], z, N, 1, d[i], d[i + 1], d[i], 0, d[i + 1], 0, nullptr, 0, st))) return rc;
+      if (i + 1 < nl) {
+        float *an = A.f((size_t)N * d[i + 1] + 64);
+        if ((rc = snet_act_fwd(z, an, N * d[i + 1], m->fcn_act, m->fcn_cst, st))) return rc;
+        zs.push_back(z);
+        a = an;
+      }
+    }
+    if ((rc = snet_rescale_reduce(z, types, m->scale, m->shift, m->n_scale, N, ea, energy, st))) return rc;
+    // reverse: dE/dz_last = scale[type]; then W^T and the activation's derivative per layer; the last product lands in g_x
+    float *gz = A.f((size_t)N + 64);
+    if ((rc = snet_readout_grad(m->one_d, 1, types, m->scale, m->n_scale, N, gz, st))) return rc;
+    for (int i = nl - 1; i >= 0; --i) {
+      float *ga = i == 0 ? g_x : A.f((size_t)N * d[i] + 64);
+      if ((rc = snet_gemm(gz, m->fcn_wt[i], ga, N, 1, d[i + 1], d[i], d[i + 1], 0, d[i], 0, nullptr, 0, st))) return rc;
+      if (i > 0 && (rc = snet_act_bwd(zs[i - 1], ga, ga, N * d[i], m->fcn_act, m->fcn_cst, st))) return rc;
+      gz = ga;
+    }
+  } else {
+    if ((rc = snet_readout_energy(x, N, m->ro1.dim_in, m->ro_v, m->ro_c, types, m->scale, m->shift, m->n_scale, ea, energy, st)))
+      return rc;
+    // ---------------- reverse: dE/dx of the folded readout = scale[type] * v
+    if ((rc = snet_readout_grad(m->ro_v, m->ro1.dim_in, types, m->scale, m->n_scale, N, g_x, st))) return rc;
+  }
   SNET_REQUIRE(hipMemsetAsync(g_vec, 0, (size_t)E * 3 * 4, st) == hipSuccess &&
                    hipMemsetAsync(g_emb, 0, (size_t)E * nb * 4, st) == hipSuccess,
                "snet_model_eval: memset failed");

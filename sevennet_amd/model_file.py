@@ -7,7 +7,7 @@ all tables of `ModelSpec` plus the weights with every normalisation already fold
 host needs no Python, no torch and no e3nn.
 
 Layout (all ints int32, floats float32 unless noted):
-    magic 'SNETMDL3'   (v3: species tables of layer 0; unread tensor-product paths are not stored)
+    magic 'SNETMDL4'   (v3: species tables of layer 0; unread tensor-product paths are not stored; v4: readout kind, `readout_as_fcn`)
     header  : n_species n_layers lmax normalize n_basis cutoff_kind poly_p act_radial n_scale d0
               cutoff(f32) cutoff_on(f32) act_cst(f32)
     coeffs[n_basis]  embed[n_species*d0]  scale[n_scale]  shift[n_scale]
@@ -15,10 +15,11 @@ Layout (all ints int32, floats float32 unless noted):
                mlp dims[4]  W0 W1 W2 (row-major, 1/sqrt(fan_in) folded)
                linear sc (all-zero header if absent), si1, si2   (see _write_linear)
                n_gate_segs, segs[kind in_off out_off mul l gate_off act | cst f32]
-    readout linears ro1, ro2
+    readout kind (0 / 1); kind 0: readout linears ro1, ro2
     species tables of layer 0 (model_spec.species_only_tables): dx0, gin0 (0 = no self-connection),
                h0[n_species*dx0], sc0[n_species*gin0]  -- SI1(x) and sc(x) of the species-only layer-0 inputs, fp64-evaluated
-    folded readout (model_spec.folded_readout): d_ro, c (float64), v[d_ro] (float64)  -- e_i = x_i . v + c
+    kind 0: folded readout (model_spec.folded_readout): d_ro, c (float64), v[d_ro] (float64)  -- e_i = x_i . v + c
+    kind 1: n_fcn_layers, widths[n + 1], act id, act_cst (f32), then W_i[d_i * d_{i+1}] with 1/sqrt(d_i) folded
     metadata : n_bytes, then `key=value` lines (utf-8) -- the `_extra_files` of the reference's deployed
                model (deploy.py:56-72): chemical_symbols_to_index, cutoff, num_species, model_type,
                version, dtype
@@ -33,7 +34,7 @@ import numpy as np
 from .model_spec import (ACT_CST, ACT_ID, LinearSpec, build_model_spec, folded_readout, linear_modal_bias,
                          linear_weight_matrices, species_only_tables)
 
-MAGIC = b'SNETMDL3'
+MAGIC = b'SNETMDL4'
 
 _SYMBOLS = ('X H He Li Be B C N O F Ne Na Mg Al Si P S Cl Ar K Ca Sc Ti V Cr Mn Fe Co Ni Cu Zn Ga Ge As Se Br Kr Rb Sr '
             'Y Zr Nb Mo Tc Ru Rh Pd Ag Cd In Sn Sb Te I Xe Cs Ba La Ce Pr Nd Pm Sm Eu Gd Tb Dy Ho Er Tm Yb Lu Hf Ta W '
@@ -94,9 +95,6 @@ def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray],
     """modal: fidelity channel of a multi-modal model, fixed in the file like the reference's
     `prepare_modal_deploy` (sevenn/scripts/deploy.py:42-47)."""
     sp = build_model_spec(config)
-    if sp.readout_fcn_dims:
-        raise NotImplementedError('readout_as_fcn models run through the Python host (HipForceEngine); the .snet format of the '
-                                  'native sequencer carries the two-linear readout only')
     mi = sp.modal_index(modal)
     sd = {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, 'detach') else v, dtype=np.float64)
           for k, v in state_dict.items()}
@@ -137,17 +135,26 @@ def write_model_file(path: str, config: dict, state_dict: Dict[str, np.ndarray],
         for s in ls.gate.segs:
             out.append(_i(s.kind, s.in_off, s.out_off, s.mul, s.l, s.gate_off, s.act))
             out.append(_f(ACT_CST[inv_act[s.act]]))
-    out.append(_write_linear(sp.readout1, sd[sp.readout1.name], mi, sd.get(sp.readout1.bias_name)))
-    out.append(_write_linear(sp.readout2, sd[sp.readout2.name], -1, sd.get(sp.readout2.bias_name)))
+    fcn = sp.readout_fcn_dims
+    out.append(_i(1 if fcn else 0))   # readout kind: 0 = two linears (stored folded below), 1 = `readout_as_fcn` (nn/linear.py:145-180)
+    if not fcn:
+        out.append(_write_linear(sp.readout1, sd[sp.readout1.name], mi, sd.get(sp.readout1.bias_name)))
+        out.append(_write_linear(sp.readout2, sd[sp.readout2.name], -1, sd.get(sp.readout2.bias_name)))
     h0, sc0 = species_only_tables(sp, sd, mi)
     out.append(_i(h0.shape[1], 0 if sc0 is None else sc0.shape[1]))
     out.append(_arr(h0))
     if sc0 is not None:
         out.append(_arr(sc0))
-    v, c = folded_readout(sp, sd, mi)
-    out.append(_i(len(v)))
-    out.append(struct.pack('<d', c))
-    out.append(np.ascontiguousarray(v, dtype='<f8').tobytes())
+    if fcn:   # layer count, widths, activation, then W_i / sqrt(fan_in) as [d_i, d_{i+1}] (what engine.py multiplies with)
+        out.append(_i(len(fcn) - 1, *fcn, ACT_ID[sp.readout_fcn_act]))
+        out.append(_f(ACT_CST[sp.readout_fcn_act]))
+        for i in range(len(fcn) - 1):
+            out.append(_arr(sd[f'readout_FCN.fcn.layer{i}.weight'].reshape(fcn[i], fcn[i + 1]) / np.sqrt(fcn[i])))
+    else:
+        v, c = folded_readout(sp, sd, mi)
+        out.append(_i(len(v)))
+        out.append(struct.pack('<d', c))
+        out.append(np.ascontiguousarray(v, dtype='<f8').tobytes())
     meta = {'chemical_symbols_to_index': ' '.join(species_symbols(config, sp.num_species)),
             'cutoff': repr(float(sp.cutoff)), 'num_species': str(sp.num_species),
             'model_type': str(config.get('model_type', 'E3_equivariant_model')),

@@ -19,7 +19,7 @@ def test_model_file_header_and_size(tmp_path):
     cfg = sevennet_0_config()
     p, sd = _write(tmp_path, cfg)
     blob = p.read_bytes()
-    assert blob[:8] == b'SNETMDL3'
+    assert blob[:8] == b'SNETMDL4'
     sp = build_model_spec(cfg)
     hdr = struct.unpack('<10i3f', blob[8:8 + 52])
     assert hdr[0] == sp.num_species and hdr[1] == 5 and hdr[2] == 2 and hdr[4] == 8 and hdr[9] == 128
@@ -74,7 +74,7 @@ def test_deploy_cli_from_checkpoint(tmp_path):
     out = tmp_path / 'm.snet'
     assert main([str(ck), '-o', str(out)]) == 0
     blob = out.read_bytes()
-    assert blob[:8] == b'SNETMDL3'
+    assert blob[:8] == b'SNETMDL4'
     tail = blob[-400:].decode('latin1')
     assert 'chemical_symbols_to_index=Hf O\n' in tail and 'model_type=E3_equivariant_model' in tail
 
@@ -237,3 +237,29 @@ def test_paths_nothing_reads_are_not_evaluated():
             assert l2.w_cols is None or (c is cfg and l2.t == 3)
     full = build_model_spec(dict(cfg, _prune_unread_paths=False)).layers[3]
     assert len(full.conv.paths) == 68 and full.w_cols is None
+
+
+def test_model_file_carries_the_fcn_readout(tmp_path):
+    """format v4: `readout_as_fcn` models are written (readout kind 1: widths, activation, W_i / sqrt(fan_in)); the tail of the file
+    before the metadata is exactly that block"""
+    from sevennet_amd.model_spec import ACT_CST, ACT_ID
+    from sevennet_amd.shapes import unit_test_config
+    cfg = unit_test_config(readout_as_fcn=True, readout_fcn_hidden_neurons=[16, 8], readout_fcn_activation='elu')
+    p, sd = _write(tmp_path, cfg)
+    blob = p.read_bytes()
+    assert blob[:8] == b'SNETMDL4'
+    meta_len = blob.rfind(b'chemical_symbols_to_index=')
+    n_meta = struct.unpack('<i', blob[meta_len - 4:meta_len])[0]
+    assert meta_len + n_meta == len(blob)
+    dims = [4, 16, 8, 1]
+    n_w = sum(dims[i] * dims[i + 1] for i in range(3))
+    blk = blob[meta_len - 4 - 4 * n_w - 4 * (1 + 4 + 1) - 4:meta_len - 4]
+    head = struct.unpack('<6i', blk[:24])
+    assert list(head) == [3, 4, 16, 8, 1, ACT_ID['elu']]
+    assert struct.unpack('<f', blk[24:28])[0] == pytest.approx(ACT_CST['elu'])
+    w = np.frombuffer(blk[28:], '<f4')
+    off = 0
+    for i in range(3):
+        ref = np.asarray(sd[f'readout_FCN.fcn.layer{i}.weight'], np.float64).reshape(dims[i], dims[i + 1]) / np.sqrt(dims[i])
+        assert np.allclose(w[off:off + ref.size], ref.astype(np.float32).ravel())
+        off += ref.size

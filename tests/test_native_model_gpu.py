@@ -56,6 +56,10 @@ CASES = {
     # o3.Linear biases (folded into the .snet linears' constant rows, the species tables and the readout vector) + other activations
     'unit_bias_ssp_abs': dict(cfg='unit', over={'use_bias_in_linear': True, 'act_radial': 'ssp', 'act_scalar': {'e': 'ssp', 'o': 'abs'},
                                                 'act_gate': {'e': 'ssp', 'o': 'abs'}}, cutoff=4.0, nsp=4),
+    # `readout_as_fcn` in the .snet file (format v4): the native sequencer runs engine.py's launches in engine.py's order
+    'unit_bias_fcn_elu': dict(cfg='unit', over={'use_bias_in_linear': True, 'readout_as_fcn': True, 'readout_fcn_activation': 'elu'},
+                              cutoff=4.0, nsp=4),
+    'unit_fcn_one_hidden_relu': dict(cfg='unit', over={'readout_as_fcn': True, 'readout_fcn_hidden_neurons': [16]}, cutoff=4.0, nsp=4),
 }
 
 
