@@ -138,3 +138,22 @@ def test_packed_tile_definition_properties():
         assert a[-1] == b[0]                      # the interior list's sentinel is the boundary list's first edge
         if kind == 0 and n % 4 == 0:
             assert len(packed_tiles_expected(rp, 0, n)[0]) - 1 == 7 * n // 4
+
+
+def test_work_list_format_per_shape():
+    """which reverse kernels take packed two-row tiles (DESIGN 4b viii): the two-wave middle-layer class and the narrow lmax-3 shapes;
+    not the first / last layers (measured slower there), not the wide lmax-3 shapes (no registers for the second g_out set)"""
+    import re
+    from sevennet_amd import codegen_fused
+    from sevennet_amd.shapes import aot_conv_specs
+    specs = aot_conv_specs(())
+    mode = {}
+    for tag in ('22d6a77ad5ac', 'ecc5d202727d', '005c575f8ec2', '0b99ee053764', '1cad2f51cbd0', '2d3e65aea6f3', '0431c055196e',
+                '707b9944ff82', '502c5bba8e99'):
+        src = codegen_fused.gen_conv_fused(specs[tag])
+        mode[tag] = int(re.search(r'launch_bwd, launch_fwd, (\d)\}', src).group(1))
+        packed = 'tile_node[2 * t + 1]' in src
+        assert packed == bool(mode[tag])                         # the kernel body and the advertised format agree
+        assert ('s_g[NWV][2][NGP * 16 + 16]' in src) == packed   # two g_out sets, 16 floats apart, only in the packed form
+    assert mode == {'22d6a77ad5ac': 1, 'ecc5d202727d': 0, '005c575f8ec2': 0, '0b99ee053764': 0, '1cad2f51cbd0': 0, '2d3e65aea6f3': 0,
+                    '0431c055196e': 0, '707b9944ff82': 0, '502c5bba8e99': 1}
