@@ -19,6 +19,11 @@ double pair_get_energy(PairD3 *pair);                                           
 double *pair_get_force(PairD3 *pair);                                              /* :2068  [natoms*3] eV/A */
 double *pair_get_stress(PairD3 *pair);                                             /* :2072  [6] virial sums xx yy zz xy xz yz (eV) */
 void pair_fin(PairD3 *pair);                                                       /* :2076 */
+/* Failure behaviour.  The reference's functions abort the process on a CUDA error; these never abort: the first failure on a
+ * handle (missing data/d3_params.bin, unknown functional / damping name, HIP error) is sticky, printed once to stderr, and from
+ * then on pair_get_force / pair_get_stress return NULL and pair_get_energy NaN.  pair_failed (an extension) reads the flag;
+ * the message is snet_last_error(). */
+int pair_failed(PairD3 *pair);
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define SNET_ABI_VERSION 1
+/* Bumped whenever an exported signature or a file format changes incompatibly; every host checks snet_abi_version() against
+ * the header it was built from (sevennet_amd/_lib.py, lammps/pair_*_hip.cpp).  History: 1 = rounds 1-3; 2 = round 4 (snet_nl_grid /
+ * _bin / _count / _fill gained the open-axis arguments, .snet files moved to "SNETMDL4") and round 5 (pair_failed). */
+#define SNET_ABI_VERSION 2
 
 /* ---- housekeeping ------------------------------------------------------- */
 int snet_abi_version(void);

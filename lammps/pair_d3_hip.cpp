@@ -85,8 +85,13 @@ void PairD3Hip::coeff(int narg, char **arg) {
   }
   for (int i = 1; i <= ntypes; ++i)
     for (int j = 1; j <= ntypes; ++j) setflag[i][j] = 1;
+  if (snet_abi_version() != SNET_ABI_VERSION) error->all(FLERR, "pair_style d3: libsnet_hip.so was built from a different snet_hip.h");
   if (!d3) d3 = pair_init();
-  if (!d3) error->all(FLERR, "pair_style d3: the D3 engine of libsnet_hip.so could not be created");
+  if (!d3 || pair_failed(d3)) error->all(FLERR, std::string("pair_style d3: the D3 engine of libsnet_hip.so could not be created: ") + snet_last_error());
+  // functional / damping names and the parameter blob are resolved HERE, so that a typo or a missing data/d3_params.bin stops
+  // the run at setup like the reference's error->all (pair_d3.cu:261-285, :303-640), not as zero dispersion at step one
+  pair_run_settings(d3, rthr, cnthr, damping.c_str(), functional.c_str());
+  if (pair_failed(d3)) error->all(FLERR, std::string("pair_style d3: ") + snet_last_error());
 }
 
 void PairD3Hip::init_style() {
@@ -110,12 +115,13 @@ void PairD3Hip::compute(int eflag, int vflag) {
   pair_set_atom(d3, n, atom->ntypes, atom->type, xflat.data());
   pair_set_domain(d3, domain->xperiodic, domain->yperiodic, domain->zperiodic, domain->boxlo, domain->boxhi, domain->xy,
                   domain->xz, domain->yz);
-  pair_run_settings(d3, rthr, cnthr, damping.c_str(), functional.c_str());
+  // (settings were resolved in coeff(); the tables went to the device with the first pair_run_coeff: per step only the
+  // positions, types and the box travel)
   pair_run_coeff(d3, atomic_numbers.data());
   pair_run_compute(d3);
   const double *f = pair_get_force(d3);
   const double *s = pair_get_stress(d3);
-  if (!f || !s) error->all(FLERR, std::string("pair_style d3: ") + snet_last_error());
+  if (pair_failed(d3) || !f || !s) error->all(FLERR, std::string("pair_style d3: ") + snet_last_error());
   if (eflag_global) eng_vdwl += pair_get_energy(d3);
   for (int i = 0; i < n; ++i)
     for (int k = 0; k < 3; ++k) atom->f[i][k] += f[3 * (size_t)i + k];

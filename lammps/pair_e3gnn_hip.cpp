@@ -83,6 +83,9 @@ void PairE3GNNHip::coeff(int narg, char **arg) {
   allocate();
   if (narg < 3 || strcmp(arg[0], "*") != 0 || strcmp(arg[1], "*") != 0)
     error->all(FLERR, "e3gnn: first and second input of pair_coeff should be '*'");
+  if (snet_abi_version() != SNET_ABI_VERSION)
+    error->all(FLERR, "e3gnn: libsnet_hip.so was built from a different snet_hip.h (ABI version " + std::to_string(snet_abi_version()) +
+                          ", this pair style expects " + std::to_string(SNET_ABI_VERSION) + "); rebuild the library or the pair style");
   if (snet_model_load(arg[2], &model)) error->all(FLERR, std::string("e3gnn: ") + snet_last_error());
   if (snet_md_create(model, &host)) error->all(FLERR, std::string("e3gnn: ") + snet_last_error());
 
@@ -207,6 +210,12 @@ void PairE3GNNHip::build_halo_plan() {
 void PairE3GNNHip::compute(int eflag, int vflag) {
   ev_init(eflag, vflag);
   if (ghost_mode == 1 && vflag_atom) error->all(FLERR, "atomic stress is not supported\n");
+  // an empty sub-domain: the reference's parallel style fails inside LibTorch there (docs/source/user_guide/lammps_torch.md:
+  // 111-113: "encounters an error when one of the subdomain cells contains no atoms"); this one stops with a message that names
+  // the remedy.  error->one, not error->all: only the empty rank gets here, the others are already inside the step's exchange.
+  if (list->inum == 0)
+    error->one(FLERR, "e3gnn: this MPI rank owns no atoms; every rank must own at least one "
+                      "(use the `processors` command or `fix balance` so that no sub-domain is empty)");
   if (ghost_mode == 1 && (neighbor->ago == 0 || halo == nullptr)) build_halo_plan();
 
   const int nall = atom->nlocal + atom->nghost;

@@ -10,6 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2   # == SNET_ABI_VERSION of include/snet_hip.h (tests/test_abi_cpu.py keeps the two in step)
 LIB_PATH = os.environ.get('SNET_HIP_LIB') or os.path.join(_HERE, 'libsnet_hip.so')  # env: kernel experiments
 
 c_f32p = C.c_void_p   # device float*
@@ -199,8 +200,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.snet_abi_version() != 1:
-        raise RuntimeError('libsnet_hip.so ABI version mismatch')
+    if lib.snet_abi_version() != ABI_VERSION:
+        raise RuntimeError(f'{LIB_PATH}: ABI version {lib.snet_abi_version()}, this package binds version {ABI_VERSION} '
+                           '(include/snet_hip.h SNET_ABI_VERSION): rebuild with `python -m sevennet_amd.build`')
     _lib = lib
     return lib
 

@@ -102,6 +102,35 @@ def write_d3_blob() -> str:
     return dst
 
 
+def build_lammps_harness(verbose: bool = True) -> str:
+    """tests/lammps_mock/run_pair: the LAMMPS pair styles of lammps/*.cpp compiled by g++ against the runnable single-rank mock of
+    the LAMMPS API (tests/lammps_mock/) and linked to libsnet_hip.so -- test scaffolding (tests/test_lammps_glue_gpu.py runs
+    `pair_coeff -> init_style -> compute` through it on the GPU box; the binary travels in-tree like the library)."""
+    root = os.path.dirname(HERE)
+    mock = os.path.join(root, 'tests', 'lammps_mock')
+    out = os.path.join(mock, 'run_pair')
+    srcs = [os.path.join(mock, 'run_pair.cpp'), os.path.join(mock, 'lmp_mock_runtime.cpp'),
+            os.path.join(root, 'lammps', 'pair_e3gnn_hip.cpp'), os.path.join(root, 'lammps', 'pair_d3_hip.cpp')]
+    deps = srcs + [LIB] + [os.path.join(mock, f) for f in os.listdir(mock) if f.endswith('.h')] + \
+        [os.path.join(root, 'lammps', f) for f in os.listdir(os.path.join(root, 'lammps')) if f.endswith('.h')] + \
+        [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
+        return out
+    gxx = shutil.which('g++')
+    if gxx is None:
+        raise RuntimeError('g++ not found: the LAMMPS mock harness cannot be built')
+    rocm = '/opt/rocm'
+    cmd = [gxx, '-std=c++17', '-O1', '-D__HIP_PLATFORM_AMD__', f'-I{mock}', f'-I{INCLUDE}', f'-I{rocm}/include'] + srcs + \
+        ['-o', out, f'-L{os.path.dirname(LIB)}', '-l:' + os.path.basename(LIB), f'-L{rocm}/lib', '-lamdhip64',
+         '-Wl,-rpath,$ORIGIN/../../sevennet_amd', f'-Wl,-rpath,{rocm}/lib']
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'g++ failed on the LAMMPS mock harness:\n{r.stderr[-4000:]}')
+    if verbose:
+        print(f'[sevennet_amd.build] built {out}', flush=True)
+    return out
+
+
 def build(jobs: int = 0, force: bool = False, extra_configs=(), verbose: bool = True) -> str:
     write_d3_blob()
     os.makedirs(GEN, exist_ok=True)
@@ -138,6 +167,8 @@ def build(jobs: int = 0, force: bool = False, extra_configs=(), verbose: bool = 
             raise RuntimeError(f'link failed:\n{r.stderr[-4000:]}')
     if verbose:
         print(f'[sevennet_amd.build] built {LIB}', flush=True)
+    if not os.environ.get('SNET_BUILD_LIB'):   # (experiment libraries do not rebuild the harness)
+        build_lammps_harness(verbose)
     return LIB
 
 

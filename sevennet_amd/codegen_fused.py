@@ -207,6 +207,46 @@ def _emit_reverse_body(A, pi, p):
     A('}')
 
 
+def _emit_reverse_body_pk(A, pi, p):
+    """The reverse body of `_emit_reverse_body` on PACKED fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32): the lane's 4 channels are two
+    register pairs, the per-edge scalars (V, the Clebsch-Gordan constants) enter as splat operands.  Same products, same
+    accumulation order per channel; only s_ac sums its four channels pairwise ((0 + 2) + (1 + 3)).  Why (round 5,
+    profiles/r05_issue_rate_probe.txt): a wave issues one vector instruction per ~7.5 cycles whatever its kind, so at the two waves per
+    SIMD these kernels run at, the vector pipe is capped by the issue cadence at about half its rate and the kernel's time is its
+    INSTRUCTION COUNT times that cadence -- a packed instruction does two lanes' worth of multiply-adds in the same issue slot
+    (measured: v_pk_fma_f32 7.0 cycles per wave-instruction against 7.5 for v_fma_f32 at one and two waves per SIMD)."""
+    d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
+    A(f'__device__ __forceinline__ void bwdf_p{pi}(const f32x4 (&xr)[{d1}], const float (&ys)[NSH], const f32x4 w,')
+    A(f'    const f32x4 (&G)[{d3}], f32x4 &gw, float (&gy)[NSH], f32x4 (&gx)[{d1}]) {{')
+    A('  const f32x2 wl = lo2(w), wh = hi2(w);')
+    A('  f32x2 gwl = f32x2{0.f, 0.f}, gwh = gwl;')
+    for a, cl in reverse_plan(p):
+        A(f'  {{  // x component {a}')
+        A(f'    const f32x2 xl = lo2(xr[{a}]), xh = hi2(xr[{a}]);')
+        A('    const f32x2 wxl = wl * xl, wxh = wh * xh;')
+        A('    f32x2 Pl, Ph;')
+        for k, (c, bl) in enumerate(cl):
+            tl = [f'{_f(v)} * ys[{p.sh_off + b}]' for b, v in bl]
+            A(f'    {{ const float V = {_sum_expr(tl)};')
+            A('      const f32x2 V2 = f32x2{V, V};')
+            A(f'      const f32x2 Gl = lo2(G[{c}]), Gh = hi2(G[{c}]);')
+            if k == 0:
+                A('      Pl = V2 * Gl; Ph = V2 * Gh;')
+            else:
+                A('      Pl = __builtin_elementwise_fma(V2, Gl, Pl); Ph = __builtin_elementwise_fma(V2, Gh, Ph);')
+            A('      const f32x2 s2 = __builtin_elementwise_fma(wxh, Gh, wxl * Gl);')
+            A('      const float s = s2[0] + s2[1];')
+            for b, v in bl:
+                A(f'      gy[{p.sh_off + b}] = fmaf({_f(v)}, s, gy[{p.sh_off + b}]);')
+            A('    }')
+        A('    gwl = __builtin_elementwise_fma(xl, Pl, gwl); gwh = __builtin_elementwise_fma(xh, Ph, gwh);')
+        A(f'    const f32x2 gl_ = __builtin_elementwise_fma(wl, Pl, lo2(gx[{a}])), gh_ = __builtin_elementwise_fma(wh, Ph, hi2(gx[{a}]));')
+        A(f'    gx[{a}] = f32x4{{gl_[0], gl_[1], gh_[0], gh_[1]}};')
+        A('  }')
+    A('  gw = f32x4{gwl[0], gwl[1], gwh[0], gwh[1]};')
+    A('}')
+
+
 def _emit_reverse_body_v1(A, pi, p, terms, byab):
     """round-2 formulation (SNET_CODEGEN_OPTS=tpold=1, kept for A/B runs): one (a, b) entry at a time,
     U_ab = sum_c C[a,b,c] G_c consumed at once by the three products it feeds (g_w, d/dY_b, d/dx_a)"""
@@ -265,6 +305,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('#include "snet_split.h"')
     A('namespace {')
     A('using namespace snet;')
+    A('__device__ __forceinline__ f32x2 lo2(const f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }')
+    A('__device__ __forceinline__ f32x2 hi2(const f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }')
     # row stride of the forward kernel's spherical-harmonics staging: the four edge groups of a wave read rows 4 apart,
     # which for nsh = 16 (lmax 3) all fall on one LDS bank (measured: 36 % of the kernel's LDS cycles were conflicts)
     NSHP = NSH + 1 if (4 * NSH) % 32 == 0 else NSH
@@ -290,6 +332,15 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     def out_index(p, m3):
         return p.out_off + m3 * p.out_mul + p.out_ch
 
+    # Packed fp32 reverse bodies (round 5, `_emit_reverse_body_pk`): on by default for the shapes that run two waves per SIMD with
+    # register headroom -- the packed-tile class (SevenNet-0 middle layers 5.04 -> 4.92 ms, same box) -- and off elsewhere: the
+    # first layer's 8-wave kernel crosses 128 registers with them (127 -> 132: 1.89 -> 2.29 ms), the lmax-3 shapes at 256 registers
+    # start to spill (0 -> 6, 7 -> 37).  SNET_CODEGEN_OPTS=pk=0 / 1 forces it (profiles/r05_ab_packed_fp32_bodies.txt).
+    _bsp, _ = schedule_bwd(spec)
+    _ngpp = max((sum(2 * p_.l3 + 1 for _, p_ in b_['cat'].paths) * b_['U'] + 15) // 16 * 16 for b_ in _bsp)
+    _livep = 12 * max(2 * c_.l1 + 1 for c_ in cats) + 32 + NSH + 8 * (_ngpp // 16) + 16 + 4 * max(2 * p_.l3 + 1 for p_ in spec.paths) + 35
+    _xt_auto = _livep <= 200 and _livep - 4 * (_ngpp // 16) > 168 and len(cats) > 1
+    PK = bool(int(OPTS['pk'])) if 'pk' in OPTS else ((bool(int(OPTS['xtile'])) if 'xtile' in OPTS else _xt_auto))
     # ------------------------------------------------------------------ per-path device functions
     for pi, p in enumerate(spec.paths):
         d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
@@ -300,7 +351,9 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         byab: Dict[tuple, List[tuple]] = {}
         for a_, b_, cc, v in terms:
             byab.setdefault((a_, b_), []).append((cc, v))
-        if not OPTS.get('tpold'):
+        if PK:
+            _emit_reverse_body_pk(A, pi, p)
+        elif not OPTS.get('tpold'):
             _emit_reverse_body(A, pi, p)
         else:
             _emit_reverse_body_v1(A, pi, p, terms, byab)
@@ -325,6 +378,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('')
 
     # ------------------------------------------------------------------ reverse kernel
+    if OPTS.get('stamp') == tag:
+        A('__device__ unsigned long long snet_stamps[32];')
     A('template <int NT, bool F16, int NWV, bool GLDS, int OCC>')
     A(f'__global__ __launch_bounds__(64 * NWV, OCC) void conv_bwdf_{tag}(const float *__restrict__ x, const float *__restrict__ sh,')
     A('    const float *__restrict__ dsh, const float *__restrict__ h2, const int32_t *__restrict__ w_row,')
@@ -338,6 +393,36 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     # Barrier groups (round 4, SNET_CODEGEN_OPTS=bgrp=<n>): the sub-steps of a block are walked in groups of up to BG; one slab of
     # GLN sub-steps is staged and one workgroup barrier paid per GROUP instead of per sub-step (BG = 1: the round-3 form)
     BG = max(1, int(OPTS.get('bgrp', 1)))
+    # Phase stamps (SNET_CODEGEN_OPTS=stamp=<tag>, kernel-tuning builds only): s_memtime at the phase boundaries of the reverse kernel,
+    # per-phase cycle sums of every wave added to the device array snet_stamps (read back by snet_debug_stamps; tools/microbench.py
+    # --stamps).  Every stamp drains the wave's LDS counter and fences the scheduler, so the instrumented kernel runs ~10 % slower
+    # than the shipped one: the split between phases is what it is for.
+    ST = OPTS.get('stamp') == tag
+    NPH = 16
+    # In-wave software pipeline of the sub-steps (SNET_CODEGEN_OPTS=pipe=<n>; round 5).  The phases of a sub-step -- fragments from
+    # LDS, chained matrix products, the tensor-product body on their result -- are a serial latency chain per wave, and two waves per
+    # SIMD do not cover it (SQ counters: 63 % of the wave cycles parked or issue-stalled with every pipe below 35 %).  pipe >= 1: the w
+    # products of the sub-step's SECOND tile are issued inside the (opaque-branch) region of the FIRST tile's body, so the compiler
+    # interleaves the independent matrix chain with the body's vector instructions.  pipe >= 2: the g_h2 products of the PREVIOUS
+    # sub-step (operand split kept in 8 registers, its slab kept alive by a third LDS buffer) join that region too: 18 of the 24
+    # matrix instructions of a sub-step and their LDS round trips run under the vector work.
+    PIPE = int(OPTS.get('pipe', 0))
+    SGB = int(OPTS.get('sgb', 0))     # pipe + sgb=<n>: sched_group_barrier pattern [1 matrix, <= n vector] over the first body's region
+    F16_DEFAULT = True                # (pattern sized for the f16x3 mode: 3 matrix instructions per product)
+
+    def body_valu(p_):
+        n = 0
+        for a_, cl_ in reverse_plan(p_):
+            n += 4 + 8
+            for c_, bl_ in cl_:
+                n += len(bl_) + 4 + 4 + len(bl_)
+        return n
+    NBUF = 3 if PIPE >= 2 else 2
+    NB = '(buf ^ 1)' if NBUF == 2 else '(buf == 2 ? 0 : buf + 1)'
+
+    def S(i, ind='      '):
+        if ST:
+            A(f'{ind}stamp({i});')
     # Packed tiles (SNET_CODEGEN_OPTS=xtile=1): a tile is a window of <= 16 consecutive CSR edges that may run from one destination
     # node (A) into the next one that has edges (B); snet_edge_tiles_packed writes tile_ptr[t] = first edge, tile_node[2t .. 2t+1] = A, B.
     # The wave keeps BOTH nodes' g_out entries in its LDS buffer and every edge lane reads its own node's set.
@@ -357,9 +442,23 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     if GLN == 1:
         BG = 1
     A(f'  constexpr int LPS = 8 * NT, NTH = 64 * NWV, NST = (LPS * 64 + NTH - 1) / NTH, GLN = {GLN};  // 1-KB fragment lines per sub-step; sub-steps per slab')
-    A('  __shared__ u32x4 slab[2][GLN * LPS * 64];')
+    A(f'  __shared__ u32x4 slab[{NBUF}][GLN * LPS * 64];')
     A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
     A('  const int j = lane & 15, g = lane >> 4;')
+    if ST:
+        A(f'  unsigned ph[{NPH}];')
+        A('#pragma unroll')
+        A(f'  for (int i = 0; i < {NPH}; ++i) ph[i] = 0u;')
+        A('  unsigned t_prev;')
+        A('  { unsigned long long t0_; asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); t_prev = (unsigned)t0_; }')
+        A('  auto stamp = [&](int i) {')
+        A('    __builtin_amdgcn_sched_barrier(0);')
+        A('    unsigned long long t_; asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");')
+        A('    const unsigned tn = (unsigned)t_;')
+        A('    ph[i] += tn - t_prev;')
+        A('    t_prev = tn;')
+        A('    __builtin_amdgcn_sched_barrier(0);')
+        A('  };')
     # Prologue order: every load is requested as soon as its address is known -- the first weight slab at once, the
     # node's g_out entries with the row pointers, the first source rows with h2 -- so the tile pays four dependent
     # memory latencies (tile -> node -> edge -> rows) instead of seven before its first matrix product.
@@ -548,6 +647,12 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    g_unsc = snet::pow2f(-(kg + tail.w2_exp));')
     A('  }')
     A('  int sidx = 0, buf = 0, gbuf = 0;')
+    if PIPE >= 2:
+        A('  const u32x4 *slp = slab[0];   // slab of the previous sub-step (first one: any finite fragments, times a zero operand)')
+        A('  SplitN<NT> bprev;')
+        A('#pragma unroll')
+        A('  for (int tm = 0; tm < NT; ++tm) bprev.t[tm] = as_bf16x8(u32x4{0u, 0u, 0u, 0u});')
+    S(0, '  ')
     for ci, bs in enumerate(bsched):
         cat, U, ncb = bs['cat'], bs['U'], bs['ncb']
         d1 = 2 * cat.l1 + 1
@@ -613,6 +718,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A('    }')
         elif ci + 1 < len(bsched):
             emit_g_loads('    ', ci + 1, '0')
+        S(1, '    ')
         for si_, (ta, tb) in enumerate(bs['steps']):
             A('    {')
             gi_, pos_ = si_ // BG, si_ % BG       # barrier group of this sub-step and its place inside it
@@ -620,10 +726,11 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 if pos_ == 0 and gi_ > 0:         # (group 0: requested at the block top)
                     A(f'      stage_load(sidx + {len(groups[gi_])}, ' + ('(diag & 32) ? 0 : ' if exp else '') + f'{next_group_size(gi_)}, buf ^ 1);')
             elif not (HOIST and si_ == 0):   # (first sub-step of a block: requested at the end of the previous block / the prologue)
-                A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, buf ^ 1);')
+                A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + f') stage_load(sidx + 1, {NB});')
             # hipcc's machine scheduler, left alone, sinks the prefetch loads next to their use (zero overlap) and
             # interleaves the phases until ~200 VGPRs spill: pin the prefetch at the top and fence the phases
             A('      __builtin_amdgcn_sched_barrier(0);')
+            S(2)
             A('      const u32x4 *sl = slab[buf]' + (f' + {pos_} * (LPS * 64);' if BG > 1 else ';'))
             A('      f32x4 gw0 = f32x4{0.f, 0.f, 0.f, 0.f}, gw1 = gw0;')
             # kernel-tuning knobs, both measured neutral on MI355X (SevenNet-0 middle layer): wfirst = both tiles' weight
@@ -651,7 +758,60 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A('        for (int tm = 0; tm < NT; ++tm) ag[m][tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
             if wfirst or gpf:
                 A('      __builtin_amdgcn_sched_barrier(0);')
-            for tp, tl_ in enumerate((ta, tb)):
+            def w_chain(ind, tp, dst):
+                A('#pragma unroll')
+                A(f'{ind}for (int q = 0; q < 2; ++q) {{')
+                A(f'{ind}  bf16x8 a[NT];')
+                A('#pragma unroll')
+                A(f'{ind}  for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
+                A(f'{ind}  {dst} = mfma16_split<NT, F16>(a, hb[q], {dst});')
+                A(f'{ind}}}')
+
+            def g_products(ind, slab_, b_):
+                A('#pragma unroll')
+                A(f'{ind}for (int m = 0; m < 4; ++m) {{')
+                A(f'{ind}  bf16x8 a[NT];')
+                A('#pragma unroll')
+                A(f'{ind}  for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8({slab_}[(4 * NT + m * NT + tm) * 64 + lane]);')
+                A(f'{ind}  ga[m] = mfma16_split<NT, F16>(a, {b_}, ga[m]);')
+                A(f'{ind}}}')
+            if PIPE:
+                A('      f32x4 wv0 = f32x4{0.f, 0.f, 0.f, 0.f}, wv1 = wv0;')
+                w_chain('      ', 0, 'wv0')
+                A('      if constexpr (F16) wv0 *= w_unscale;')
+                for tp, tl_ in enumerate((ta, tb)):
+                    if tl_ is None:
+                        continue
+                    pi, u = tl_
+                    p = spec.paths[pi]
+                    d3 = 2 * p.l3 + 1
+                    A(f'      {{  // tile {tp}: path {pi}, channel tile {U} cb + {u}')
+                    A(f'        f32x4 G[{d3}];')
+                    for m3 in range(d3):
+                        A(f'        G[{m3}] = *reinterpret_cast<const f32x4 *>(gl_ + {g_row(ci, pi, m3, u)} * 16);')
+                    A('        float ys[NSH];')
+                    for b_ in range(2 * p.l2 + 1):
+                        A(f'        ys[{p.sh_off + b_}] = yl[{(p.sh_off + b_) * 16}];')
+                    A('        if (!(diag & 1)) {')
+                    if tp == 0:   # independent matrix chains join the first body's region
+                        if PIPE >= 2:
+                            g_products('          ', 'slp', 'bprev')
+                        if tb is not None:
+                            w_chain('          ', 1, 'wv1')
+                    A(f'          bwdf_p{pi}(xr[{u}], ys, wv{tp}, G, gw{tp}, gy, gx[{u}]);')
+                    if tp == 0 and SGB:
+                        # prescribe the interleave: one matrix instruction, then the vector instructions that fit its shadow
+                        n_m = (3 if F16_DEFAULT else 6) * ((4 if PIPE >= 2 else 0) + (2 if tb is not None else 0))
+                        n_v = body_valu(p)
+                        per = max(1, min(SGB, n_v // max(n_m, 1)))
+                        for _ in range(n_m):
+                            A('          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);')
+                            A(f'          __builtin_amdgcn_sched_group_barrier(0x002, {per}, 0);')
+                    A('        }')
+                    if tp == 0 and tb is not None:
+                        A('        if constexpr (F16) wv1 *= w_unscale;')
+                    A('      }')
+            for tp, tl_ in enumerate(() if PIPE else (ta, tb)):
                 if tl_ is None:
                     continue
                 pi, u = tl_
@@ -672,6 +832,9 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                     A('          wv = mfma16_split<NT, F16>(a, hb[q], wv);')
                     A('        }')
                     A('        if constexpr (F16) wv *= w_unscale;')
+                    if ST:
+                        A('        asm volatile("" :: "v"(wv[0]), "v"(wv[3]));')
+                    S(3 + 2 * tp, '        ')
                 A(f'        f32x4 G[{d3}];')
                 for m3 in range(d3):
                     A(f'        G[{m3}] = *reinterpret_cast<const f32x4 *>(gl_ + {g_row(ci, pi, m3, u)} * 16);')
@@ -682,7 +845,15 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 # straight-line code hipcc's scheduler interleaves it with the surrounding matrix products and
                 # loads until ~200 VGPRs spill to scratch (measured: 692 spilled registers without the branch, 0 with)
                 A(f'        gw{tp} = f32x4{{0.f, 0.f, 0.f, 0.f}};')
-                A(f'        if (!(diag & 1)) bwdf_p{pi}(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
+                if OPTS.get('nobr'):   # kernel-tuning: the body fenced by scheduler barriers instead of the opaque branch
+                    A('        __builtin_amdgcn_sched_barrier(0);')
+                    A(f'        bwdf_p{pi}(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
+                    A('        __builtin_amdgcn_sched_barrier(0);')
+                else:
+                    A(f'        if (!(diag & 1)) bwdf_p{pi}(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
+                if ST:
+                    A(f'        asm volatile("" :: "v"(gw{tp}[0]), "v"(gw{tp}[3]));')
+                S(4 + 2 * tp, '        ')
                 A('      }')
             A('      float v[8] = {gw0[0], gw0[1], gw0[2], gw0[3], gw1[0], gw1[1], gw1[2], gw1[3]};')
             A('      if constexpr (F16) {')
@@ -690,10 +861,13 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A('        for (int i = 0; i < 8; ++i) v[i] *= g_sc;')
             A('      }')
             A('      const SplitN<NT> b = splitn8<NT, F16>(v);')
+            if PIPE >= 2:
+                A('      bprev = b;')
+                A('      slp = sl;')
             if exp:
                 A('      if (diag & 2) ga[0] += f32x4{v[0], v[1], v[4], v[5]}; else')
             A('#pragma unroll')
-            A('      for (int m = 0; m < 4; ++m) {')
+            A('      for (int m = 0; m < ' + ('0' if PIPE >= 2 else '4') + '; ++m) {')
             if gpf:
                 A('        ga[m] = mfma16_split<NT, F16>(ag[m], b, ga[m]);')
             else:
@@ -708,13 +882,18 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                     A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
                     A('      buf ^= 1;')
             else:
-                A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_store(buf ^ 1);')
+                if ST:
+                    A('      asm volatile("" :: "v"(ga[0][0]), "v"(ga[1][0]), "v"(ga[2][0]), "v"(ga[3][0]));')
+                S(7)
+                A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + f') stage_store({NB});')
+                S(8)
                 A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
-                A('      buf ^= 1;')
+                S(9)
+                A(f'      buf = {NB};')
             A('      ++sidx;')
             A('    }')
         if HOIST:   # the next block's first sub-step: its slab request goes out BEFORE this block's stores
-            A('    if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, buf ^ 1);')
+            A('    if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + f') stage_load(sidx + 1, {NB});')
             A('    __builtin_amdgcn_sched_barrier(0);')
         A('    if (g_xe && valid' + (' && !(diag & 16)' if exp else '') + ') {')
         for u in range(U):
@@ -750,7 +929,13 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A(f'    for (int u = 0; u < {U}; ++u)')
             A('#pragma unroll')
             A(f'      for (int m = 0; m < {d1}; ++m) xr{ci}[u][m] = xn{ci}[u][m];')
+        S(10, '    ')
         A('  }')
+    if PIPE >= 2:
+        A('  {  // the last sub-step\'s g_h2 products')
+        g_products('    ', 'slp', 'bprev')
+        A('  }')
+        A('  __syncthreads();   // (the tail reuses the slab buffers)')
     if dead_x:
         A('  if (g_xe && valid) {  // x blocks that feed no path get a zero gradient')
         for i in dead_x:
@@ -829,6 +1014,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    if constexpr (F16) k_e = scale8(ev);')
     A('    const SplitN<NT> eb = splitn8<NT, F16>(ev);')
     A('    __syncthreads();')
+    S(11, '    ')
     A('    f32x4 z1[4], z2[4];')
     A('#pragma unroll')
     A('    for (int m = 0; m < 4; ++m) {')
@@ -915,6 +1101,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('      f32x4 *o = reinterpret_cast<f32x4 *>(tail.g_emb + (size_t)e * nb + 4 * g);')
     A('      *o = *o + ge;')
     A('    }')
+    S(12, '    ')
     A('  }')
     A('  // d/d(edge_vec) = sum_i gy_i dY_i/dr (Y_0 is constant).  The 4 channel groups of an edge (lanes j, j+16, j+32,')
     A('  // j+48) are summed with two permlane swaps per value; only the g == 0 lanes then touch dsh and g_vec.')
@@ -935,6 +1122,12 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    float *o = g_vec + (size_t)e * 3;')
     A('    o[0] += t0; o[1] += t1; o[2] += t2;')
     A('  }')
+    if ST:
+        S(13, '  ')
+        A('  if (lane == 0 && live) {')
+        A(f'    for (int i = 0; i < {NPH}; ++i) atomicAdd(&snet_stamps[i], (unsigned long long)ph[i]);')
+        A('    atomicAdd(&snet_stamps[31], 1ull);')
+        A('  }')
     A('}')
     A('')
 
@@ -1243,7 +1436,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
             A(f'  if (nt == 4 && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
     def bwd_lds(nt, nwv):
-        return 2 * GLN * 8 * nt * 1024 + nwv * (2 * NGP * 64 + (128 if XT else 0) + NSH * 64)
+        return NBUF * GLN * 8 * nt * 1024 + nwv * (2 * NGP * 64 + (128 if XT else 0) + NSH * 64)
 
     def bwd_cfg(nt):
         # measured on MI355X (SevenNet-0 middle layer): three 4-wave workgroups per CU (LDS <= 53 KB each, <= 168
@@ -1325,4 +1518,10 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A(f'const snet::FusedKernels kernels = {{"{tag}", DX, DOUT, NSH, WN, NS, SUB_COLS, {len(cols_rev)}, SUB_COLS_B, GXE_CHUNK, launch_bwd, launch_fwd, {1 if XT else 0}}};')
     A('const snet::FusedRegistrar registrar(&kernels);')
     A('}  // namespace')
+    if OPTS.get('stamp') == tag:
+        A('extern "C" int snet_debug_stamps(unsigned long long *out, int reset) {')
+        A('  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(snet_stamps), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;')
+        A('  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(snet_stamps), z, sizeof(z)) != hipSuccess) return 1; }')
+        A('  return 0;')
+        A('}')
     return '\n'.join(L) + '\n'

@@ -89,7 +89,10 @@ struct PairD3 {  // the reference's opaque handle type name
   std::vector<double> x;
   double cell[9] = {0};
   int pbc[3] = {1, 1, 1};
-  bool have_domain = false, have_settings = false, failed = false;
+  bool have_domain = false, have_settings = false, failed = false, tables_set = false;
+  // last arguments of pair_run_settings: the reference's callers repeat the call every step with the same values
+  double set_rthr = 0.0, set_cnthr = 0.0;
+  std::string set_damp, set_func;
   double result_E = 0.0;
   std::vector<double> result_F;
   double result_S[6] = {0, 0, 0, 0, 0, 0};
@@ -97,8 +100,9 @@ struct PairD3 {  // the reference's opaque handle type name
 
 namespace {
 void fail(PairD3 *p, const std::string &what) {
-  // the reference's functions return void and abort on CUDA errors; here a failure is sticky, printed once, and readable
-  // through snet_last_error(); results stay zero
+  // the reference's functions return void and abort on CUDA errors; here a failure is sticky, printed once, readable through
+  // snet_last_error() / pair_failed(), and the getters stop handing out results: pair_get_force / pair_get_stress return NULL
+  // and pair_get_energy NaN while it is set, so no caller can keep running on zero dispersion
   if (p) p->failed = true;
   snet::set_error(what);
   fprintf(stderr, "%s\n", what.c_str());
@@ -140,6 +144,8 @@ void pair_run_settings(PairD3 *pair, double rthr, double cnthr, const char *damp
   const D3Params &P = params();
   if (!P.ok) return fail(pair, P.error);
   if (!damp_name || !func_name) return fail(pair, "pair_run_settings: null name");
+  if (pair->have_settings && rthr == pair->set_rthr && cnthr == pair->set_cnthr && pair->set_damp == damp_name && pair->set_func == func_name)
+    return;   // unchanged since the last call
   int damping = -1;
   if (strcmp(damp_name, "damp_zero") == 0) damping = 0;
   else if (strcmp(damp_name, "damp_bj") == 0) damping = 1;
@@ -149,6 +155,7 @@ void pair_run_settings(PairD3 *pair, double rthr, double cnthr, const char *damp
   if (it == P.func[damping].end()) return fail(pair, std::string("pair_run_settings: functional name unknown: ") + func_name);
   if (snet_d3_settings(pair->h, rthr, cnthr, damping, it->second.data())) return fail(pair, snet_last_error());
   pair->have_settings = true;
+  pair->set_rthr = rthr; pair->set_cnthr = cnthr; pair->set_damp = damp_name; pair->set_func = func_name;
 }
 
 void pair_run_coeff(PairD3 *pair, int *atomic_numbers) {
@@ -162,8 +169,12 @@ void pair_run_coeff(PairD3 *pair, int *atomic_numbers) {
     if (t < 1 || t > pair->ntypes) return fail(pair, "pair_run_coeff: atom type out of range (types are 1-based)");
     z[i] = atomic_numbers[t - 1];
   }
-  if (snet_d3_set_tables(pair->h, P.r0ab.data(), P.c6ab.data(), P.n_c6, P.r2r4.data(), P.rcov.data()) ||
-      snet_d3_set_atoms(pair->h, pair->natoms, z.data(), pair->x.data()) || snet_d3_set_cell(pair->h, pair->cell, pair->pbc))
+  // the parameter tables go to the device once per handle, not once per step
+  if (!pair->tables_set) {
+    if (snet_d3_set_tables(pair->h, P.r0ab.data(), P.c6ab.data(), P.n_c6, P.r2r4.data(), P.rcov.data())) return fail(pair, snet_last_error());
+    pair->tables_set = true;
+  }
+  if (snet_d3_set_atoms(pair->h, pair->natoms, z.data(), pair->x.data()) || snet_d3_set_cell(pair->h, pair->cell, pair->pbc))
     return fail(pair, snet_last_error());
 }
 
@@ -183,11 +194,14 @@ void pair_run_compute(PairD3 *pair) {
   pair->result_S[3] = -v * s[1]; pair->result_S[4] = -v * s[2]; pair->result_S[5] = -v * s[5];
 }
 
-double pair_get_energy(PairD3 *pair) { return pair ? pair->result_E : 0.0; }
+double pair_get_energy(PairD3 *pair) { return (pair && !pair->failed) ? pair->result_E : __builtin_nan(""); }
 
-double *pair_get_force(PairD3 *pair) { return (pair && !pair->result_F.empty()) ? pair->result_F.data() : nullptr; }
+double *pair_get_force(PairD3 *pair) { return (pair && !pair->failed && !pair->result_F.empty()) ? pair->result_F.data() : nullptr; }
 
-double *pair_get_stress(PairD3 *pair) { return pair ? pair->result_S : nullptr; }
+double *pair_get_stress(PairD3 *pair) { return (pair && !pair->failed) ? pair->result_S : nullptr; }
+
+// extension (not in the reference's ABI): 1 once any call on this handle has failed; the message is snet_last_error()
+int pair_failed(PairD3 *pair) { return (!pair || pair->failed) ? 1 : 0; }
 
 void pair_fin(PairD3 *pair) {
   if (!pair) return;

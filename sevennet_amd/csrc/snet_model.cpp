@@ -260,6 +260,8 @@ struct snet_model {
   int32_t *c_tile_ptr_b = nullptr;   // tile pointers re-based on the boundary rows' sub-list
   size_t c_tile_ptr_b_cap = 0;
   int64_t c_tile_k = 0;              // first tile of the first boundary row
+  bool c_split_valid = false;        // c_tile_ptr_b / c_tile_k hold the cached graph's boundary sub-list (built only by an
+                                     // evaluation that ran split: a cache hit of an un-split evaluation must not trust them)
   // packed tiles (snet_edge_tiles_packed): one list, the interior rows' tiles [0, k) in front of the boundary rows'
   int32_t *c_ptile_e0 = nullptr, *c_ptile_nodes = nullptr;
   size_t c_ptile_cap = 0;
@@ -551,6 +553,8 @@ extern "C" int snet_model_set_halo(snet_model *m, snet_halo_fn forward, snet_hal
   m->halo_rev = reverse;
   m->halo_user = user;
   m->fold_forces = fold_forces != 0;
+  m->topo_valid = false;   // the split lists of a cached graph depend on whether (and which) halo is installed
+  m->c_split_valid = false;
   return 0;
 }
 
@@ -813,10 +817,11 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
       if (m->c_tile_ptr_b) (void)hipFree(m->c_tile_ptr_b);
       m->c_tile_ptr_b = nullptr;
       m->c_tile_ptr_b_cap = (size_t)N + 64;
+      m->c_split_valid = false;
       SNET_REQUIRE(hipMalloc((void **)&m->c_tile_ptr_b, m->c_tile_ptr_b_cap * 4) == hipSuccess, "snet_model_eval: alloc");
     }
     tile_ptr_b = m->c_tile_ptr_b;
-    if (topo_hit) {
+    if (topo_hit && m->c_split_valid) {
       tile_k = m->c_tile_k;
     } else {
       int32_t k32 = 0;
@@ -825,8 +830,10 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
       ++m->eval_syncs;
       tile_k = m->c_tile_k = k32;
       if ((rc = snet_i32_shift(tile_ptr, -k32, tile_ptr_b, N + 1, st))) return rc;
+      m->c_split_valid = true;
     }
   }
+  if (!topo_hit && !(hsplit && need_tiles[0])) m->c_split_valid = false;   // a new graph was tiled without its boundary sub-list
   if (m->topo_cache) {
     m->topo_key = key;
     m->topo_valid = true;

@@ -29,7 +29,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f'{n} declared in snet_hip.h but not exported'
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature'
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.snet_abi_version() == 1
+    assert lib.snet_abi_version() == _lib.ABI_VERSION
+    hdr = open(os.path.join(ROOT, 'include', 'snet_hip.h')).read()
+    assert int(re.search(r'#define SNET_ABI_VERSION (\d+)', hdr).group(1)) == _lib.ABI_VERSION   # header, library, binding in step
 
 
 def test_library_exports_the_reference_d3_binding():
@@ -40,7 +42,8 @@ def test_library_exports_the_reference_d3_binding():
         text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
     names = sorted(set(re.findall(r'\b(pair_[a-z_]+)\s*\(', text)))
     assert names == sorted(['pair_init', 'pair_set_atom', 'pair_set_domain', 'pair_run_settings', 'pair_run_coeff',
-                            'pair_run_compute', 'pair_get_energy', 'pair_get_force', 'pair_get_stress', 'pair_fin'])
+                            'pair_run_compute', 'pair_get_energy', 'pair_get_force', 'pair_get_stress', 'pair_fin',
+                            'pair_failed'])   # (pair_failed: the one extension, reads the sticky failure flag)
     lib = C.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
@@ -57,9 +60,20 @@ def test_library_exports_the_reference_d3_binding():
     lib.pair_get_energy.restype = C.c_double
     lib.pair_get_energy.argtypes = [C.c_void_p]
     lib.pair_fin.argtypes = [C.c_void_p]
+    lib.pair_get_force.restype = C.c_void_p
+    lib.pair_get_force.argtypes = [C.c_void_p]
+    lib.pair_get_stress.restype = C.c_void_p
+    lib.pair_get_stress.argtypes = [C.c_void_p]
+    lib.pair_failed.argtypes = [C.c_void_p]
     p = lib.pair_init()
     assert p
-    assert lib.pair_get_energy(p) == 0.0
+    # a failed handle never hands out results a caller could mistake for "zero dispersion" (ADVICE r4): NaN energy, NULL arrays
+    if lib.pair_failed(p):
+        assert np.isnan(lib.pair_get_energy(p)) and lib.pair_get_force(p) is None and lib.pair_get_stress(p) is None
+    else:   # (a GPU is present: an unknown functional name is the failure that must stick)
+        lib.pair_run_settings.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_char_p, C.c_char_p]
+        lib.pair_run_settings(p, 9000.0, 1600.0, b'damp_bj', b'no-such-functional')
+        assert lib.pair_failed(p) and np.isnan(lib.pair_get_energy(p)) and lib.pair_get_stress(p) is None
     lib.pair_fin(p)
 
 

@@ -31,6 +31,8 @@ def main():
     ap.add_argument('--fv', default='', help='kernel-tuning builds (SNET_CODEGEN_OPTS=fexp=<tag>): semicolon-separated '
                     '"nwv,glds,occ[,diag]" variants of the fused kernels to time, e.g. "4,0,2;4,1,2;4,1,1;4,1,2,1"')
     ap.add_argument('--only', default='', help='substring filter on kernel names')
+    ap.add_argument('--stamps', action='store_true', help='stamp builds (SNET_CODEGEN_OPTS=stamp=<tag>): print the per-phase '
+                    'cycle sums the instrumented reverse kernel collected (snet_debug_stamps)')
     ap.add_argument('--order', default='raster', choices=['raster', 'morton', 'random'], help='atom order of the test cell')
     a = ap.parse_args()
     from bench import kernel_model, model_config
@@ -127,6 +129,7 @@ def main():
         'radial_mlp_hidden_fwd': lambda: lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb), E, _ptr(h2), st),
         f'conv_fwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_fwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(m), st),
         f'conv_bwd_fused[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), _ptr(g_xe), _ptr(g_h2), None, None, _ptr(g_vec), _ptr(x_max), _ptr(g_max), st),
+        f'conv_bwd_fused_tail[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), _ptr(g_xe), None, _ptr(emb), _ptr(g_emb), _ptr(g_vec), _ptr(x_max), _ptr(g_max), st),
         f'conv_bwd_fused_no_gxe[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(g.w_row), _ptr(g.row_ptr), _ptr(g.src), _ptr(tile_ptr), _ptr(tile_node), n_tiles, L.scale, _ptr(g_m), None, _ptr(g_h2), None, None, _ptr(g_vec), _ptr(x_max), _ptr(g_max), st),
         'radial_mlp_hidden_bwd': lambda: lib.snet_radial_mlp_hidden_bwd(L.mlp_plan, _ptr(emb), _ptr(g_h2), E, _ptr(g_emb), st),
         f'radial_mlp_fwd[wn={wn}]': lambda: eng._mlp_fwd(L, emb, E),
@@ -173,6 +176,9 @@ def main():
             os.environ['SNET_FV_DIAG'] = parts[3] if len(parts) > 3 else '0'
         fn()
         torch.cuda.synchronize()
+        stamps = a.stamps and 'conv_bwd_fused' in name and hasattr(lib, 'snet_debug_stamps')
+        if stamps:
+            lib.snet_debug_stamps(None, 1)
         ts = []
         for _ in range(a.iters):
             s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -188,6 +194,18 @@ def main():
             extra = (f"{k['bytes'] / ms / 1e6:8.1f} GB/s (algorithmic)" if k['bound'] == 'hbm'
                      else f"{k['flops'] / ms / 1e9:8.2f} TFLOP/s")
         print(f'{name:34s} {ms:8.3f} ms  {extra}')
+        if stamps:
+            buf = (C.c_ulonglong * 32)()
+            lib.snet_debug_stamps(buf, 1)
+            v = np.array(list(buf), np.float64)
+            waves = max(v[31], 1.0)
+            tot = v[:16].sum()
+            names = ['prologue', 'block top', 'sub-step top (slab request)', 'tile 0: w products', 'tile 0: tensor product',
+                     'tile 1: w products', 'tile 1: tensor product', 'split + g_h2 products', 'slab park (vmcnt + ds_write)',
+                     'workgroup barrier', 'block end (stores, park, rows)', 'tail A', 'tail B', 'dY epilogue', '-', '-']
+            print(f'    stamps: {int(waves)} wave-launches, {tot / waves:9.0f} cycles per wave')
+            for i in range(14):
+                print(f'    phase {i:2d} {names[i]:34s} {v[i] / waves:9.0f} cycles per wave  {100 * v[i] / tot:5.1f} %')
 
 
 if __name__ == '__main__':
