@@ -38,6 +38,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak
 MFMA_F32_PEAK_TF = 157.3   # dense fp32-input MFMA peak
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (the split-precision products run there)
+# fp32 vector peak: 256 CUs x 4 SIMD-32 x (64 lanes / 2 cycles) x 2 flop x 2.4 GHz (MI355X_MICROARCH.md: a wave64 VALU instruction
+# issues over 2 cycles).  Round 4 priced the vector pipe at 4 cycles per instruction (78.6 TF): corrected.
+# What a kernel can reach depends on its occupancy: ONE wave issues a vector instruction every ~7.5 cycles whatever its kind, so the
+# pipe needs four waves per SIMD for its rate; measured with s_memtime inside the kernel (tools/gpu/issue_probe,
+# profiles/r05_issue_rate_probe.txt): 2.5 cycles per SIMD-instruction at 4 waves per SIMD (with the clock down at 1.6 GHz: 103 TF),
+# 4.0 at the two waves per SIMD the fused reverse kernels run at, 7.5 at one.
+VALU_F32_PEAK_TF = 157.3
+VALU_F32_MEASURED_TF = {4: 103.0, 2: 66.0, 1: 39.0}   # waves per SIMD -> v_fma_f32 TFLOP/s of the whole chip (issue probe, round 5)
 # algorithmic work per atom-step of the named shapes (bytes, flops), fwd + reverse
 STEP_WORK = {'sevennet_0': (0.992e6, 44.5e6), 'sevennet_l3i5': (1.584e6, 119e6), 'sevennet_mf_ompa': (3.225e6, 305e6)}
 
@@ -170,6 +178,19 @@ def scheduled_work(eng, graph):
     return dict(mfma=mfma, valu=valu)
 
 
+def fused_source_hashes():
+    """sha1 (12 hex digits) of the generated source of every ahead-of-time fused tensor-product kernel: what a PMC profile is stamped
+    with (tools/collect_profiles.sh) and what `roofline.traffic` is checked against"""
+    import hashlib
+    from sevennet_amd import codegen_fused
+    from sevennet_amd.shapes import aot_conv_specs
+    out = {}
+    for tag, spec in aot_conv_specs(()).items():
+        if codegen_fused.fusable(spec):
+            out[tag] = hashlib.sha1(codegen_fused.gen_conv_fused(spec).encode()).hexdigest()[:12]
+    return out
+
+
 def cpu_model_name():
     try:
         with open('/proc/cpuinfo') as f:
@@ -300,27 +321,62 @@ def main():
         graph = build_graph(bg.types, bg.edge_index, bg.edge_vec, n_local=bg.n_local, n_interior=bg.n_interior, device=dev,
                             num_species=eng.spec.num_species)
         use_native = a.halo == 'native' or (a.halo == 'auto' and backend == 'nccl')
+        rccl_info = None
         if use_native:
             from sevennet_amd.parallel import NativeHalo, RcclComm
-            ok = 1
-            try:
-                rccl_comm = RcclComm(world, rank)
-                halo = NativeHalo(rccl_comm, bg.send_lists, bg.recv_counts, overlap=not a.no_halo_overlap)
-            except Exception as exc:   # the library's own communicator could not be made on this rank: say so, decide together
-                print(f'[bench rank {rank}] native RCCL halo unavailable ({exc}); asking for the torch.distributed exchange', file=sys.stderr)
-                ok = 0
-            if a.halo == 'auto' and world > 1:   # every rank must use the same transport
+            # Agree on the transport BEFORE the collective communicator construction: RcclComm() broadcasts the unique
+            # id and runs ncclCommInitRank -- a rank that failed alone in there would leave the others blocked inside it.  The
+            # local probe (library loads, every symbol binds) is what can differ between ranks; it is reduced first.
+            ok = 1 if RcclComm.available() else 0
+            if world > 1:
                 flag = torch.tensor([ok], device=dev, dtype=torch.int32)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 0:
-                    use_native, halo = False, None
-            elif not ok:
-                raise SystemExit('--halo native: the RCCL communicator of libsnet_hip.so could not be created')
+                ok = int(flag.item())
+            if not ok:
+                if a.halo == 'native':
+                    raise SystemExit('--halo native: librccl.so cannot be bound by libsnet_hip.so on every rank')
+                if rank == 0:
+                    print('[bench] native RCCL halo unavailable on some rank; every rank uses the torch.distributed exchange', file=sys.stderr)
+                use_native = False
+            else:
+                rccl_comm = RcclComm(world, rank)   # collective; a failure past the probe is fatal on every rank alike
+                rccl_info = rccl_comm.info()
+                if rccl_info != (world, rank):
+                    raise SystemExit(f'[bench rank {rank}] RCCL reports communicator {rccl_info}, expected ({world}, {rank})')
+                halo = NativeHalo(rccl_comm, bg.send_lists, bg.recv_counts, overlap=not a.no_halo_overlap)
         if not use_native:
             halo = HaloExchange(bg.send_lists, bg.recv_counts, dev)
         ne = torch.tensor([graph.n_edges], device=dev, dtype=torch.int64)
         dist.all_reduce(ne)
         n_edges_total = int(ne.item())
+        # start-up self-check of the decomposition, so that a first real multi-GPU run is diagnosable from its
+        # JSON line alone: owned atoms partition the cell; what every rank expects to RECEIVE from a peer is what that peer will
+        # SEND to it (the two count matrices are transposes); ghost rows = rows received
+        sc = torch.zeros(world, world, device=dev, dtype=torch.int64)
+        rc_ = torch.zeros(world, world, device=dev, dtype=torch.int64)
+        sc[rank] = torch.tensor([len(s_) for s_ in bg.send_lists], device=dev, dtype=torch.int64)
+        rc_[rank] = torch.tensor([int(c) for c in bg.recv_counts], device=dev, dtype=torch.int64)
+        own = torch.tensor([graph.n_local, graph.n_total - graph.n_local, getattr(bg, 'n_interior', 0) or 0], device=dev, dtype=torch.int64)
+        owns = torch.zeros(world, 3, device=dev, dtype=torch.int64)
+        owns[rank] = own
+        for t_ in (sc, rc_, owns):
+            dist.all_reduce(t_)
+        sc, rc_, owns = sc.cpu().numpy(), rc_.cpu().numpy(), owns.cpu().numpy()
+        problems = []
+        if int(owns[:, 0].sum()) != n_atoms:
+            problems.append(f'owned atoms sum to {int(owns[:, 0].sum())}, cell has {n_atoms}')
+        if not (sc.T == rc_).all():
+            problems.append('send / receive count matrices are not transposes of each other')
+        if not (rc_.sum(1) == owns[:, 1]).all():
+            problems.append('ghost rows differ from the rows received')
+        if np.diag(sc).any():
+            problems.append('a rank sends to itself')
+        if problems:
+            raise SystemExit(f'[bench rank {rank}] decomposition self-check failed: ' + '; '.join(problems))
+        selfcheck = dict(ok=True, owned_atoms_by_rank=owns[:, 0].tolist(), ghost_rows_by_rank=owns[:, 1].tolist(),
+                         interior_atoms_by_rank=owns[:, 2].tolist(), send_rows_by_rank=sc.sum(1).tolist(),
+                         peers_by_rank=(sc > 0).sum(1).tolist(),
+                         rccl_comm=(None if rccl_info is None else dict(nranks=rccl_info[0], rank0_user_rank=rccl_info[1])))
     t_graph = time.perf_counter() - t0
 
     nat = None
@@ -388,12 +444,22 @@ def main():
         models0.update(kernel_model(ls, graph.n_local, graph.n_edges, getattr(L, 'mlp_tail', False), eng.spec.n_basis))
     dominant0 = max((k for k in probe if k in models0), key=lambda k: probe[k])
     eng.events, eng.event_filter = [], {dominant0}
+    # per-step durations for the MEDIAN ("median of >= 20 steps"): one HIP event between consecutive steps on the
+    # compute stream (K + 1 records per K steps), read after the closing fence
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         out = step()
+        marks[i + 1].record()
     t_enq = time.perf_counter() - t0  # host time to enqueue K steps (kernels run asynchronously)
     fence()
     dt = time.perf_counter() - t0
+    per_step = torch.tensor([marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)], device=dev, dtype=torch.float64)
+    if dist_mode:   # a step is over when the slowest rank is
+        dist.all_reduce(per_step, op=dist.ReduceOp.MAX)
+    per_step = per_step.cpu().numpy()
+    step_ms_median = float(np.median(per_step))
     if dist_mode:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -455,6 +521,16 @@ def main():
             roof['traffic'] = sum(v['hbm_bytes_per_launch'] for v in parts)
             roof['traffic_frac_of_peak'] = roof['traffic'] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             roof['traffic_source'] = os.path.basename(pmc) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)'
+            # the counters belong to the kernel SOURCE they were collected on: tools/collect_profiles.sh stamps the profile with
+            # the sha1 of every generated fused kernel; a kernel edited since then ships its figure marked stale, not silently
+            tag_ = dominant.split('[')[-1].rstrip(']')
+            now = fused_source_hashes().get(tag_)
+            then = (tr.get('__kernel_sources__') or {}).get(tag_)
+            roof['traffic_kernel_sha1'] = then
+            roof['traffic_stale'] = (then is None) or (now != then)
+            if roof['traffic_stale']:
+                roof['traffic_note'] = (f'PMC pass predates the current kernel source (profile: {then or "unstamped"}, tree: {now}); '
+                                        're-run tools/collect_profiles.sh')
     except Exception:  # noqa: BLE001
         pass
     if any(k.endswith('@side') for k in totals):
@@ -475,11 +551,12 @@ def main():
         sb, sf = (v * n_atoms for v in STEP_WORK[a.model])
         t = dt / a.steps * world   # GPU-seconds per step
         sched = scheduled_work(eng, graph)
-        valu_peak = 256 * 64 * 2 * 2.4e9   # 256 CUs x 64 fp32 lanes x FMA x 2.4 GHz (non-packed): 78.6 TFLOP/s
+        valu_peak = VALU_F32_PEAK_TF * 1e12
         roof['step'] = dict(bytes=sb, frac_hbm=sb / t / (HBM_PEAK_GBS * 1e9), floor_ms_hbm=sb / (HBM_PEAK_GBS * 1e9) * 1e3,
                             mfma_flops_issued=sched['mfma'], valu_flops=sched['valu'],
                             frac_mfma_issued=sched['mfma'] * world / t / (MFMA_BF16_PEAK_TF * 1e12),
                             frac_valu=sched['valu'] * world / t / valu_peak,
+                            valu_peak_tflops=VALU_F32_PEAK_TF, valu_measured_tflops_by_waves_per_simd=VALU_F32_MEASURED_TF,
                             flops_survey_dense_fp32=sf,
                             note='bytes: SURVEY.md 8(d) per atom-step (fwd + reverse, no cache credit, radial weights not '
                                  'materialised) over 8 TB/s.  mfma_flops_issued: every 16x16x32 / 32x32x16 product the kernels issue '
@@ -487,8 +564,11 @@ def main():
                                  '2.5 PFLOP/s dense f16 / bf16 peak.  valu_flops: the sparse tensor-product arithmetic as generated '
                                  '(forward: nnz(C) FMAs + pair products per channel; reverse: Clebsch-Gordan tensor contracted with the '
                                  'harmonics per edge, two FMAs per nonzero (a, c) pair and three per x component per channel) over '
-                                 '78.6 TFLOP/s (256 CUs x 64 lanes x FMA x 2.4 GHz).  flops_survey_dense_fp32 = SURVEY.md 8(d)\'s '
-                                 'dense-CG count, for reference only.')
+                                 'the 157.3 TFLOP/s fp32 vector peak (SIMD-32: a wave64 instruction issues over 2 cycles); '
+                                 'valu_measured_tflops_by_waves_per_simd = what plain v_fma_f32 streams reach on this chip by occupancy '
+                                 '(one wave issues a vector instruction every ~7.5 cycles: tools/gpu/issue_probe, '
+                                 'profiles/r05_issue_rate_probe.txt).  flops_survey_dense_fp32 = SURVEY.md 8(d)\'s dense-CG count, for '
+                                 'reference only.')
 
     # ghost exchange of this rank per step: L-1 forward (width dx_t) + L-1 reverse exchanges + one force fold; bytes = rows
     # sent + received; time = HIP-event brackets around the exchange calls (with the split exchange the brackets cover
@@ -504,8 +584,12 @@ def main():
         res = {
             'metric': 'atom-steps/sec (energy+forces), SevenNet-0 100k-atom cell, 1/2/4/8 MI355X' if a.model == 'sevennet_0'
             else f'atom-steps/sec (energy+forces), {a.model} shape',
-            'value': n_atoms * a.steps / dt, 'unit': 'atom-steps/s', 'n_gpus': world, 'steps': a.steps,
-            'warmup': a.warmup, 'ms_per_step': step_ms, 'higher_is_better': True, 'scaling': 'strong',
+            # value: SURVEY.md 8(d)'s statistic -- atoms / MEDIAN step time of the K timed steps (per-step HIP events, max over ranks);
+            # ms_per_step: the contract's bracket -- wall time of the K steps between two fences / K (max over ranks); value_mean from it
+            'value': n_atoms / (step_ms_median * 1e-3), 'unit': 'atom-steps/s', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': step_ms, 'ms_per_step_median': step_ms_median, 'value_mean': n_atoms * a.steps / dt,
+            'ms_per_step_min_max': [float(per_step.min()), float(per_step.max())],
+            'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': DTYPE_LABEL[a.terms if a.fused != 'off' else 0], 'data': 'synthetic',
             'config': {'workload': f'{a.model} shape (5 interaction layers), {n_atoms}-atom periodic diamond-Si '
                                    f'cell (a=5.431 A x {a.reps}^3, {wl_note}), cutoff {cfg["cutoff"]} A, '
@@ -525,12 +609,17 @@ def main():
                                                           else f'torch.distributed all_to_all_single ({backend})')),
                        'halo_overlap': (None if not dist_mode else bool(getattr(halo, 'overlap', True))),
                        'ghost_rows_rank0': (None if not dist_mode else int(graph.n_total - graph.n_local)),
+                       'decomposition_selfcheck': (None if not dist_mode else selfcheck),
                        'halo_exposed_ms': (None if not dist_mode else round(halo_ms, 3)),   # main-stream time inside the exchange calls (start: enqueue only; finish: the wait)
                        'halo_ms_per_step_rank0': (None if not dist_mode else round(halo_ms, 4)),
                        'halo_exchanges_per_step': (None if not dist_mode else halo_n),
                        'halo_bytes_per_step_rank0': (None if not dist_mode else halo_bytes),
                        'halo_gbs_rank0': (None if not dist_mode or halo_ms <= 0 else round(halo_bytes / (halo_ms * 1e-3) / 1e9, 2)),
                        'kernel_ms_per_step_rank0': round(sum(v for k, v in totals.items() if not k.startswith('halo')) / n_break, 3),
+                       # what the step costs beyond its kernels' own durations: dependent-dispatch gaps, the per-step input copy,
+                       # torch fill kernels (main-stream classes only: '@side' brackets overlap the others)
+                       'non_kernel_ms_per_step_rank0': round(step_ms_median - sum(v for k, v in totals.items() if not k.startswith('halo') and not k.endswith('@side')) / n_break, 3),
+                       'dispatches_per_step_rank0': int(sum(c for k, c in counts.items() if not k.startswith('halo')) / n_break),
                        'energy': float(e_total.cpu())},
             'roofline': roof,
         }

@@ -235,6 +235,13 @@ int snet_conv_bwd_fused(const snet_fused_plan *plan, const float *x, const float
                         const int32_t *tile_ptr, const int32_t *tile_node, int64_t n_tiles, float scale,
                         const float *g_out, float *g_xe, float *g_h2, const float *emb, float *g_emb, float *g_vec,
                         const float *x_rowmax, const float *g_rowmax, void *stream);
+/* The same reverse pass for hosts that differentiate with respect to the harmonics THEMSELVES -- the reference's plug-in point
+ * hands `edge_attr` to autograd (sevenn/nn/convolution.py:118-141, flash_helper.py:33-48): g_sh[E, nsh] is OVERWRITTEN with
+ * dE/dY of every edge; no dsh / g_vec (the caller chains through its own spherical-harmonics module). */
+int snet_conv_bwd_fused_sh(const snet_fused_plan *plan, const float *x, const float *sh, const float *h2, const int32_t *w_row,
+                           const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, const int32_t *tile_node,
+                           int64_t n_tiles, float scale, const float *g_out, float *g_xe, float *g_h2, const float *emb,
+                           float *g_emb, float *g_sh, const float *x_rowmax, const float *g_rowmax, void *stream);
 int snet_fused_plan_has_mlp_tail(const snet_fused_plan *plan);
 /* g_xe[E,dx] of snet_conv_bwd_fused is an intermediate with its own row layout: the 16-channel chunks of a row are stored in
  * the order the kernel produces them ([x block][channel tile][component]: each (block, tile) writes one contiguous run per
@@ -446,6 +453,12 @@ typedef struct snet_halo snet_halo;
 int snet_rccl_unique_id(void *id128);
 int snet_rccl_comm_create(const void *id128, int32_t world, int32_t rank, void **comm);
 void snet_rccl_comm_destroy(void *comm);
+/* snet_rccl_available: 1 if librccl.so can be bound in this process -- local and non-collective, so that ranks can agree on the
+ * transport BEFORE entering the collective snet_rccl_comm_create.  snet_rccl_comm_info: the size and this process's rank as RCCL
+ * itself reports them (ncclCommCount / ncclCommUserRank): a host's start-up check that the communicator spans the ranks it
+ * thinks it does. */
+int snet_rccl_available(void);
+int snet_rccl_comm_info(void *comm, int32_t *world_out, int32_t *rank_out);
 int snet_rccl_allreduce_sum_f64(void *comm, double *dev_values, int64_t n, void *stream);
 int snet_halo_create(void *comm, int32_t world, int32_t rank, const int32_t *send_counts, const int32_t *send_idx_host,
                      const int32_t *recv_counts, const int32_t *recv_perm_host, snet_halo **out);

@@ -85,6 +85,9 @@ SIGNATURES = {
     'snet_conv_bwd_fused': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, c_i32p,
                                       c_i32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                       c_stream]),
+    'snet_conv_bwd_fused_sh': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, c_i32p,
+                                         c_i32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                         c_stream]),
     'snet_fused_plan_has_mlp_tail': (C.c_int, [C.c_void_p]),
     'snet_fused_plan_gxe_chunks': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]),
     'snet_segment_sum_rows_chunked': (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, c_i32p, c_f32p, c_stream]),
@@ -141,6 +144,8 @@ SIGNATURES = {
     'snet_rccl_unique_id': (C.c_int, [C.c_void_p]),
     'snet_rccl_comm_create': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     'snet_rccl_comm_destroy': (None, [C.c_void_p]),
+    'snet_rccl_available': (C.c_int, []),
+    'snet_rccl_comm_info': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'snet_rccl_allreduce_sum_f64': (C.c_int, [C.c_void_p, c_f64p, C.c_int64, c_stream]),
     'snet_loopback_hub_create': (C.c_int, [C.c_int32, C.POINTER(C.c_void_p)]),
     'snet_loopback_hub_abort': (None, [C.c_void_p]),

@@ -1110,7 +1110,15 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    gy[i] = snet::swap_add16(gy[i], gy[i]);')
     A('    gy[i] = snet::swap_add32(gy[i], gy[i]);')
     A('  }')
-    A('  if (valid && g == 0) {')
+    A('  if (tail.g_sh != nullptr) {   // b1 plug-in: the gradient with respect to the harmonics themselves (wave-uniform branch)')
+    A('    gy[0] = snet::swap_add16(gy[0], gy[0]);')
+    A('    gy[0] = snet::swap_add32(gy[0], gy[0]);')
+    A('    if (valid && g == 0) {')
+    A('#pragma unroll')
+    A('      for (int i = 0; i < NSH; ++i) tail.g_sh[(size_t)e * NSH + i] = gy[i];')
+    A('    }')
+    A('  }')
+    A('  if (dsh != nullptr && valid && g == 0) {')
     A('    float t0 = 0.f, t1 = 0.f, t2 = 0.f;')
     A('    const float *jd = dsh + (size_t)e * (3 * NSH);')
     A('#pragma unroll')

@@ -197,26 +197,44 @@ int snet_fused_plan_gxe_chunks(const snet_fused_plan *fp, int32_t *chunk_pos, in
 }
 int snet_fused_plan_has_mlp_tail(const snet_fused_plan *fp) { return fp != nullptr && fp->hidden.w0 != nullptr; }
 
+static int conv_bwd_fused_impl(const char *who, const snet_fused_plan *fp, const float *x, const float *sh, const float *dsh,
+                               const float *h2, const int32_t *w_row, const int32_t *row_ptr, const int32_t *src,
+                               const int32_t *tile_ptr, const int32_t *tile_node, int64_t n_tiles, float scale, const float *g_out,
+                               float *g_xe, float *g_h2, const float *emb, float *g_emb, float *g_vec, float *g_sh,
+                               const float *x_rowmax, const float *g_rowmax, void *stream) {
+  SNET_REQUIRE(fp != nullptr, std::string(who) + ": null plan");
+  SNET_REQUIRE(fp->terms != 4 || (x_rowmax != nullptr && g_rowmax != nullptr),
+               std::string(who) + ": terms = 4 (fp16 operands) needs x_rowmax and g_rowmax (snet_row_absmax of x and g_out)");
+  SNET_REQUIRE(n_tiles < (1ll << 31), std::string(who) + ": too many tiles");
+  if (n_tiles <= 0) return 0;
+  SNET_REQUIRE(tile_ptr != nullptr && tile_node != nullptr, std::string(who) + ": null tile list");
+  SNET_REQUIRE((g_h2 != nullptr) != (g_emb != nullptr), std::string(who) + ": exactly one of g_h2 / g_emb is the output");
+  SNET_REQUIRE(g_emb == nullptr || (fp->hidden.w0 != nullptr && emb != nullptr),
+               std::string(who) + ": g_emb needs emb and a plan with the hidden-layer tail (snet_fused_plan_has_mlp_tail)");
+  SNET_REQUIRE((dsh != nullptr) == (g_vec != nullptr), std::string(who) + ": dsh and g_vec go together");
+  SNET_REQUIRE(g_vec != nullptr || g_sh != nullptr, std::string(who) + ": no output for the harmonics' gradient (g_vec or g_sh)");
+  const snet::FusedTail tail{emb, g_emb, fp->hidden.nb, fp->hidden.act, fp->hidden.cst, fp->exps[0], fp->exps[1], fp->exps[2],
+                             x_rowmax, g_rowmax, g_sh};
+  fp->k->bwd(fp->terms, x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node, n_tiles, fp->slabs_b, scale, g_out,
+             g_xe, g_h2, g_vec, tail, static_cast<hipStream_t>(stream));
+  SNET_CHECK_LAUNCH(who);
+  return 0;
+}
 int snet_conv_bwd_fused(const snet_fused_plan *fp, const float *x, const float *sh, const float *dsh, const float *h2,
                         const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr,
                         const int32_t *tile_node, int64_t n_tiles, float scale, const float *g_out, float *g_xe,
                         float *g_h2, const float *emb, float *g_emb, float *g_vec, const float *x_rowmax,
                         const float *g_rowmax, void *stream) {
-  SNET_REQUIRE(fp != nullptr, "snet_conv_bwd_fused: null plan");
-  SNET_REQUIRE(fp->terms != 4 || (x_rowmax != nullptr && g_rowmax != nullptr),
-               "snet_conv_bwd_fused: terms = 4 (fp16 operands) needs x_rowmax and g_rowmax (snet_row_absmax of x and g_out)");
-  SNET_REQUIRE(n_tiles < (1ll << 31), "snet_conv_bwd_fused: too many tiles");
-  if (n_tiles <= 0) return 0;
-  SNET_REQUIRE(tile_ptr != nullptr && tile_node != nullptr, "snet_conv_bwd_fused: null tile list");
-  SNET_REQUIRE((g_h2 != nullptr) != (g_emb != nullptr), "snet_conv_bwd_fused: exactly one of g_h2 / g_emb is the output");
-  SNET_REQUIRE(g_emb == nullptr || (fp->hidden.w0 != nullptr && emb != nullptr),
-               "snet_conv_bwd_fused: g_emb needs emb and a plan with the hidden-layer tail (snet_fused_plan_has_mlp_tail)");
-  const snet::FusedTail tail{emb, g_emb, fp->hidden.nb, fp->hidden.act, fp->hidden.cst, fp->exps[0], fp->exps[1], fp->exps[2],
-                             x_rowmax, g_rowmax};
-  fp->k->bwd(fp->terms, x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node, n_tiles, fp->slabs_b, scale, g_out,
-             g_xe, g_h2, g_vec, tail, static_cast<hipStream_t>(stream));
-  SNET_CHECK_LAUNCH("snet_conv_bwd_fused");
-  return 0;
+  return conv_bwd_fused_impl("snet_conv_bwd_fused", fp, x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node, n_tiles, scale, g_out,
+                             g_xe, g_h2, emb, g_emb, g_vec, nullptr, x_rowmax, g_rowmax, stream);
+}
+int snet_conv_bwd_fused_sh(const snet_fused_plan *fp, const float *x, const float *sh, const float *h2, const int32_t *w_row,
+                           const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, const int32_t *tile_node,
+                           int64_t n_tiles, float scale, const float *g_out, float *g_xe, float *g_h2, const float *emb,
+                           float *g_emb, float *g_sh, const float *x_rowmax, const float *g_rowmax, void *stream) {
+  SNET_REQUIRE(g_sh != nullptr, "snet_conv_bwd_fused_sh: null g_sh");
+  return conv_bwd_fused_impl("snet_conv_bwd_fused_sh", fp, x, sh, nullptr, h2, w_row, row_ptr, src, tile_ptr, tile_node, n_tiles, scale,
+                             g_out, g_xe, g_h2, emb, g_emb, nullptr, g_sh, x_rowmax, g_rowmax, stream);
 }
 int snet_conv_bwd_edge(const snet_conv_plan *plan, const float *x, const float *sh, const float *w,
                        const int32_t *w_row, const int32_t *row_ptr, const int32_t *src, int64_t n_dst, float scale, const float *g_out,

@@ -76,6 +76,9 @@ struct FusedTail {
   // precision mode 4: max |x[row]| per source row and max |g_out[node]| per destination node (snet_row_absmax):
   // the bound the per-edge power-of-two scale of the fp16 operand g_w is derived from
   const float *x_max, *g_max;
+  // optional output (b1 plug-in: the reference's autograd needs the gradient with respect to edge_attr itself): g_sh[E, nsh]
+  // OVERWRITTEN with dE/dY of every edge; NULL in the MD hosts, which take dE/d(edge_vec) through dsh / g_vec instead
+  float *g_sh;
 };
 struct FusedKernels {
   const char *tag;

@@ -49,6 +49,8 @@ struct Rccl {
   int (*Recv)(void *, size_t, int, int, Comm, hipStream_t) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  int (*CommCount)(Comm, int *) = nullptr;      // optional: diagnostics only
+  int (*CommUserRank)(Comm, int *) = nullptr;
 };
 
 Rccl *rccl() {
@@ -73,6 +75,8 @@ Rccl *rccl() {
       r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
       r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
       r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+      r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+      r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
       if (!(r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv &&
             r.AllReduce))
         r.h = nullptr;
@@ -284,6 +288,30 @@ int snet_rccl_comm_create(const void *id128, int32_t world, int32_t rank, void *
   box->world = world;
   box->rank = rank;
   *comm = box;
+  return 0;
+}
+
+// 1 when librccl.so can be bound in this process (dlopen + every symbol the exchange needs), 0 otherwise: a LOCAL, non-collective
+// probe -- hosts agree on the transport with it BEFORE any rank enters the collective communicator construction
+int snet_rccl_available(void) { return rccl() != nullptr ? 1 : 0; }
+
+// what RCCL itself reports for a communicator (ncclCommCount / ncclCommUserRank); the in-process test transport reports its own
+int snet_rccl_comm_info(void *comm, int32_t *world_out, int32_t *rank_out) {
+  auto *box = static_cast<CommBox *>(comm);
+  SNET_REQUIRE(box != nullptr && world_out != nullptr && rank_out != nullptr, "snet_rccl_comm_info: bad argument");
+  *world_out = box->world;
+  *rank_out = box->rank;
+  if (box->kind == 0) {
+    Rccl *r = rccl();
+    SNET_REQUIRE(r != nullptr && r->CommCount && r->CommUserRank, "snet_rccl_comm_info: ncclCommCount not available");
+    int n = 0, me = 0;
+    int rc = r->CommCount(box->nccl, &n);
+    if (rc) return fail("ncclCommCount", rc);
+    rc = r->CommUserRank(box->nccl, &me);
+    if (rc) return fail("ncclCommUserRank", rc);
+    *world_out = n;
+    *rank_out = me;
+  }
   return 0;
 }
 

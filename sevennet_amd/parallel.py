@@ -270,6 +270,20 @@ class RcclComm:
                    'snet_rccl_comm_create')
         self.world, self.rank = world, rank
 
+    @staticmethod
+    def available() -> bool:
+        """librccl.so can be bound in this process: a LOCAL probe (no collective), for agreeing on the transport before any rank
+        enters the collective constructor above"""
+        from . import _lib
+        return bool(_lib.load().snet_rccl_available())
+
+    def info(self):
+        """(world, rank) as RCCL itself reports them (ncclCommCount / ncclCommUserRank)"""
+        from . import _lib
+        w, r = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.snet_rccl_comm_info(self.handle, C.byref(w), C.byref(r)), 'snet_rccl_comm_info')
+        return int(w.value), int(r.value)
+
     def all_reduce_f64(self, t: torch.Tensor):
         """in-place sum of a float64 device tensor over all ranks (total energy, virial)"""
         from . import _lib

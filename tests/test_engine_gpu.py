@@ -11,9 +11,11 @@ F_TOL = 1e-4  # eV/A, BASELINE.json north_star tolerance (absolute)
 
 
 def f_tol(scale):
-    """absolute 1e-4 eV/A up to 30 eV/A force scale (fp32 rounding of the reference's own path is
-    ~3e-6 relative); only synthetic-weight systems with larger forces get the proportional bound"""
-    return F_TOL * max(1.0, float(scale) / 30.0)
+    """the north-star force bar: 1e-4 eV/A ABSOLUTE.  (Rounds 2-4 scaled it up above 30 eV/A of force; no test system is that
+    large -- the MD-scale systems pin max|F| = 8 eV/A -- and the knob is gone: a system with larger forces fails here and has
+    to state its own tolerance.)"""
+    assert float(scale) <= 30.0, f'force scale {float(scale):.3g} eV/A: outside the range the 1e-4 eV/A bar is tested on'
+    return F_TOL
 
 
 def _engine(cfg, sd):
@@ -568,6 +570,16 @@ def test_bench_multi_rank_path_dry_run():
         assert many['n_gpus'] == n and many['config']['atoms'] == one['config']['atoms']
         assert many['config']['edges'] == one['config']['edges']
         assert abs(many['config']['energy'] - one['config']['energy']) <= 1e-9 * abs(one['config']['energy'])
+        # the start-up self-check of the decomposition travels in the line
+        sc = many['config']['decomposition_selfcheck']
+        assert sc['ok'] and sum(sc['owned_atoms_by_rank']) == one['config']['atoms'] and len(sc['ghost_rows_by_rank']) == n
+        assert sc['ghost_rows_by_rank'][0] == many['config']['ghost_rows_rank0'] and min(sc['peers_by_rank']) >= 1
+        # value = atoms / median step; the contract's bracket (mean) rides along
+        assert many['ms_per_step_median'] > 0 and abs(many['value'] - many['config']['atoms'] / (many['ms_per_step_median'] * 1e-3)) < 1e-6 * many['value']
+    # the world-1 soak of the N > 1 path on REAL RCCL: the communicator reports itself (ncclCommCount)
+    soak = run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+                '--master-port', '29613', 'bench.py', '--gpus', '1', '--dist-path', '--halo', 'native'] + common)
+    assert soak['config']['decomposition_selfcheck']['rccl_comm'] == {'nranks': 1, 'rank0_user_rank': 0}
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: real RCCL at world size 2')
@@ -594,6 +606,7 @@ def test_bench_two_ranks_real_rccl():
         assert abs(two['config']['energy'] - one['config']['energy']) <= 1e-9 * abs(one['config']['energy'])
         assert 'RCCL' in two['config']['halo'] and two['config']['halo_exchanges_per_step'] == 9
         assert two['config']['halo_exposed_ms'] is not None
+        assert two['config']['decomposition_selfcheck']['rccl_comm']['nranks'] == 2
 
 
 MD_FMAX = 8.0  # eV/A: largest force component of the MD-scale parity systems
@@ -640,6 +653,36 @@ def test_md_scale_forces_within_1e4_absolute_small_cell(model):
     dF = np.abs(out['forces'].cpu().numpy() - ref['forces'].numpy()).max()
     assert dF < 1e-4 and dF < 1e-5 * MD_FMAX, dF
     _compare(eng, out, ref, len(types), rel=1e-5)
+
+
+def test_bf16_compute_mode_whole_model_mf_ompa_shape():
+    """BASELINE config 5's STATED mode -- "bf16 compute with fp32 force accumulation" = `fused_terms=2` (two bf16 terms per operand,
+    three matrix-core products; bench.py --terms 2) -- as a whole-model test (VERDICT r4 weak #1a): SevenNet-MF-ompa shape,
+    4-species 64-atom cell, forces at MD scale (max|F| = 8 eV/A), against the fp64 oracle.  Tolerance of SURVEY.md 8(d) config 5:
+    1e-3 eV/A absolute on forces (measured 4e-5, profiles/r03_terms_accuracy*.txt: the bar is asserted 5x tighter than stated, at
+    2e-4); energy rtol 1e-5.  The fp32-class default mode on the same system must stay inside 1e-4 and be the more accurate one."""
+    from bench import model_config
+    from sevennet_amd.engine import HipForceEngine, build_graph
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = model_config('sevennet_mf_ompa')
+    sd = random_state_dict(cfg, seed=0)
+    types, pos, cell, ei, ev = synthetic_system((2, 2, 2), sigma=0.1, seed=0, cutoff=cfg['cutoff'])
+    types = np.random.default_rng(4).choice(np.array([3, 8, 14, 22]), size=len(types))
+    sd, ref = _md_scale_state(cfg, sd, types, ei, ev, 'mpa')
+    f_ref = ref['forces'].numpy()
+    err = {}
+    for mode in ('bf16x3', 'f16x3'):
+        eng = HipForceEngine(cfg, sd, device='cuda:0', modal='mpa', fused_terms=mode)
+        assert eng.fused_mode == mode and eng.fused_terms == {'bf16x3': 2, 'f16x3': 4}[mode]
+        assert all(L.fused_fwd and L.fused_bwd for L in eng.layers)
+        g = build_graph(types, ei, ev, device='cuda:0', num_species=eng.spec.num_species)
+        out = eng.compute(g)
+        torch.cuda.synchronize()
+        err[mode] = float(np.abs(out['forces'].cpu().numpy() - f_ref).max())
+        assert abs(float(out['energy'].cpu()) - float(ref['energy'])) <= 1e-5 * abs(float(ref['energy']))
+        assert np.abs(out['forces'].cpu().numpy().astype(np.float64).sum(0)).max() < 1e-3
+    assert err['bf16x3'] < 1e-3 and err['bf16x3'] < 2e-4, err      # config 5's bar, and what the mode actually delivers
+    assert err['f16x3'] < 1e-4 and err['f16x3'] <= err['bf16x3'], err
 
 
 @pytest.mark.parametrize('n_tile', [11, 23])
@@ -1039,13 +1082,16 @@ def test_rank_without_ghosts_still_serves_its_peers(host):
     assert np.abs(F - fr).max() <= max(1e-8, 2e-5 * np.abs(fr).max())
 
 
-@pytest.mark.parametrize('model,n_tile', [('sevennet_l3i5', 19), ('sevennet_mf_ompa', 15), ('sevennet_mf_ompa', 29)])
-def test_lmax3_shapes_full_size_equal_tiled_small_cell(model, n_tile):
+@pytest.mark.parametrize('model,n_tile,mode', [('sevennet_l3i5', 19, 'f16x3'), ('sevennet_mf_ompa', 15, 'f16x3'),
+                                               ('sevennet_mf_ompa', 29, 'f16x3'), ('sevennet_mf_ompa', 29, 'bf16x3')])
+def test_lmax3_shapes_full_size_equal_tiled_small_cell(model, n_tile, mode):
     """BASELINE config 4 / 5 sizes through the size-independent tiling property: SevenNet-l3i5 shape at
     19^3 x 8 = 54 872 atoms and the SevenNet-MF-ompa shape (119 species, two fidelity channels, cutoff 6) at
     15^3 x 8 = 27 000 atoms and -- config 5's full workload on ONE GPU -- at 29^3 x 8 = 195 112 atoms (9.0 M edges).  The big cell is an exact n^3 tiling of a rattled, 4-species-decorated 8-atom cell, so
     every replica must carry the forces / atomic energies of the 2^3 tiling, which the fp64 oracle evaluates;
-    the fused tensor-product kernels (engine default) run every layer of both shapes."""
+    the fused tensor-product kernels (engine default) run every layer of both shapes.  mode 'bf16x3' = config 5's stated
+    "bf16 compute, fp32 force accumulation" (bench.py --terms 2) on its full 195 112-atom workload: SURVEY.md 8(d)'s bar for that
+    configuration is 1e-3 eV/A (asserted at 2e-4); the default fp32-class mode keeps the 1e-4 eV/A bar."""
     from bench import model_config
     from oracle.model import OracleModel
     from sevennet_amd.engine import HipForceEngine
@@ -1072,8 +1118,8 @@ def test_lmax3_shapes_full_size_equal_tiled_small_cell(model, n_tile):
     f_unit, e_unit = ref['forces'].numpy()[:8], ref['atomic_energy'].numpy()[:8]
     pos, cell, ty = tile(n_tile)
     n_big = len(pos)
-    eng = HipForceEngine(cfg, sd, device='cuda:0', modal=modal)
-    assert all(L.fused_fwd and L.fused_bwd for L in eng.layers)
+    eng = HipForceEngine(cfg, sd, device='cuda:0', modal=modal, fused_terms=mode)
+    assert eng.fused_mode == mode and all(L.fused_fwd and L.fused_bwd for L in eng.layers)
     g = build_graph_gpu(ty, pos, cell, cfg['cutoff'], device='cuda:0',
                         num_species=eng.spec.num_species if eng.needs_species_rows else 0)
     assert g.n_edges * 64 == ei.shape[1] * n_big
@@ -1082,6 +1128,10 @@ def test_lmax3_shapes_full_size_equal_tiled_small_cell(model, n_tile):
     F = out['forces'].cpu().numpy().reshape(-1, 8, 3)
     Ea = out['atomic_energy'].cpu().numpy().reshape(-1, 8)
     scale = max(1.0, np.abs(f_unit).max())
+    if mode == 'bf16x3':   # config 5's own tolerance; energies to the reference's LAMMPS-vs-ASE rtol
+        assert np.abs(F - f_unit[None]).max() < 2e-4, np.abs(F - f_unit[None]).max()
+        assert abs(float(out['energy'].cpu()) / n_big - float(ref['energy']) / 64) <= 1e-5 * abs(float(ref['energy']) / 64)
+        return
     assert np.abs(F - f_unit[None]).max() < 1e-4, (np.abs(F - f_unit[None]).max(), scale)   # absolute, at MD-scale forces
     _energy_fp32_class(float(out['energy'].cpu()) / n_big, Ea, ref, 64, 8)
     # net force: every replica repeats the same rounding, so the total grows with the number of replicas -- per replica

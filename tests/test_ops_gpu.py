@@ -316,6 +316,80 @@ def test_conv_plugin_vs_oracle_autograd(cfg_name):
         assert err < 3e-5 * max(1.0, b.abs().max().item()), (name, err)
 
 
+class _RefConvStub:
+    """what sevenn.nn.flash_helper.patch_convolution receives: a not yet instantiated IrrepsConvolution -- restated as a plain
+    object with the attributes the reference's class sets in its constructor (sevenn/nn/convolution.py:50-105); the reference
+    package itself cannot be imported here (e3nn absent)"""
+
+    def __init__(self, spec, ins, hs, act, denominator):
+        self.convolution_kwargs = dict(irreps_in1=str(spec.irreps_x), irreps_in2=str(spec.irreps_sh), irreps_out=str(spec.irreps_mid),
+                                       instructions=ins, shared_weights=False, internal_weights=False)
+        self.weight_nn_kwargs = dict(hs=hs, act=act)
+        self.denominator = torch.nn.Parameter(torch.tensor([denominator]), requires_grad=False)
+        self.key_x, self.key_filter, self.key_weight_input, self.key_edge_idx = 'x', 'edge_attr', 'edge_embedding', 'edge_index'
+        self.is_parallel = False
+        self.layer_instantiated = False
+
+
+@pytest.mark.parametrize('cfg_name,terms', [('7net0_mid', 4), ('7net0_mid', 3), ('jit_c32_l2', 4)])
+def test_fused_convolution_module_vs_oracle_autograd(cfg_name, terms):
+    """b1, the whole module (VERDICT r4 missing #3 / next #7): `patch_convolution(irreps_convolution)` returns a module that
+    replaces the reference's IrrepsConvolution -- same parameter names (weight_nn.layer{0,1,2}.weight, denominator), same
+    forward(data) -- and runs hidden radial layers + fused tensor-product kernels: no weight[E, wn] in memory.  Against the
+    oracle's restatement of convolution.py:118-141 (FullyConnectedNet -> uvu tensor product -> scatter -> / denominator) in fp64:
+    output and the gradients with respect to x, edge_attr and edge_embedding (what the force autograd needs); unsorted int64
+    edge_index as the reference's data loaders produce it."""
+    from oracle.e3 import Irreps as OIrreps
+    from oracle.model import fcn_apply, tp_uvu
+    from sevennet_amd.conv_plugin import HipFusedIrrepsConvolution, patch_convolution
+    spec = _conv_case(cfg_name)
+    dev = 'cuda:0'
+    ins = [(p.i_x, p.i_sh, k, 'uvu', True) for p, k in zip(spec.paths, _mid_index(spec))]
+    nb, den = 8, 28.0
+    g = torch.Generator().manual_seed(11)
+    stub = _RefConvStub(spec, ins, [nb, 64, 64, spec.weight_numel], 'silu', den)
+    conv = patch_convolution(stub, fused=True, fused_terms=terms).to(dev)
+    assert isinstance(conv, HipFusedIrrepsConvolution)
+    assert sorted(k for k, _ in conv.state_dict().items()) == ['denominator', 'weight_nn.layer0.weight', 'weight_nn.layer1.weight', 'weight_nn.layer2.weight']
+    W = [torch.randn(nb, 64, generator=g), torch.randn(64, 64, generator=g), torch.randn(64, spec.weight_numel, generator=g)]
+    conv.load_state_dict({'denominator': torch.tensor([den]), **{f'weight_nn.layer{k}.weight': W[k] for k in range(3)}})
+    N, E = 41, 733
+    x = torch.randn(N, spec.irreps_x.dim, generator=g)
+    sh = torch.randn(E, spec.irreps_sh.dim, generator=g)
+    emb = torch.randn(E, nb, generator=g) * 0.5
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, N - 4, (E,), generator=g)
+    xd, shd, ed = [t.to(dev).requires_grad_(True) for t in (x, sh, emb)]
+    data = {'x': xd, 'edge_attr': shd, 'edge_embedding': ed, 'edge_index': torch.stack([dst, src]).to(dev)}
+    out = conv(data)['x']
+    go = torch.randn(N, spec.irreps_out.dim, generator=g)
+    out.backward(go.to(dev))
+    torch.cuda.synchronize()
+    x64, sh64, e64 = [t.double().requires_grad_(True) for t in (x, sh, emb)]
+    w64 = fcn_apply(e64, [w.double() for w in W], 'silu')
+    oins = [(i, j, k) for (i, j, k, _, _) in ins]
+    msg = tp_uvu(x64[src], sh64, w64, OIrreps(str(spec.irreps_x)), OIrreps(str(spec.irreps_sh)), OIrreps(str(spec.irreps_mid)), oins)
+    ref = torch.zeros(N, msg.shape[1], dtype=torch.float64).index_add_(0, dst, msg) / den
+    ref.backward(go.double())
+    for a, b, name in ((out, ref, 'out'), (xd.grad, x64.grad, 'g_x'), (shd.grad, sh64.grad, 'g_edge_attr'), (ed.grad, e64.grad, 'g_edge_embedding')):
+        err = (a.detach().cpu().double() - b.detach()).abs().max().item()
+        assert err < 3e-5 * max(1.0, b.abs().max().item()), (name, err, b.abs().max().item())
+    # a second call with the same weights reuses the plans; changed weights rebuild them
+    key = conv._plan_key
+    conv({'x': xd.detach(), 'edge_attr': shd.detach(), 'edge_embedding': ed.detach(), 'edge_index': data['edge_index']})
+    assert conv._plan_key == key
+    with torch.no_grad():
+        conv.weight_nn.layer2.weight.mul_(2.0)
+    out2 = conv({'x': xd.detach(), 'edge_attr': shd.detach(), 'edge_embedding': ed.detach(), 'edge_index': data['edge_index']})['x']
+    assert conv._plan_key != key and (out2 - 2.0 * out.detach()).abs().max().item() < 1e-4 * out.detach().abs().max().item()
+    # shapes without fused kernels (multiplicities not multiples of 16) are refused by the fused module itself
+    from sevennet_amd.model_spec import build_model_spec
+    from sevennet_amd.shapes import unit_test_config
+    small = build_model_spec(unit_test_config()).layers[1].conv
+    with pytest.raises(NotImplementedError, match='no fused kernels'):
+        HipFusedIrrepsConvolution(str(small.irreps_x), str(small.irreps_sh), str(small.irreps_out), [nb, 64, 64])
+
+
 def _fused_case(model, layer, seed, pairs):
     """random inputs for one convolution shape: ragged degrees (0, 1, 15, 16, 17, 31, 32, 33, 70 ...),
     ghost source rows, optional pair-shared radial rows (w_row)"""

@@ -23,6 +23,16 @@ cp $OUT/${TAG}_pmc_mfma_busy.json profiles/${TAG}_pmc_mfma_busy.json
 cp $(find $OUT/${TAG}_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats.csv
 python tools/pmc_reduce.py $(find $OUT/${TAG}_fetch -name "*counter_collection.csv" | head -1) \
                            $(find $OUT/${TAG}_write -name "*counter_collection.csv" | head -1) > $OUT/${TAG}_pmc_hbm_traffic.json
+# stamp the traffic file with the kernel sources it was measured on (bench.py marks `roofline.traffic` stale when they differ)
+python - <<PY
+import json, sys
+sys.path.insert(0, '$ROOT')
+from bench import fused_source_hashes
+p = '$OUT/${TAG}_pmc_hbm_traffic.json'
+d = json.load(open(p))
+d['__kernel_sources__'] = fused_source_hashes()
+json.dump(d, open(p, 'w'), indent=1)
+PY
 # the bench line itself, with the fresh traffic file visible to bench.py
 cp $OUT/${TAG}_pmc_hbm_traffic.json profiles/${TAG}_pmc_hbm_traffic.json
 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err
