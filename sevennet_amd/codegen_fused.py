@@ -468,6 +468,14 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     else:
         _emit_staging(A, 'LPS')
         A('  stage_load(0, 0);')
+    # Stagger experiment (SNET_CODEGEN_OPTS=stag=<n>; round 5): all workgroups of a launch start together and do the same amount of
+    # work, so their memory phases (block boundaries) and compute phases may stay aligned across the whole chip for the entire launch.
+    # stag = n delays the second workgroup of every CU of the FIRST generation (blocks 256 .. 511) by n x 8128 cycles once.
+    STAG = int(OPTS.get('stag', 0))
+    if STAG:
+        A('  if (blockIdx.x >= 256u && blockIdx.x < 512u) {')
+        A(f'    for (int i_ = 0; i_ < {STAG}; ++i_) __builtin_amdgcn_s_sleep(127);')
+        A('  }')
     A('  const int t_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
     A('  const bool live = t_raw < n_tiles;')
     A('  const int t = __builtin_amdgcn_readfirstlane(live ? t_raw : n_tiles - 1);  // idle waves shadow the last tile, stores masked')

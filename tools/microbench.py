@@ -87,6 +87,20 @@ def main():
         out = plug(xq, shq, wq, g.src, g.center)
         out.backward(goq)
         xq.grad = shq.grad = wq.grad = None
+    fplug = None
+    try:   # the WHOLE convolution behind the plug-in point (hidden radial layers + fused kernels, no weight[E, wn])
+        from sevennet_amd.conv_plugin import HipFusedIrrepsConvolution
+        fplug = HipFusedIrrepsConvolution(str(ls.conv.irreps_x), str(ls.conv.irreps_sh), str(ls.conv.irreps_out), list(ls.mlp_dims[:-1]),
+                                          'silu', 28.0, fused_terms=a.terms).to(dev)
+        eidx = torch.stack([g.center.long(), g.src.long()])
+        xq_mi, embq = rnd(N, dx).requires_grad_(True), emb.clone().requires_grad_(True)
+    except Exception as exc:  # noqa: BLE001
+        print('fused plugin module unavailable:', exc)
+
+    def fused_plugin_step():
+        out = fplug({'x': xq_mi, 'edge_attr': shq, 'edge_embedding': embq, 'edge_index': eidx})['x']
+        out.backward(goq)
+        xq_mi.grad = shq.grad = embq.grad = None
     km = kernel_model(ls, N, E)
     st = _stream()
     h2 = rnd(E, 64)
@@ -140,6 +154,7 @@ def main():
         f'radial_mlp_bwd[wn={wn}]': lambda: eng._mlp_bwd(L, emb, None, g_w, g_emb, E),
         f'conv_bwd_node[{ls.conv.tag}]': lambda: lib.snet_conv_bwd_node(L.plan, _ptr(sh), _ptr(w), None, _ptr(g.col_ptr), _ptr(g.eperm), _ptr(g.center), N, L.scale, _ptr(g_m), _ptr(g_h), st),
         'plugin_fwd_bwd(b1 autograd op)': plugin_step,
+        'plugin_fused_module_fwd_bwd(b1, whole convolution)': fused_plugin_step,
         'si2_fwd': lambda: eng._linear(L.si2, m, N, g),
         'si1_fwd': lambda: eng._linear(L.si1, h, N, g),
         'sc_fwd': lambda: eng._linear(L.sc, h, N, g),
