@@ -182,6 +182,7 @@ def _emit_reverse_body(A, pi, p):
                        g_Y_b += sum_ac C_abc s_ac  with  s_ac = sum_channels (w x_a) G_c   (one dot product per (a, c)).
     SevenNet-0 middle layer: 6 340 instead of 9 584 vector instructions per 16-edge tile; lmax-3 shapes gain more."""
     d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
+    A('template <bool GX>   // GX = false: the launch has no g_xe output (first / last layer): the source-row gradient is not formed at all')
     A(f'__device__ __forceinline__ void bwdf_p{pi}(const f32x4 (&xr)[{d1}], const float (&ys)[NSH], const f32x4 w,')
     A(f'    const f32x4 (&G)[{d3}], f32x4 &gw, float (&gy)[NSH], f32x4 (&gx)[{d1}]) {{')
     A('  float gw0 = 0.f, gw1 = 0.f, gw2 = 0.f, gw3 = 0.f;')
@@ -201,7 +202,7 @@ def _emit_reverse_body(A, pi, p):
             A('    }')
         for r in range(4):
             A(f'    gw{r} = fmaf(xr[{a}][{r}], P{r}, gw{r});')
-            A(f'    gx[{a}][{r}] = fmaf(w[{r}], P{r}, gx[{a}][{r}]);')
+            A(f'    if constexpr (GX) gx[{a}][{r}] = fmaf(w[{r}], P{r}, gx[{a}][{r}]);')
         A('  }')
     A('  gw = f32x4{gw0, gw1, gw2, gw3};')
     A('}')
@@ -216,6 +217,7 @@ def _emit_reverse_body_pk(A, pi, p):
     INSTRUCTION COUNT times that cadence -- a packed instruction does two lanes' worth of multiply-adds in the same issue slot
     (measured: v_pk_fma_f32 7.0 cycles per wave-instruction against 7.5 for v_fma_f32 at one and two waves per SIMD)."""
     d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
+    A('template <bool GX>')
     A(f'__device__ __forceinline__ void bwdf_p{pi}(const f32x4 (&xr)[{d1}], const float (&ys)[NSH], const f32x4 w,')
     A(f'    const f32x4 (&G)[{d3}], f32x4 &gw, float (&gy)[NSH], f32x4 (&gx)[{d1}]) {{')
     A('  const f32x2 wl = lo2(w), wh = hi2(w);')
@@ -240,8 +242,10 @@ def _emit_reverse_body_pk(A, pi, p):
                 A(f'      gy[{p.sh_off + b}] = fmaf({_f(v)}, s, gy[{p.sh_off + b}]);')
             A('    }')
         A('    gwl = __builtin_elementwise_fma(xl, Pl, gwl); gwh = __builtin_elementwise_fma(xh, Ph, gwh);')
-        A(f'    const f32x2 gl_ = __builtin_elementwise_fma(wl, Pl, lo2(gx[{a}])), gh_ = __builtin_elementwise_fma(wh, Ph, hi2(gx[{a}]));')
-        A(f'    gx[{a}] = f32x4{{gl_[0], gl_[1], gh_[0], gh_[1]}};')
+        A('    if constexpr (GX) {')
+        A(f'      const f32x2 gl_ = __builtin_elementwise_fma(wl, Pl, lo2(gx[{a}])), gh_ = __builtin_elementwise_fma(wh, Ph, hi2(gx[{a}]));')
+        A(f'      gx[{a}] = f32x4{{gl_[0], gl_[1], gh_[0], gh_[1]}};')
+        A('    }')
         A('  }')
     A('  gw = f32x4{gwl[0], gwl[1], gwh[0], gwh[1]};')
     A('}')
@@ -251,6 +255,7 @@ def _emit_reverse_body_v1(A, pi, p, terms, byab):
     """round-2 formulation (SNET_CODEGEN_OPTS=tpold=1, kept for A/B runs): one (a, b) entry at a time,
     U_ab = sum_c C[a,b,c] G_c consumed at once by the three products it feeds (g_w, d/dY_b, d/dx_a)"""
     d1, d2, d3 = 2 * p.l1 + 1, 2 * p.l2 + 1, 2 * p.l3 + 1
+    A('template <bool GX>')
     A(f'__device__ __forceinline__ void bwdf_p{pi}(const f32x4 (&xr)[{d1}], const float (&ys)[NSH], const f32x4 w,')
     A(f'    const f32x4 (&G)[{d3}], f32x4 &gw, float (&gy)[NSH], f32x4 (&gx)[{d1}]) {{')
     for r in range(4):
@@ -380,7 +385,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     # ------------------------------------------------------------------ reverse kernel
     if OPTS.get('stamp') == tag:
         A('__device__ unsigned long long snet_stamps[32];')
-    A('template <int NT, bool F16, int NWV, bool GLDS, int OCC>')
+    A('template <int NT, bool F16, int NWV, bool GLDS, int OCC, bool GX>')
     A(f'__global__ __launch_bounds__(64 * NWV, OCC) void conv_bwdf_{tag}(const float *__restrict__ x, const float *__restrict__ sh,')
     A('    const float *__restrict__ dsh, const float *__restrict__ h2, const int32_t *__restrict__ w_row,')
     A('    const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ src, const int32_t *__restrict__ tile_ptr,')
@@ -806,7 +811,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                             g_products('          ', 'slp', 'bprev')
                         if tb is not None:
                             w_chain('          ', 1, 'wv1')
-                    A(f'          bwdf_p{pi}(xr[{u}], ys, wv{tp}, G, gw{tp}, gy, gx[{u}]);')
+                    A(f'          bwdf_p{pi}<GX>(xr[{u}], ys, wv{tp}, G, gw{tp}, gy, gx[{u}]);')
                     if tp == 0 and SGB:
                         # prescribe the interleave: one matrix instruction, then the vector instructions that fit its shadow
                         n_m = (3 if F16_DEFAULT else 6) * ((4 if PIPE >= 2 else 0) + (2 if tb is not None else 0))
@@ -855,10 +860,10 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A(f'        gw{tp} = f32x4{{0.f, 0.f, 0.f, 0.f}};')
                 if OPTS.get('nobr'):   # kernel-tuning: the body fenced by scheduler barriers instead of the opaque branch
                     A('        __builtin_amdgcn_sched_barrier(0);')
-                    A(f'        bwdf_p{pi}(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
+                    A(f'        bwdf_p{pi}<GX>(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
                     A('        __builtin_amdgcn_sched_barrier(0);')
                 else:
-                    A(f'        if (!(diag & 1)) bwdf_p{pi}(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
+                    A(f'        if (!(diag & 1)) bwdf_p{pi}<GX>(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
                 if ST:
                     A(f'        asm volatile("" :: "v"(gw{tp}[0]), "v"(gw{tp}[3]));')
                 S(4 + 2 * tp, '        ')
@@ -903,7 +908,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         if HOIST:   # the next block's first sub-step: its slab request goes out BEFORE this block's stores
             A('    if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + f') stage_load(sidx + 1, {NB});')
             A('    __builtin_amdgcn_sched_barrier(0);')
-        A('    if (g_xe && valid' + (' && !(diag & 16)' if exp else '') + ') {')
+        A('    if (GX && g_xe && valid' + (' && !(diag & 16)' if exp else '') + ') {')
         for u in range(U):
             if gxe_std:
                 A(f'      {"float *" if u == 0 else ""}o = g_xe + (size_t)e * DX + {cat.x_off} + 16 * ({U} * cb + {u}) + 4 * g;')
@@ -945,7 +950,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         A('  }')
         A('  __syncthreads();   // (the tail reuses the slab buffers)')
     if dead_x:
-        A('  if (g_xe && valid) {  // x blocks that feed no path get a zero gradient')
+        A('  if (GX && g_xe && valid) {  // x blocks that feed no path get a zero gradient')
         for i in dead_x:
             mul_d, l_d, _ = spec.irreps_x[i]
             A(f'    for (int q = 4 * g; q < {mul_d * (2 * l_d + 1)}; q += 16)')
@@ -1437,8 +1442,14 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  int diag = 0;')
     if exp:
         A('  if (const char *e = getenv("SNET_FV_DIAG")) diag = atoi(e);')
-    A(f'  conv_bwdf_{tag}<NT, F16, NWV, GLDS, OCC><<<dim3(grid), dim3(64 * NWV), 0, st>>>(x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node,')
-    A('      (int)n_tiles, static_cast<const u32x4 *>(slabs), scale, g_out, g_xe, g_h2, g_vec, tail, diag);')
+    A('  // launches without a g_xe output (first layer, last layer with the transposed convolution) take the instantiation that does not form')
+    A('  // the source-row gradient: its multiply-adds and its 4 U d1 registers per lane are gone, not just its stores')
+    A('  if (g_xe != nullptr)')
+    A(f'    conv_bwdf_{tag}<NT, F16, NWV, GLDS, OCC, true><<<dim3(grid), dim3(64 * NWV), 0, st>>>(x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node,')
+    A('        (int)n_tiles, static_cast<const u32x4 *>(slabs), scale, g_out, g_xe, g_h2, g_vec, tail, diag);')
+    A('  else')
+    A(f'    conv_bwdf_{tag}<NT, F16, NWV, GLDS, OCC, false><<<dim3(grid), dim3(64 * NWV), 0, st>>>(x, sh, dsh, h2, w_row, row_ptr, src, tile_ptr, tile_node,')
+    A('        (int)n_tiles, static_cast<const u32x4 *>(slabs), scale, g_out, g_xe, g_h2, g_vec, tail, diag);')
     A('}')
     A('void launch_bwd(int nt, const float *x, const float *sh, const float *dsh, const float *h2, const int32_t *w_row,')
     A('                const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, const int32_t *tile_node, int64_t n_tiles,')

@@ -284,3 +284,54 @@ def test_row_map_reciprocal_is_exact_in_its_stated_range():
     for d in range(1, 151):
         inv = 65536 // d + 1
         assert all(((x * inv) >> 16) == x // d for x in range(d + 256)), d
+
+
+def test_fused_plugin_module_host_side():
+    """b1, the whole-convolution module (sevennet_amd.conv_plugin.HipFusedIrrepsConvolution) without a GPU: what a reference
+    maintainer relies on before any kernel runs -- parameter names and shapes of the reference's IrrepsConvolution (so that a reference
+    state_dict loads), construction from the keyword tables patch_convolution receives, refusal of shapes without fused kernels and of
+    radial networks the fused tail does not cover, and a loud error instead of a CPU fallback"""
+    import torch
+    from sevennet_amd.conv_plugin import HipFusedIrrepsConvolution, patch_convolution
+    from sevennet_amd.model_spec import build_model_spec, sevennet_0_config
+    from sevennet_amd.shapes import unit_test_config
+    spec = build_model_spec(sevennet_0_config()).layers[1].conv
+    # (sevennet_0_config is a pre-0.11 model: e3nn instruction order; sort_by_out=True is the >= 0.11 order, another weight-column
+    # order and therefore another compiled shape)
+    m = HipFusedIrrepsConvolution(str(spec.irreps_x), str(spec.irreps_sh), str(spec.irreps_out), [8, 64, 64], 'silu', 28.0, sort_by_out=False)
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {
+        'weight_nn.layer0.weight': (8, 64), 'weight_nn.layer1.weight': (64, 64), 'weight_nn.layer2.weight': (64, spec.weight_numel),
+        'denominator': (1,)}
+    assert m.spec.tag == spec.tag and m.spec.weight_numel == spec.weight_numel == 960
+    assert [(p.i_x, p.i_sh, p.l3) for p in m.spec.paths] == [(p.i_x, p.i_sh, p.l3) for p in spec.paths]
+    m.load_state_dict({'weight_nn.layer0.weight': torch.zeros(8, 64), 'weight_nn.layer1.weight': torch.zeros(64, 64),
+                       'weight_nn.layer2.weight': torch.zeros(64, 960), 'denominator': torch.tensor([35.989574])})
+    assert abs(float(m.denominator) - 35.989574) < 1e-6
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        m({'x': torch.zeros(4, spec.irreps_x.dim), 'edge_attr': torch.zeros(3, 9), 'edge_embedding': torch.zeros(3, 8),
+           'edge_index': torch.zeros(2, 3, dtype=torch.long)})
+    # shapes / networks outside the fused kernels' domain are refused by name
+    small = build_model_spec(unit_test_config()).layers[1].conv
+    with pytest.raises(NotImplementedError, match='no fused kernels'):
+        HipFusedIrrepsConvolution(str(small.irreps_x), str(small.irreps_sh), str(small.irreps_out), [8, 64, 64])
+    with pytest.raises(NotImplementedError, match='radial network'):
+        HipFusedIrrepsConvolution(str(spec.irreps_x), str(spec.irreps_sh), str(spec.irreps_out), [8, 32, 32], sort_by_out=False)
+    with pytest.raises(NotImplementedError, match='radial activation'):
+        HipFusedIrrepsConvolution(str(spec.irreps_x), str(spec.irreps_sh), str(spec.irreps_out), [8, 64, 64], 'gelu', sort_by_out=False)
+
+    class Stub:   # the attributes sevenn/nn/convolution.py:50-105 sets; e3nn-order instructions re-sorted by output block (:78-82)
+        def __init__(self, conv):
+            order = sorted(range(len(conv.paths)), key=lambda q: (conv.paths[q].out_off, conv.paths[q].out_ch))
+            k_of = {q: k for k, q in enumerate(order)}
+            self.convolution_kwargs = dict(irreps_in1=str(conv.irreps_x), irreps_in2=str(conv.irreps_sh), irreps_out=str(conv.irreps_mid),
+                                           instructions=[(p.i_x, p.i_sh, k_of[q], 'uvu', True) for q, p in enumerate(conv.paths)])
+            self.weight_nn_kwargs = dict(hs=[8, 64, 64, conv.weight_numel], act=torch.nn.functional.silu)
+            self.denominator = torch.nn.Parameter(torch.tensor([28.0]), requires_grad=False)
+            self.key_x, self.key_filter, self.key_weight_input, self.key_edge_idx = 'x', 'edge_attr', 'edge_embedding', 'edge_index'
+            self.is_parallel, self.layer_instantiated = False, False
+    got = patch_convolution(Stub(spec))
+    assert isinstance(got, HipFusedIrrepsConvolution) and got.spec.tag == spec.tag and got.act == 'silu' and got.layer_instantiated
+    with pytest.warns(UserWarning, match='no fused kernels'):
+        with pytest.raises(ModuleNotFoundError):     # the fallback is the reference's own class: its package is not installed here
+            patch_convolution(Stub(small))

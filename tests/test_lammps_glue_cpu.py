@@ -70,3 +70,40 @@ def test_patch_script_on_a_lammps_shaped_tree(tmp_path):
     assert again.returncode != 0 and 'already patched' in again.stdout
     bad = subprocess.run(['bash', script, str(tmp_path / 'nope')], capture_output=True, text=True)
     assert bad.returncode != 0
+
+
+@pytest.mark.skipif(shutil.which('g++') is None or not os.path.exists('/opt/rocm/include/hip/hip_runtime.h'),
+                    reason='needs g++ and the HIP headers')
+def test_runnable_lammps_mock_builds_links_and_fails_cleanly_without_a_gpu(tmp_path):
+    """the harness of tests/test_lammps_glue_gpu.py (round 5): g++ compiles the real pair-style sources against the runnable mock and
+    links them to libsnet_hip.so here, without a GPU; the driver's error paths that need no device work: usage, unknown style,
+    unreadable structure, and -- on a box without a ROCm device -- the pair style's own refusal instead of a crash"""
+    from sevennet_amd import _lib
+    from sevennet_amd.build import build, build_lammps_harness
+    if not os.path.exists(_lib.LIB_PATH):
+        build(verbose=False)
+    exe = build_lammps_harness(verbose=False)
+    assert os.path.exists(exe) and os.access(exe, os.X_OK)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and 'usage: run_pair' in r.stderr
+    struct = tmp_path / 's.txt'
+    struct.write_text('2 1\n4 0 0\n0 4 0\n0 0 4\n0.5\n1 0 0 0\n1 1.5 0 0\n')
+    out = str(tmp_path / 'o.json')
+    r = subprocess.run([exe, 'lj/cut', str(struct), out, '--', '*', '*'], capture_output=True, text=True)
+    assert r.returncode == 3 and 'unknown pair style' in r.stderr
+    r = subprocess.run([exe, 'd3', str(tmp_path / 'missing.txt'), out, '9000', '1600', 'damp_bj', 'pbe', '--', '*', '*', 'H'],
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and 'cannot open' in r.stderr
+    # pair_style d3 validates its arguments before it touches the device (pair_d3.cu:261-285)
+    r = subprocess.run([exe, 'd3', str(struct), out, '9000', '1600', '--', '*', '*', 'H'], capture_output=True, text=True)
+    assert r.returncode == 3 and 'needs Four arguments' in r.stderr
+    r = subprocess.run([exe, 'd3', str(struct), out, '9000', '1600', 'damp_foo', 'pbe', '--', '*', '*', 'H'], capture_output=True, text=True)
+    assert r.returncode == 3 and 'Unknown damping' in r.stderr
+    r = subprocess.run([exe, 'd3', str(struct), out, '9000', '1600', 'damp_bj', 'pbe', '--', '*', '*', 'Xx'], capture_output=True, text=True)
+    assert r.returncode == 3 and 'unknown element' in r.stderr
+    import torch
+    if not torch.cuda.is_available():   # no device: the e3gnn constructor refuses (the engine has no CPU path), nothing segfaults
+        r = subprocess.run([exe, 'e3gnn', str(struct), out, '--', '*', '*', 'nope.snet', 'H'], capture_output=True, text=True)
+        assert r.returncode == 3 and 'no ROCm device' in r.stderr
+        r = subprocess.run([exe, 'd3', str(struct), out, '9000', '1600', 'damp_bj', 'pbe', '--', '*', '*', 'H'], capture_output=True, text=True)
+        assert r.returncode == 3 and 'pair_style d3' in r.stderr
