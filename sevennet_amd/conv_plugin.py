@@ -212,7 +212,7 @@ class HipUvuConvolution(torch.nn.Module):
 # `weight` nor `message` nor their gradients exist in memory (convolution.py:118-141 restated on snet_conv_fwd_fused /
 # snet_conv_bwd_fused_sh).
 def _tiles_for(ep: _EdgePlan, mode: int, n_nodes: int, lib):
-    key = ('tiles', mode)
+    key = ('tiles', mode, n_nodes)
     got = getattr(ep, '_tiles', {}).get(key)
     if got is not None:
         return got

@@ -382,6 +382,24 @@ def test_fused_convolution_module_vs_oracle_autograd(cfg_name, terms):
         conv.weight_nn.layer2.weight.mul_(2.0)
     out2 = conv({'x': xd.detach(), 'edge_attr': shd.detach(), 'edge_embedding': ed.detach(), 'edge_index': data['edge_index']})['x']
     assert conv._plan_key != key and (out2 - 2.0 * out.detach()).abs().max().item() < 1e-4 * out.detach().abs().max().item()
+    # parallel mode (convolution.py:124-125,137-138): ghost rows arrive separately, are sources only, and the output has the local rows
+    n_loc = N - 4
+    stub_p = _RefConvStub(spec, ins, [nb, 64, 64, spec.weight_numel], 'silu', den)
+    stub_p.is_parallel = True
+    conv_p = patch_convolution(stub_p, fused=True, fused_terms=terms).to(dev)
+    conv_p.load_state_dict(conv.state_dict())
+    with torch.no_grad():
+        conv_p.weight_nn.layer2.weight.copy_(W[2].to(dev))     # (conv's last layer was doubled above)
+    xl, xg = x[:n_loc].to(dev).requires_grad_(True), x[n_loc:].to(dev).requires_grad_(True)
+    out_p = conv_p({'x': xl, 'node_feature_ghost': xg, 'edge_attr': shd.detach(), 'edge_embedding': ed.detach(),
+                    'edge_index': data['edge_index']})['x']
+    assert out_p.shape == (n_loc, spec.irreps_out.dim)
+    assert (out_p.detach().cpu().double() - ref.detach()[:n_loc]).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    out_p.backward(go[:n_loc].to(dev))
+    torch.cuda.synchronize()
+    # (rows n_loc .. N of the reference output are zero -- no edge ends there -- so the full-output gradient above is the same function)
+    gx_all = torch.cat([xl.grad, xg.grad]).cpu().double()
+    assert (gx_all - x64.grad).abs().max().item() < 3e-5 * max(1.0, x64.grad.abs().max().item())
     # shapes without fused kernels (multiplicities not multiples of 16) are refused by the fused module itself
     from sevennet_amd.model_spec import build_model_spec
     from sevennet_amd.shapes import unit_test_config
