@@ -89,13 +89,16 @@ def main():
         xq.grad = shq.grad = wq.grad = None
     fplug = None
     try:   # the WHOLE convolution behind the plug-in point (hidden radial layers + fused kernels, no weight[E, wn])
+        if a.only and 'plugin' not in a.only:
+            raise RuntimeError('not requested')
         from sevennet_amd.conv_plugin import HipFusedIrrepsConvolution
         fplug = HipFusedIrrepsConvolution(str(ls.conv.irreps_x), str(ls.conv.irreps_sh), str(ls.conv.irreps_out), list(ls.mlp_dims[:-1]),
-                                          'silu', 28.0, fused_terms=a.terms).to(dev)
+                                          'silu', 28.0, fused_terms=a.terms,
+                                          sort_by_out=[(p_.i_x, p_.i_sh) for p_ in ls.conv.paths] != sorted((p_.i_x, p_.i_sh) for p_ in ls.conv.paths)).to(dev)
         eidx = torch.stack([g.center.long(), g.src.long()])
         xq_mi, embq = rnd(N, dx).requires_grad_(True), emb.clone().requires_grad_(True)
     except Exception as exc:  # noqa: BLE001
-        print('fused plugin module unavailable:', exc)
+        print('fused plugin module not built:', exc)
 
     def fused_plugin_step():
         out = fplug({'x': xq_mi, 'edge_attr': shq, 'edge_embedding': embq, 'edge_index': eidx})['x']
@@ -174,6 +177,10 @@ def main():
         'gate_bwd': lambda: lib.snet_gate_bwd_norm(_ptr(y_r), _ptr(xo_r), _ptr(gy_r), N, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), 1.0, _ptr(g_max), st),
         'row_absmax': lambda: lib.snet_row_absmax(_ptr(h), N, dx, _ptr(x_max), st),
     }
+    if fplug is None:
+        ops.pop('plugin_fused_module_fwd_bwd(b1, whole convolution)')
+    if plug is None:
+        ops.pop('plugin_fwd_bwd(b1 autograd op)')
     print(f'lib={_lib.LIB_PATH} N={N} E={E} layer={a.layer} dx={dx} dmid={dmid} wn={wn}')
     todo = []
     for name, fn in ops.items():
