@@ -343,7 +343,7 @@ class HipFusedIrrepsConvolution(torch.nn.Module):
     def __init__(self, irreps_x, irreps_filter, irreps_out, weight_layer_input_to_hidden, weight_layer_act='silu',
                  denominator: float = 1.0, data_key_x: str = 'x', data_key_filter: str = 'edge_attr',
                  data_key_weight_input: str = 'edge_embedding', data_key_edge_idx: str = 'edge_index', is_parallel: bool = False,
-                 sort_by_out: bool = True, fused_terms: int = 4, **_ignored):
+                 sort_by_out: bool = True, fused_terms: int = 4, data_key_x_ghost: str = 'x_ghost', **_ignored):
         super().__init__()
         from .model_spec import ACT_CST, ACT_ID, make_conv
         self.lib = _lib.load()
@@ -351,6 +351,7 @@ class HipFusedIrrepsConvolution(torch.nn.Module):
         self.key_x, self.key_filter = data_key_x, data_key_filter
         self.key_weight_input, self.key_edge_idx = data_key_weight_input, data_key_edge_idx
         self.is_parallel = is_parallel
+        self.key_x_ghost = data_key_x_ghost      # sevenn/_keys.py:39 NODE_FEATURE_GHOST
         hs = list(weight_layer_input_to_hidden) + [self.spec.weight_numel]
         if len(hs) != 4 or hs[1] != 64 or hs[2] != 64 or hs[0] > 32:
             raise NotImplementedError(f'fused convolution: radial network {hs} (needs [n_basis <= 32, 64, 64, weight_numel])')
@@ -429,7 +430,7 @@ class HipFusedIrrepsConvolution(torch.nn.Module):
         n_dst = None
         if self.is_parallel:   # ghost rows are sources only (convolution.py:124-125,137-138)
             n_dst = x.shape[0]
-            x = torch.cat([x, data['node_feature_ghost']])
+            x = torch.cat([x, data[self.key_x_ghost]])
         ei = data[self.key_edge_idx]
         out = _FusedConvFn.apply(x, data[self.key_filter], data[self.key_weight_input], ei[1], ei[0], n_dst, self)
         data[self.key_x] = out

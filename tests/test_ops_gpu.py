@@ -391,7 +391,7 @@ def test_fused_convolution_module_vs_oracle_autograd(cfg_name, terms):
     with torch.no_grad():
         conv_p.weight_nn.layer2.weight.copy_(W[2].to(dev))     # (conv's last layer was doubled above)
     xl, xg = x[:n_loc].to(dev).requires_grad_(True), x[n_loc:].to(dev).requires_grad_(True)
-    out_p = conv_p({'x': xl, 'node_feature_ghost': xg, 'edge_attr': shd.detach(), 'edge_embedding': ed.detach(),
+    out_p = conv_p({'x': xl, 'x_ghost': xg, 'edge_attr': shd.detach(), 'edge_embedding': ed.detach(),
                     'edge_index': data['edge_index']})['x']
     assert out_p.shape == (n_loc, spec.irreps_out.dim)
     assert (out_p.detach().cpu().double() - ref.detach()[:n_loc]).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
