@@ -397,13 +397,29 @@ class HipFusedIrrepsConvolution(torch.nn.Module):
     def instantiate(self):   # (the reference calls this on lazily built layers: nothing left to do)
         return None
 
+    def _free_plans(self):
+        if getattr(self, 'fplan', None) is not None:
+            self.lib.snet_fused_plan_destroy(self.fplan)
+        if getattr(self, 'mlp_plan', None) is not None:
+            self.lib.snet_radial_mlp_plan_destroy(self.mlp_plan)
+        self.fplan = self.mlp_plan = None
+        self._plan_key = None
+
+    def __del__(self):
+        try:
+            self._free_plans()
+            if getattr(self, 'plan', None) is not None:
+                self.lib.snet_conv_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def _ensure_plans(self):
         ws = [getattr(self.weight_nn, f'layer{k}').weight for k in range(3)]
         key = tuple((w.data_ptr(), w._version) for w in ws) + (float(self.denominator.detach().reshape(-1)[0]), self.fused_terms)
         if key == self._plan_key:
             return
-        if self.fplan is not None:
-            self.lib.snet_fused_plan_destroy(self.fplan)
+        self._free_plans()
         hs = self.weight_nn.hs
         hw = [np.ascontiguousarray(w.detach().cpu().double().numpy() / np.sqrt(hs[k]), dtype=np.float32) for k, w in enumerate(ws)]
         fp = [w.ctypes.data_as(C.POINTER(C.c_float)) for w in hw]
