@@ -1007,15 +1007,34 @@ def test_interior_boundary_split_of_the_fused_convolutions(world):
     assert any(0 < b.n_interior < b.n_local for b in bricks)
     from sevennet_amd.native_model import NativeModel
     out = {}
-    for split in (True, False, 'native'):
+    class _CallbackHalo:   # the same exchange behind Python callbacks: the sequencer then cannot split (snet_model_set_halo)
+        def __init__(self, h):
+            self.h = h
+
+        def forward(self, x, n_local):
+            return self.h.forward(x, n_local)
+
+        def reverse(self, gx, n_local):
+            return self.h.reverse(gx, n_local)
+
+    for split in (True, False, 'native', 'native_late'):
         hub = LoopbackHub(world)
         halos = [NativeHalo(hub.comm(r), bricks[r].send_lists, bricks[r].recv_counts) for r in range(world)]
-        models = [NativeModel(cfg, sd) if split == 'native' else HipForceEngine(cfg, sd, device='cuda:0') for _ in range(world)]
+        models = [NativeModel(cfg, sd) if str(split).startswith('native') else HipForceEngine(cfg, sd, device='cuda:0') for _ in range(world)]
 
         def fn(r):
             b = bricks[r]
             g = build_graph(b.types, b.edge_index, b.edge_vec, n_local=b.n_local, n_interior=b.n_interior, device='cuda:0')
-            if split == 'native':      # the C++ sequencer: same split on its own second stream (snet_model_set_interior)
+            if split == 'native_late':
+                # the graph is first evaluated UN-split (callback halo), its topology cached; then the library halo is
+                # installed and the SAME graph evaluated again -- a cache hit that must not reuse a boundary tile list nobody built
+                models[r].set_halo(_CallbackHalo(halos[r]))
+                first = models[r].compute(g)
+                torch.cuda.synchronize()
+                models[r].set_halo(halos[r])
+                o = models[r].compute(g)
+                assert torch.equal(first['forces'], o['forces']) and torch.equal(first['energy'], o['energy'])
+            elif split == 'native':      # the C++ sequencer: same split on its own second stream (snet_model_set_interior)
                 models[r].set_halo(halos[r])
                 o = models[r].compute(g)
             else:
@@ -1027,6 +1046,8 @@ def test_interior_boundary_split_of_the_fused_convolutions(world):
     for (e1, f1, d1), (e0, f0, d0), (e2, f2, d2) in zip(out[True], out[False], out['native']):
         assert e1 == e0 and np.array_equal(f1, f0) and np.array_equal(d1, d0)
         assert e1 == e2 and np.array_equal(f1, f2) and np.array_equal(d1, d2)   # both hosts bit for bit
+    for (e2, f2, d2), (e3, f3, d3) in zip(out['native'], out['native_late']):
+        assert e2 == e3 and np.array_equal(f2, f3) and np.array_equal(d2, d3)
     F = np.zeros((len(types), 3), np.float32)
     for b, (_, f, _) in zip(bricks, out[True]):
         F[b.global_ids[:b.n_local]] = f[:b.n_local]
