@@ -383,8 +383,9 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('')
 
     # ------------------------------------------------------------------ reverse kernel
-    if OPTS.get('stamp') == tag:
-        A('__device__ unsigned long long snet_stamps[32];')
+    if OPTS.get('stamp') == tag or OPTS.get('stampl') == tag:
+        A('constexpr int SNET_STAMP_TILES = 1 << 18;')
+        A('__device__ unsigned snet_stamps[16 * SNET_STAMP_TILES];   // one row per tile: no atomics (2.7 M atomics on 16 hot words stalled the whole chip)')
     A('template <int NT, bool F16, int NWV, bool GLDS, int OCC, bool GX>')
     A(f'__global__ __launch_bounds__(64 * NWV, OCC) void conv_bwdf_{tag}(const float *__restrict__ x, const float *__restrict__ sh,')
     A('    const float *__restrict__ dsh, const float *__restrict__ h2, const int32_t *__restrict__ w_row,')
@@ -402,7 +403,11 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     # per-phase cycle sums of every wave added to the device array snet_stamps (read back by snet_debug_stamps; tools/microbench.py
     # --stamps).  Every stamp drains the wave's LDS counter and fences the scheduler, so the instrumented kernel runs ~10 % slower
     # than the shipped one: the split between phases is what it is for.
-    ST = OPTS.get('stamp') == tag
+    # stampl=<tag>: the LIGHT form -- stamps at the block-level boundaries only (prologue, block top, the block's sub-steps as one
+    # phase [id 9], block end, tail, epilogue: ~25 stamps per tile instead of ~270), so the split between "inside the sub-steps" and
+    # "around them" is measured on a kernel that runs close to the shipped one
+    STL = OPTS.get('stampl') == tag
+    ST = OPTS.get('stamp') == tag or STL
     NPH = 16
     # In-wave software pipeline of the sub-steps (SNET_CODEGEN_OPTS=pipe=<n>; round 5).  The phases of a sub-step -- fragments from
     # LDS, chained matrix products, the tensor-product body on their result -- are a serial latency chain per wave, and two waves per
@@ -426,7 +431,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     NB = '(buf ^ 1)' if NBUF == 2 else '(buf == 2 ? 0 : buf + 1)'
 
     def S(i, ind='      '):
-        if ST:
+        if ST and (not STL or i in (0, 1, 10, 11, 12, 13)):
             A(f'{ind}stamp({i});')
     # Packed tiles (SNET_CODEGEN_OPTS=xtile=1): a tile is a window of <= 16 consecutive CSR edges that may run from one destination
     # node (A) into the next one that has edges (B); snet_edge_tiles_packed writes tile_ptr[t] = first edge, tile_node[2t .. 2t+1] = A, B.
@@ -845,7 +850,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                     A('          wv = mfma16_split<NT, F16>(a, hb[q], wv);')
                     A('        }')
                     A('        if constexpr (F16) wv *= w_unscale;')
-                    if ST:
+                    if ST and not STL:
                         A('        asm volatile("" :: "v"(wv[0]), "v"(wv[3]));')
                     S(3 + 2 * tp, '        ')
                 A(f'        f32x4 G[{d3}];')
@@ -864,7 +869,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                     A('        __builtin_amdgcn_sched_barrier(0);')
                 else:
                     A(f'        if (!(diag & 1)) bwdf_p{pi}<GX>(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
-                if ST:
+                if ST and not STL:
                     A(f'        asm volatile("" :: "v"(gw{tp}[0]), "v"(gw{tp}[3]));')
                 S(4 + 2 * tp, '        ')
                 A('      }')
@@ -895,7 +900,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                     A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
                     A('      buf ^= 1;')
             else:
-                if ST:
+                if ST and not STL:
                     A('      asm volatile("" :: "v"(ga[0][0]), "v"(ga[1][0]), "v"(ga[2][0]), "v"(ga[3][0]));')
                 S(7)
                 A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + f') stage_store({NB});')
@@ -905,6 +910,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A(f'      buf = {NB};')
             A('      ++sidx;')
             A('    }')
+        if STL:
+            A('    stamp(9);   // (light stamps: all sub-steps of the block)')
         if HOIST:   # the next block's first sub-step: its slab request goes out BEFORE this block's stores
             A('    if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + f') stage_load(sidx + 1, {NB});')
             A('    __builtin_amdgcn_sched_barrier(0);')
@@ -1145,9 +1152,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  }')
     if ST:
         S(13, '  ')
-        A('  if (lane == 0 && live) {')
-        A(f'    for (int i = 0; i < {NPH}; ++i) atomicAdd(&snet_stamps[i], (unsigned long long)ph[i]);')
-        A('    atomicAdd(&snet_stamps[31], 1ull);')
+        A('  if (lane == 0 && live && t_raw < SNET_STAMP_TILES) {')
+        A(f'    for (int i = 0; i < {NPH}; ++i) snet_stamps[t_raw * 16 + i] = ph[i];')
         A('  }')
     A('}')
     A('')
@@ -1545,10 +1551,24 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A(f'const snet::FusedKernels kernels = {{"{tag}", DX, DOUT, NSH, WN, NS, SUB_COLS, {len(cols_rev)}, SUB_COLS_B, GXE_CHUNK, launch_bwd, launch_fwd, {1 if XT else 0}}};')
     A('const snet::FusedRegistrar registrar(&kernels);')
     A('}  // namespace')
-    if OPTS.get('stamp') == tag:
+    if OPTS.get('stamp') == tag or OPTS.get('stampl') == tag:
+        A('// out[0 .. 15] = per-phase cycle sums over the tiles of the LAST launch, out[31] = number of tiles that reported')
         A('extern "C" int snet_debug_stamps(unsigned long long *out, int reset) {')
-        A('  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(snet_stamps), 32 * sizeof(unsigned long long)) != hipSuccess) return 1;')
-        A('  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(snet_stamps), z, sizeof(z)) != hipSuccess) return 1; }')
+        A('  static unsigned *host = nullptr;')
+        A('  const size_t bytes = sizeof(unsigned) * 16 * SNET_STAMP_TILES;')
+        A('  if (!host) host = static_cast<unsigned *>(malloc(bytes));')
+        A('  if (out) {')
+        A('    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(snet_stamps), bytes) != hipSuccess) return 1;')
+        A('    for (int i = 0; i < 32; ++i) out[i] = 0;')
+        A('    for (int t = 0; t < SNET_STAMP_TILES; ++t) {')
+        A('      unsigned long long tot = 0;')
+        A('      for (int i = 0; i < 16; ++i) tot += host[t * 16 + i];')
+        A('      if (!tot) continue;')
+        A('      for (int i = 0; i < 16; ++i) out[i] += host[t * 16 + i];')
+        A('      ++out[31];')
+        A('    }')
+        A('  }')
+        A('  if (reset) { void *dev = nullptr; if (hipGetSymbolAddress(&dev, HIP_SYMBOL(snet_stamps)) != hipSuccess || hipMemset(dev, 0, bytes) != hipSuccess) return 1; }')
         A('  return 0;')
         A('}')
     return '\n'.join(L) + '\n'
