@@ -31,6 +31,8 @@ def main():
     ap.add_argument('--fv', default='', help='kernel-tuning builds (SNET_CODEGEN_OPTS=fexp=<tag>): semicolon-separated '
                     '"nwv,glds,occ[,diag]" variants of the fused kernels to time, e.g. "4,0,2;4,1,2;4,1,1;4,1,2,1"')
     ap.add_argument('--only', default='', help='substring filter on kernel names')
+    ap.add_argument('--zeros', action='store_true', help='all-zero features and gradients (same instruction stream, no data toggling): '
+                    'a power-limited kernel runs faster on them (DVFS), a latency- or issue-limited one does not')
     ap.add_argument('--stamps', action='store_true', help='stamp builds (SNET_CODEGEN_OPTS=stamp=<tag>): print the per-phase '
                     'cycle sums the instrumented reverse kernel collected (snet_debug_stamps)')
     ap.add_argument('--order', default='raster', choices=['raster', 'morton', 'random'], help='atom order of the test cell')
@@ -109,6 +111,9 @@ def main():
     h2 = rnd(E, 64)
     g_h2 = rnd(E, 64)
     tile_ptr, tile_node, n_tiles = g.tiles(int(lib.snet_fused_plan_tile_mode(L.fplan)) if L.fplan is not None else 0)
+    if a.zeros:
+        for t_ in (h, g_m, h2, g_h2, sh, dsh, emb):
+            t_.zero_()
     x_max, g_max = h.abs().amax(1).contiguous(), g_m.abs().amax(1).contiguous()   # bounds of the fp16-operand mode
     gy_r, y_r, sc_r = rnd(N, ls.si2.dim_out), rnd(N, ls.gate.irreps_in.dim), rnd(N, ls.gate.irreps_in.dim)
     xo_r = rnd(N, ls.gate.irreps_out.dim)
