@@ -168,7 +168,10 @@ def build(jobs: int = 0, force: bool = False, extra_configs=(), verbose: bool = 
     if verbose:
         print(f'[sevennet_amd.build] built {LIB}', flush=True)
     if not os.environ.get('SNET_BUILD_LIB'):   # (experiment libraries do not rebuild the harness)
-        build_lammps_harness(verbose)
+        try:
+            build_lammps_harness(verbose)
+        except Exception as exc:  # noqa: BLE001  -- test scaffolding must not fail the product build (its tests then say so themselves)
+            print(f'[sevennet_amd.build] LAMMPS mock harness NOT built: {exc}', file=sys.stderr, flush=True)
     return LIB
 
 
