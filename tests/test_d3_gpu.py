@@ -148,3 +148,37 @@ def test_reference_pair_d3_binding_known_answers():
     assert abs(e - ref['energy']) < 1e-9 * abs(ref['energy'])
     assert np.abs(f - ref['forces']).max() < 1e-8 * np.abs(ref['forces']).max()
     assert np.abs(s - voigt(ref['stress'])).max() < 1e-8 * np.abs(ref['stress']).max()
+
+
+def test_reference_pair_d3_binding_failures_are_not_silent():
+    """a failed handle must not hand out zero-filled results.  With a GPU present the failure that matters is a bad name
+    (the reference aborts via error->all, pair_d3.cu:261-285): the shim's failure is sticky, pair_get_force / pair_get_stress return NULL,
+    pair_get_energy NaN, pair_failed reads 1 -- also after a later, otherwise valid, compute sequence on the same handle."""
+    import ctypes
+    from sevennet_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    _reference_stub(lib)
+    lib.pair_failed.argtypes = [ctypes.c_void_p]
+    lib.pair_failed.restype = ctypes.c_int
+    lib.pair_get_force.restype = ctypes.c_void_p       # (NULL must be visible as None)
+    lib.pair_get_stress.restype = ctypes.c_void_p
+    for damp, func in ((b'damp_bj', b'no-such-functional'), (b'damp_foo', b'pbe')):
+        pair = lib.pair_init()
+        assert not lib.pair_failed(pair)
+        types = (ctypes.c_int * 2)(1, 2)
+        x = (ctypes.c_double * 6)(0, 0, 0, 2.815, 0, 0)
+        lib.pair_set_atom(pair, 2, 2, types, x)
+        lib.pair_set_domain(pair, 1, 1, 1, (ctypes.c_double * 3)(0, 0, 0), (ctypes.c_double * 3)(5.63, 5.63, 5.63), 0.0, 0.0, 0.0)
+        lib.pair_run_settings(pair, 9000.0, 1600.0, damp, func)
+        assert lib.pair_failed(pair)
+        lib.pair_run_coeff(pair, (ctypes.c_int * 2)(11, 17))
+        lib.pair_run_compute(pair)
+        assert lib.pair_failed(pair) and np.isnan(lib.pair_get_energy(pair))
+        assert lib.pair_get_force(pair) is None and lib.pair_get_stress(pair) is None
+        lib.pair_fin(pair)
+    # a healthy handle next to them is unaffected, and repeated settings with unchanged arguments are no-ops
+    lib.pair_get_force.restype = ctypes.POINTER(ctypes.c_double)
+    lib.pair_get_stress.restype = ctypes.POINTER(ctypes.c_double * 6)
+    e1, f1, s1 = _reference_calculate(lib, NACL['numbers'], NACL['positions'], NACL['cell'], NACL['pbc'])
+    e2, f2, s2 = _reference_calculate(lib, NACL['numbers'], NACL['positions'], NACL['cell'], NACL['pbc'])
+    assert e1 == e2 and np.array_equal(f1, f2) and abs(e1 - NACL_REF['energy']) < RTOL * abs(NACL_REF['energy'])
