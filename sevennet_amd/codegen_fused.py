@@ -345,6 +345,9 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     _ngpp = max((sum(2 * p_.l3 + 1 for _, p_ in b_['cat'].paths) * b_['U'] + 15) // 16 * 16 for b_ in _bsp)
     _livep = 12 * max(2 * c_.l1 + 1 for c_ in cats) + 32 + NSH + 8 * (_ngpp // 16) + 16 + 4 * max(2 * p_.l3 + 1 for p_ in spec.paths) + 35
     _xt_auto = _livep <= 200 and _livep - 4 * (_ngpp // 16) > 168 and len(cats) > 1
+    # forward kernel: a tile with m <= 12 edges keeps ceil(m / 4) accumulator rows per lane group instead of filling groups in turn
+    # (SNET_CODEGEN_OPTS=frow=0: the previous row order; middle layers 2.79 -> 2.73 ms same box, profiles/r05_ab_forward_variants.txt)
+    FROW = bool(int(OPTS.get('frow', 1)))
     PK = bool(int(OPTS['pk'])) if 'pk' in OPTS else ((bool(int(OPTS['xtile'])) if 'xtile' in OPTS else _xt_auto))
     # ------------------------------------------------------------------ per-path device functions
     for pi, p in enumerate(spec.paths):
@@ -364,13 +367,23 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             _emit_reverse_body_v1(A, pi, p, terms, byab)
         # ---- forward: lane = channel, the 4 edges of the lane's group in the vector components
         A(f'__device__ __forceinline__ void fwdf_p{pi}(const float (&xr)[4][{d1}], const float *ysl, const f32x4 w,')
-        A(f'    float (&acc)[{d3}]) {{')
+        A(f'    float (&acc)[{d3}], const int rows) {{')
+        # rows (wave-uniform): accumulator rows per lane group that hold an edge in this tile -- a short tile is spread over the four
+        # lane groups (FROW below), so that its empty row is the SAME r = 3 in every lane and its arithmetic can be skipped.  Only
+        # r = 3 is conditional and its harmonics are read up front: one branch per body, the other three rows stay one basic block
+        ybs = sorted({b_ for (_, b_) in byab})
+        if FROW:
+            for b_ in ybs:
+                A(f'  const float y3_{b_} = ysl[3 * NSHP + {p.sh_off + b_}];')
         for r in range(4):
-            A(f'  {{  // edge {r} of the lane\'s group (its spherical harmonics: wave-private LDS rows)')
+            A(f'  if ({"true" if (r < 3 or not FROW) else "rows > 3"}) {{  // edge {r} of the lane\'s group (its spherical harmonics: wave-private LDS rows)')
             for i in range(d3):
                 A(f'    float s{i} = 0.f;')
-            for b_ in sorted({b_ for (_, b_) in byab}):
-                A(f'    const float y{b_} = ysl[{r} * NSHP + {p.sh_off + b_}];')
+            for b_ in ybs:
+                if FROW and r == 3:
+                    A(f'    const float y{b_} = y3_{b_};')
+                else:
+                    A(f'    const float y{b_} = ysl[{r} * NSHP + {p.sh_off + b_}];')
             for (a_, b_), cl in sorted(byab.items()):
                 A(f'    {{ const float xy = xr[{r}][{a_}] * y{b_};')
                 for cc, v in cl:
@@ -383,7 +396,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('')
 
     # ------------------------------------------------------------------ reverse kernel
-    if OPTS.get('stamp') == tag or OPTS.get('stampl') == tag:
+    if tag in (OPTS.get('stamp'), OPTS.get('stampl'), OPTS.get('stampf'), OPTS.get('stampfl')):
         A('constexpr int SNET_STAMP_TILES = 1 << 18;')
         A('__device__ unsigned snet_stamps[16 * SNET_STAMP_TILES];   // one row per tile: no atomics (2.7 M atomics on 16 hot words stalled the whole chip)')
     A('template <int NT, bool F16, int NWV, bool GLDS, int OCC, bool GX>')
@@ -1185,18 +1198,93 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  __shared__ __attribute__((aligned(16))) float s_ys[NWV][32 * NSHP];  // spherical harmonics of the pass\'s edges (rows padded: NSHP)')
     A(f'  __shared__ __attribute__((aligned(16))) float s_x[NWV][{MAXD1} * 256];  // source-row slice of one tile: [m][r][g][channel]')
     A(f'  __shared__ __attribute__((aligned(16))) float s_o[NWV][{NOEP} * 16];      // output rows of one block: [entry][channel]')
-    A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
-    A('  const int c = lane & 15, g = lane >> 4;')
-    A('  const int n_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
+    # Long-lived workgroups (SNET_CODEGEN_OPTS=fpers=1; round 5, kernel-tuning builds only).  The 12-wave forward configuration holds
+    # the whole LDS of its CU, so nothing else runs while a workgroup is in its prologue (three dependent memory latencies: 10.8 % of a
+    # wave's cycles, profiles/r05_phase_stamps_forward.txt).  fpers: one workgroup per CU walks the node groups b, b + grid, ... (same
+    # XCD: the grid is a multiple of 8).  Measured (profiles/r05_ab_forward_variants.txt): middle layers 2.72 -> 2.75 ms, i.e. nothing --
+    # the kernel draws the socket's 1 400 W cap (profiles/r05_power_probe.txt), so a removed bubble comes back as a lower clock.
+    FPERS = int(OPTS.get('fpers', 0))
+    # fpre=1 (with fpers): the next group's row pointers, radial-weight row indices and source rows are requested during the current
+    # group's first blocks, and the weight stream is treated as cyclic (the last block of a pass requests the first block of the next
+    # pass / group): a group then starts with ONE memory latency (h2, harmonics, first source rows together) and no slab barrier.
+    # Measured: middle layers 2.72 -> 2.75 ms, last layer 1.01 -> 0.97 ms, first layer (8-wave workgroups, two per CU) 0.94 -> 1.25 ms: off.
+    FPRE = bool(FPERS and int(OPTS.get('fpre', 0)))
+    if FPERS:
+        A('  const int n_groups = (n_nodes + NWV - 1) / NWV;')
+        if FPRE:
+            A('  int nx_beg = 0, nx_end = 0, nx_wra[2] = {0, 0}, nx_srs[2] = {0, 0}, pre_stage = 0, cbuf = 0;')
+            A('  bool slab_ready = false;')
+            A('  auto row_edge = [](int n_e, int tl, int row) {  // the forward kernel\'s row order of a pass of n_e edges (see edge_of_row)')
+            if FROW:
+                A('    const int m = tl ? max(n_e - 16, 0) : min(n_e, 16);')
+                A('    return 16 * tl + (row >> 2) * ((m + 3) >> 2) + (row & 3);')
+            else:
+                A('    return 16 * tl + row;')
+            A('  };')
+            A('  auto pre_idx = [&](unsigned vbn, int wave_) {')
+            A('    const int nr = snet::xcd_node(vbn, (unsigned)n_groups) * NWV + wave_;')
+            A('    const int nn = __builtin_amdgcn_readfirstlane(min(nr, n_nodes - 1));')
+            A('    nx_beg = row_ptr[nn]; nx_end = row_ptr[nn + 1];')
+            A('  };')
+            A('  auto pre_rows = [&](int lane_, bool live_) {')
+            A('    const int ne = live_ ? max(0, min(32, nx_end - nx_beg)) : 0, el = max(nx_beg, nx_end - 1);')
+            A('    const bool he = nx_end > nx_beg;')
+            A('#pragma unroll')
+            A('    for (int tl = 0; tl < 2; ++tl) {')
+            A('      const int ea = min(nx_beg + row_edge(ne, tl, lane_ & 15), el);')
+            A('      nx_wra[tl] = he ? (w_row ? w_row[ea] : ea) : 0;')
+            A('      nx_srs[tl] = he ? src[min(nx_beg + row_edge(ne, tl, lane_ >> 2), el)] : 0;')
+            A('    }')
+            A('  };')
+        A('  for (unsigned vb = blockIdx.x; vb < (unsigned)n_groups; vb += gridDim.x) {')
+        A('  int tid_ = threadIdx.x;')
+        A('  asm volatile("" : "+v"(tid_));   // opaque per iteration: nothing lane-derived is hoisted out of the loop (and kept live across it)')
+        A('  const int tid = tid_, lane = tid & 63, wave = tid >> 6;')
+        A('  const int c = lane & 15, g = lane >> 4;')
+        A('  const int n_raw = snet::xcd_node(vb, (unsigned)n_groups) * NWV + wave;')
+    else:
+        A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
+        A('  const int c = lane & 15, g = lane >> 4;')
+        A('  const int n_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
+    # Phase stamps of the FORWARD kernel (SNET_CODEGEN_OPTS=stampf=<tag>, stampfl=<tag> the light form: one stamp per tile instead of
+    # two per path tile), same device array and read-back as the reverse kernel's; a row per destination node
+    STFL = OPTS.get('stampfl') == tag
+    STF = OPTS.get('stampf') == tag or STFL
+    if STF:
+        A('  unsigned ph[16];')
+        A('#pragma unroll')
+        A('  for (int i = 0; i < 16; ++i) ph[i] = 0u;')
+        A('  unsigned t_prev;')
+        A('  { unsigned long long t0_; asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t0_) :: "memory"); t_prev = (unsigned)t0_; }')
+        A('  auto stamp = [&](int i) {')
+        A('    __builtin_amdgcn_sched_barrier(0);')
+        A('    unsigned long long t_; asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");')
+        A('    const unsigned tn = (unsigned)t_;')
+        A('    ph[i] += tn - t_prev;')
+        A('    t_prev = tn;')
+        A('    __builtin_amdgcn_sched_barrier(0);')
+        A('  };')
+
+    def SF(i, ind, light=True):
+        if STF and (light or not STFL):
+            A(f'{ind}stamp({i});')
     A('  const bool live = n_raw < n_nodes;')
     A('  const int node = __builtin_amdgcn_readfirstlane(live ? n_raw : n_nodes - 1);')
-    A('  const int e_beg = row_ptr[node], e_end = row_ptr[node + 1];')
+    if FPRE:
+        A('  if (pre_stage < 1) pre_idx(vb, wave);')
+        A('  if (pre_stage < 2) pre_rows(lane, live);')
+        A('  pre_stage = 0;')
+        A('  const bool has_next = vb + gridDim.x < (unsigned)n_groups;')
+        A('  const int e_beg = nx_beg, e_end = nx_end;')
+    else:
+        A('  const int e_beg = row_ptr[node], e_end = row_ptr[node + 1];')
     A('  const int my_pass = live ? (e_end - e_beg + 31) >> 5 : 0;')
     A('  if (lane == 0) s_pass[wave] = my_pass;')
     A('  __syncthreads();')
     A('  int n_pass = 1;  // every wave of the block walks the weight stream the same number of times')
     A('#pragma unroll')
     A('  for (int i = 0; i < NWV; ++i) n_pass = max(n_pass, s_pass[i]);')
+    SF(0, '  ')
     # block staging: sub-steps s0 .. s0 + n - 1, only their w parts (LPF lines each)
     A('  u32x4 st[GLDS ? 1 : NSTB];')
     A('  auto stage_load = [&](int s0, int n, int b) {  // the w parts of sub-steps s0 .. s0 + n - 1 -> slab[b]')
@@ -1236,14 +1324,26 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    const int eb = e_beg + 32 * pass;')
     A('    const int n_e = live ? max(0, min(32, e_end - eb)) : 0;  // edges of this pass: tile 0 = [0,16), tile 1 = [16,32)')
     A('    const bool two = n_e > 16;')
+    if FROW:
+        # Row r of lane group g of a tile holds the tile's edge g R + r, R = ceil(m / 4) for a tile of m edges (R = 4: the identity).
+        # A diamond-cubic atom has 28 neighbours: its second tile holds 12 edges in rows {0, 1, 2} of every group, and the
+        # tensor-product bodies skip row 3 in all 64 lanes (one eighth of the pass's vector work).
+        A('    const int m_t[2] = {min(n_e, 16), max(n_e - 16, 0)};')
+        A('    const int rows_t[2] = {(m_t[0] + 3) >> 2, (m_t[1] + 3) >> 2};')
+        A('    auto edge_of_row = [&](int tl, int row) { return 16 * tl + (row >> 2) * rows_t[tl] + (row & 3); };  // (rows r >= R alias a neighbour\'s edge: never used)')
+    else:
+        A('    auto edge_of_row = [&](int tl, int row) { return 16 * tl + row; };')
     A('    // per tile: A fragments of h2 (row = edge lane & 15) and the source row this lane stages (edge lane >> 2)')
     A('    SplitN<NT> ha[2][2];')
     A('    int srs[2];')
     A('    float w_unscale[2] = {1.f, 1.f};  // fp16 terms: h2 is scaled per 16-edge tile (wave-uniform), W2 per matrix on the host')
     A('#pragma unroll')
     A('    for (int tl = 0; tl < 2; ++tl) {')
-    A('      const int ea = min(eb + 16 * tl + c, e_last);')
-    A('      const int wra = has_e ? (w_row ? w_row[ea] : ea) : 0;')
+    A('      const int ea = min(eb + edge_of_row(tl, c), e_last);')
+    if FPRE:
+        A('      const int wra = pass == 0 ? nx_wra[tl] : (has_e ? (w_row ? w_row[ea] : ea) : 0);')
+    else:
+        A('      const int wra = has_e ? (w_row ? w_row[ea] : ea) : 0;')
     A('      float hv[2][8];')
     A('#pragma unroll')
     A('      for (int q = 0; q < 2; ++q) {')
@@ -1266,17 +1366,33 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('      }')
     A('      ha[tl][0] = splitn8<NT, F16>(hv[0]);')
     A('      ha[tl][1] = splitn8<NT, F16>(hv[1]);')
-    A('      srs[tl] = has_e ? src[min(eb + 16 * tl + (lane >> 2), e_last)] : 0;')
+    if FPRE:
+        A('      srs[tl] = pass == 0 ? nx_srs[tl] : (has_e ? src[min(eb + edge_of_row(tl, lane >> 2), e_last)] : 0);')
+    else:
+        A('      srs[tl] = has_e ? src[min(eb + edge_of_row(tl, lane >> 2), e_last)] : 0;')
     A('    }')
     A('    for (int i = lane; i < 32 * NSH; i += 64) {')
     A('      const int el = i / NSH;')
-    A('      s_ys[wave][el * NSHP + (i - el * NSH)] = has_e ? sh[(size_t)min(eb + el, e_last) * NSH + (i - el * NSH)] : 0.f;')
+    A('      s_ys[wave][el * NSHP + (i - el * NSH)] = has_e ? sh[(size_t)min(eb + edge_of_row(el >> 4, el & 15), e_last) * NSH + (i - el * NSH)] : 0.f;')
     A('    }')
     first_n = len(fgroups[0][0])
-    A(f'    stage_load(0, {first_n}, 0);')
-    A(f'    stage_store({first_n}, 0);')
-    A('    __syncthreads();  // also orders the wave\'s s_ys stores before its reads')
-    A('    int sidx = 0, buf = 0;')
+    if FPRE:
+        A('    if (!slab_ready) {   // the very first pass of the workgroup; later ones find their first block requested by the previous pass')
+        A(f'      stage_load(0, {first_n}, 0);')
+        A(f'      stage_store({first_n}, 0);')
+        A('      __syncthreads();')
+        A('      slab_ready = true; cbuf = 0;')
+        A('    }')
+        A('    __builtin_amdgcn_wave_barrier();  // the wave\'s s_ys stores before its reads (wave-private rows)')
+        SF(1, '    ')
+        A('    int sidx = 0, buf = cbuf, blk = 0;')
+        A('    const bool more = pass + 1 < n_pass || has_next;   // another pass of this workgroup follows')
+    else:
+        A(f'    stage_load(0, {first_n}, 0);')
+        A(f'    stage_store({first_n}, 0);')
+        A('    __syncthreads();  // also orders the wave\'s s_ys stores before its reads')
+        SF(1, '    ')
+        A('    int sidx = 0, buf = 0;')
     A(f'    f32x4 xq[{MAXD1}];  // the next stage\'s slice, in flight: lane L holds channels 4 (L & 3) .. + 3 of edge L >> 2')
 
     def emit_x_loads(ind, ci_, ct_expr, tl_):
@@ -1302,7 +1418,12 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 nxt = f'(ct + 1 < {nct} ? {n_first} : {n_next_cat})'
             ol = olists[(ci, gi)]
             A('      {')
-            A(f'        const int n_next = (sidx + {n_here} < NS) ? {nxt} : 0;')
+            if FPRE:
+                A(f'        const int n_next = (sidx + {n_here} < NS) ? {nxt} : (more ? {first_n} : 0);')
+                A(f'        const int s_next = (sidx + {n_here} < NS) ? sidx + {n_here} : 0;')
+            else:
+                A(f'        const int n_next = (sidx + {n_here} < NS) ? {nxt} : 0;')
+                A(f'        const int s_next = sidx + {n_here};')
             A('        const u32x4 *sl = slab[buf];')
             for _, pr in grp:
                 for pi in pr:
@@ -1342,18 +1463,20 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                     A('            }')
                     # the next block's weight fragments are requested AFTER the slice prefetch: vmcnt retires in order,
                     # and the wait in front of the next slice store must not also wait for a slab that was just requested
-                    A(f'            if (n_next) stage_load(sidx + {n_here}, n_next, buf ^ 1);')
+                    A('            if (n_next) stage_load(s_next, n_next, buf ^ 1);')
                 else:
                     emit_next_block_loads('            ')
                 A('            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch up here')
                 A('            __builtin_amdgcn_wave_barrier();')
                 A('          }')
+                SF(2, '          ')
                 A(f'          float xr[4][{d1}];')
                 A('#pragma unroll')
                 A('          for (int r = 0; r < 4; ++r)')
                 A('#pragma unroll')
                 A(f'            for (int m = 0; m < {d1}; ++m) xr[r][m] = s_x[wave][m * 256 + r * 64 + lane];')
                 A(f'          const float *ysl = &s_ys[wave][(16 * {tl} + 4 * g) * NSHP];')
+                SF(3, '          ')
                 # kernel-tuning knob, measured neutral (7.83 / 7.94 vs 7.75 ms per step over the three middle layers): weight
                 # fragments of a path tile requested one path tile ahead (fpf: 1 = its first k-step, 2 = both), so that the
                 # LDS latency in front of each chain of matrix products overlaps the previous tensor-product body
@@ -1400,9 +1523,15 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                         A(f'              wv = mfma16_split<NT, F16>(ha[{tl}][q], bfr, wv);')
                         A('            }')
                     A('#pragma unroll')
-                    A(f'            for (int r = 0; r < 4; ++r) wv[r] = (16 * {tl} + 4 * g + r < n_e) ? (F16 ? wv[r] * w_unscale[{tl}] : wv[r]) : 0.f;')
-                    A(f'            if (!(diag & 1)) fwdf_p{pi}(xr, ysl, wv, acc{pi});  // opaque branch: see the reverse kernel')
+                    if FROW:
+                        A(f'            for (int r = 0; r < 4; ++r) wv[r] = (r < rows_t[{tl}] && g * rows_t[{tl}] + r < m_t[{tl}]) ? (F16 ? wv[r] * w_unscale[{tl}] : wv[r]) : 0.f;')
+                    else:
+                        A(f'            for (int r = 0; r < 4; ++r) wv[r] = (16 * {tl} + 4 * g + r < n_e) ? (F16 ? wv[r] * w_unscale[{tl}] : wv[r]) : 0.f;')
+                    SF(4, '            ', light=False)
+                    A(f'            if (!(diag & 1)) fwdf_p{pi}(xr, ysl, wv, acc{pi}, {f"rows_t[{tl}]" if FROW else "4"});  // opaque branch: see the reverse kernel')
+                    SF(5, '            ', light=False)
                     A('          }')
+                SF(5, '          ', light=STFL)
                 A('        }')
             # reduce over the 4 edge groups, park in LDS, write out with 16-byte stores
             for q, (pi, m3) in enumerate(ol):
@@ -1421,13 +1550,30 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A('          if (pass) v += *reinterpret_cast<const f32x4 *>(o);')
                 A('          *reinterpret_cast<f32x4 *>(o) = v;')   # (streaming stores here: measured neutral, round 4)
                 A('        }')
+            SF(6, '        ')
             A('        if (n_next) stage_store(n_next, buf ^ 1);')
+            SF(7, '        ')
             A('        __syncthreads();')
+            SF(8, '        ')
             A('        buf ^= 1;')
             A(f'        sidx += {n_here};')
+            if FPRE:
+                A('        if (pass == 0 && has_next) {   // the next group\'s indices, one dependent level per block')
+                A('          if (blk == 0) { pre_idx(vb + gridDim.x, wave); pre_stage = 1; }')
+                A('          else if (blk == 1) { pre_rows(lane, snet::xcd_node(vb + gridDim.x, (unsigned)n_groups) * NWV + wave < n_nodes); pre_stage = 2; }')
+                A('        }')
+                A('        ++blk;')
             A('      }')
         A('    }')
+    if FPRE:
+        A('    cbuf = buf;   // the buffer the next pass\'s first block was requested into')
     A('  }')
+    if STF:
+        A('  if (lane == 0 && live && n_raw < SNET_STAMP_TILES) {')
+        A('    for (int i = 0; i < 16; ++i) snet_stamps[n_raw * 16 + i] = ph[i];')
+        A('  }')
+    if FPERS:
+        A('  }')
     A('}')
     A('')
 
@@ -1506,7 +1652,12 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('template <int NT, bool F16, int NWV, bool GLDS, int OCC>')
     A('void launch_fwd_t(const float *x, const float *sh, const float *h2, const int32_t *w_row, const int32_t *row_ptr,')
     A('                  const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, int w2_exp, hipStream_t st) {')
-    A('  const unsigned grid = (unsigned)((n_dst + NWV - 1) / NWV);')
+    A('  unsigned grid = (unsigned)((n_dst + NWV - 1) / NWV);')
+    if FPERS:
+        A('  static int n_cu = 0;')
+        A('  if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256; }')
+        A(f'  const unsigned cap = (unsigned)(n_cu / 8 * 8) * (NWV >= 12 ? 1u : NWV >= 6 ? 2u : 4u) * {FPERS}u;')
+        A('  if (grid > cap) grid = cap;')
     A('  int diag = 0;')
     if exp:
         A('  if (const char *e = getenv("SNET_FV_DIAG")) diag = atoi(e);')
@@ -1551,7 +1702,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A(f'const snet::FusedKernels kernels = {{"{tag}", DX, DOUT, NSH, WN, NS, SUB_COLS, {len(cols_rev)}, SUB_COLS_B, GXE_CHUNK, launch_bwd, launch_fwd, {1 if XT else 0}}};')
     A('const snet::FusedRegistrar registrar(&kernels);')
     A('}  // namespace')
-    if OPTS.get('stamp') == tag or OPTS.get('stampl') == tag:
+    if tag in (OPTS.get('stamp'), OPTS.get('stampl'), OPTS.get('stampf'), OPTS.get('stampfl')):
         A('// out[0 .. 15] = per-phase cycle sums over the tiles of the LAST launch, out[31] = number of tiles that reported')
         A('extern "C" int snet_debug_stamps(unsigned long long *out, int reset) {')
         A('  static unsigned *host = nullptr;')

@@ -203,7 +203,7 @@ def main():
             os.environ['SNET_FV_DIAG'] = parts[3] if len(parts) > 3 else '0'
         fn()
         torch.cuda.synchronize()
-        stamps = a.stamps and 'conv_bwd_fused' in name and hasattr(lib, 'snet_debug_stamps')
+        stamps = a.stamps and ('conv_bwd_fused' in name or 'conv_fwd_fused' in name) and hasattr(lib, 'snet_debug_stamps')
         if stamps:
             lib.snet_debug_stamps(None, 1)
         ts = []
@@ -230,6 +230,10 @@ def main():
             names = ['prologue', 'block top', 'sub-step top (slab request)', 'tile 0: w products', 'tile 0: tensor product',
                      'tile 1: w products', 'tile 1: tensor product', 'split + g_h2 products', 'slab park (vmcnt + ds_write)',
                      'workgroup barrier', 'block end (stores, park, rows)', 'tail A', 'tail B', 'dY epilogue', '-', '-']
+            if 'conv_fwd_fused' in name:   # stampf / stampfl builds: the forward kernel's phases, one row per destination node
+                names = ['prologue (row pointers, pass count)', 'pass top (h2 split, Y, first slab, barrier)', 'slice store + next slice / slab requests',
+                         'slice read back (LDS)', 'w products (fragments + matrix)', 'tensor-product bodies', 'reduce, park, output stores',
+                         'slab park (vmcnt + ds_write)', 'workgroup barrier'] + ['-'] * 7
             print(f'    stamps: {int(waves)} wave-launches, {tot / waves:9.0f} cycles per wave')
             for i in range(14):
                 print(f'    phase {i:2d} {names[i]:34s} {v[i] / waves:9.0f} cycles per wave  {100 * v[i] / tot:5.1f} %')
