@@ -157,3 +157,31 @@ def test_work_list_format_per_shape():
         assert ('s_g[NWV][2][NGP * 16 + 16]' in src) == packed   # two g_out sets, 16 floats apart, only in the packed form
     assert mode == {'22d6a77ad5ac': 1, 'ecc5d202727d': 0, '005c575f8ec2': 0, '0b99ee053764': 0, '1cad2f51cbd0': 0, '2d3e65aea6f3': 0,
                     '0431c055196e': 0, '707b9944ff82': 0, '502c5bba8e99': 1}
+
+
+def test_tuning_options_are_off_by_default_and_generate(monkeypatch):
+    """The kernel-tuning generator options (phase stamps of either kernel, long-lived forward workgroups, index prefetch) are
+    experiments with committed measurements: none of them may leak into the shipped source, each must still generate,
+    and the one forward-kernel change that shipped (short tiles spread over the lane groups, `frow`) must be what the default emits."""
+    from sevennet_amd import codegen
+    spec = SPECS['22d6a77ad5ac']
+    base = codegen_fused.gen_conv_fused(spec)
+    fwd = base[base.index('void conv_fwdf_'):]
+    assert 'stamp(' not in base and 'snet_stamps' not in base and 'snet_debug_stamps' not in base
+    assert 'vb += gridDim.x' not in base and 'pre_rows' not in base
+    assert 'rows_t[2]' in fwd and 'edge_of_row(tl, c)' in fwd and 'rows > 3' in base          # frow on
+    assert base.count('const int rows)') == len(spec.paths)                                      # every forward body takes the row count
+    for opts, must in (({'frow': '0'}, ['return 16 * tl + row; }']),
+                       ({'stampf': spec.tag}, ['snet_debug_stamps', 'snet_stamps[n_raw * 16 + i]']),
+                       ({'stampl': spec.tag}, ['snet_debug_stamps', 'snet_stamps[t_raw * 16 + i]']),
+                       ({'fpers': '1'}, ['vb += gridDim.x', 'hipDeviceAttributeMultiprocessorCount']),
+                       ({'fpers': '1', 'fpre': '1'}, ['pre_rows(lane, live)', 'cbuf = buf;', 'more ? '])):
+        for k, v in opts.items():
+            monkeypatch.setitem(codegen.OPTS, k, v)
+        src = codegen_fused.gen_conv_fused(spec)
+        for m in must:
+            assert m in src, (opts, m)
+        assert src.count('{') == src.count('}'), opts
+        for k in opts:
+            monkeypatch.delitem(codegen.OPTS, k)
+    assert codegen_fused.gen_conv_fused(spec) == base
