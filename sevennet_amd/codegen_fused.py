@@ -348,6 +348,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     # forward kernel: a tile with m <= 12 edges keeps ceil(m / 4) accumulator rows per lane group instead of filling groups in turn
     # (SNET_CODEGEN_OPTS=frow=0: the previous row order; middle layers 2.79 -> 2.73 ms same box, profiles/r05_ab_forward_variants.txt)
     FROW = bool(int(OPTS.get('frow', 1)))
+    FRSB = int(OPTS.get('frsb', 0))   # scheduler fence between the rows of a forward body with >= frsb Clebsch-Gordan entries (0: none)
     PK = bool(int(OPTS['pk'])) if 'pk' in OPTS else ((bool(int(OPTS['xtile'])) if 'xtile' in OPTS else _xt_auto))
     # ------------------------------------------------------------------ per-path device functions
     for pi, p in enumerate(spec.paths):
@@ -392,6 +393,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             for i in range(d3):
                 A(f'    acc[{i}] = fmaf(w[{r}], s{i}, acc[{i}]);')
             A('  }')
+            if r < 3 and FRSB and len(terms) >= FRSB:
+                A('  __builtin_amdgcn_sched_barrier(0);   // one row at a time: the rows\' temporaries are not interleaved (register pressure of the large paths)')
         A('}')
     A('')
 
@@ -1195,6 +1198,14 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  constexpr int NSTB = (LPB * LPF * 64 + NTH - 1) / NTH;')
     A('  __shared__ u32x4 slab[2][LPB * LPF * 64];')
     A('  __shared__ int s_pass[NWV];')
+    # Output-row offsets of every (x block, path group, 16-entry chunk): one register per chunk, live for the whole kernel.  The lmax-3
+    # shapes have 13 .. 25 of them (SevenNet-0: 5) beside 228 .. 256 other live registers -- MF-ompa's middle layer spilled 24 --, so
+    # where there are more than 8 the table lives in LDS and a lane reads its entry at the store (round 5).
+    N_OOFF = sum((sum(2 * spec.paths[pi].l3 + 1 for _, pr in grp for pi in pr if pi is not None) + 15) // 16 for gl in fgroups for grp in gl)
+    OOLDS = N_OOFF > 8 if 'oolds' not in OPTS else bool(int(OPTS['oolds']))
+    oo_rows, oo_index = [], {}
+    if OOLDS:
+        A(f'  __shared__ int32_t s_ooff[{16 * N_OOFF}];')
     A('  __shared__ __attribute__((aligned(16))) float s_ys[NWV][32 * NSHP];  // spherical harmonics of the pass\'s edges (rows padded: NSHP)')
     A(f'  __shared__ __attribute__((aligned(16))) float s_x[NWV][{MAXD1} * 256];  // source-row slice of one tile: [m][r][g][channel]')
     A(f'  __shared__ __attribute__((aligned(16))) float s_o[NWV][{NOEP} * 16];      // output rows of one block: [entry][channel]')
@@ -1279,6 +1290,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     else:
         A('  const int e_beg = row_ptr[node], e_end = row_ptr[node + 1];')
     A('  const int my_pass = live ? (e_end - e_beg + 31) >> 5 : 0;')
+    oo_fill_at = len(L)
     A('  if (lane == 0) s_pass[wave] = my_pass;')
     A('  __syncthreads();')
     A('  int n_pass = 1;  // every wave of the block walks the weight stream the same number of times')
@@ -1317,8 +1329,16 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             olists[(ci, gi)] = ol
             for k in range((len(ol) + 15) // 16):
                 offs = [out_index(spec.paths[ol[q][0]], ol[q][1]) if q < len(ol) else -1 for q in range(16 * k, 16 * k + 16)]
-                A(f'  static const int32_t OOFF{ci}_{gi}_{k}[16] = {{' + ', '.join(str(o) for o in offs) + '};')
-                A(f'  const int ooff{ci}_{gi}_{k} = OOFF{ci}_{gi}_{k}[lane >> 2];')
+                if OOLDS:
+                    oo_index[(ci, gi, k)] = len(oo_rows)
+                    oo_rows.append(offs)
+                else:
+                    A(f'  static const int32_t OOFF{ci}_{gi}_{k}[16] = {{' + ', '.join(str(o) for o in offs) + '};')
+                    A(f'  const int ooff{ci}_{gi}_{k} = OOFF{ci}_{gi}_{k}[lane >> 2];')
+    if OOLDS:
+        assert len(oo_rows) == N_OOFF
+        L[oo_fill_at] = (f'  static const int32_t OOFF_ALL[{16 * N_OOFF}] = {{' + ', '.join(str(o) for row in oo_rows for o in row) + '};\n'
+                         + f'  for (int i = tid; i < {16 * N_OOFF}; i += NTH) s_ooff[i] = OOFF_ALL[i];   // (ordered by the s_pass barrier below)\n' + L[oo_fill_at])
     # flat block schedule: first sub-step index and size of every block, in stream order
     A('  for (int pass = 0; pass < n_pass; ++pass) {')
     A('    const int eb = e_beg + 32 * pass;')
@@ -1544,8 +1564,12 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A('        }')
             A('        __builtin_amdgcn_wave_barrier();')
             for k in range((len(ol) + 15) // 16):
-                A(f'        if (live && ooff{ci}_{gi}_{k} >= 0) {{')
-                A(f'          float *o = onode + ooff{ci}_{gi}_{k} + 16 * ct;')
+                if OOLDS:
+                    A(f'        if (const int oo_ = s_ooff[{16 * oo_index[(ci, gi, k)]} + (lane >> 2)]; live && oo_ >= 0) {{')
+                    A('          float *o = onode + oo_ + 16 * ct;')
+                else:
+                    A(f'        if (live && ooff{ci}_{gi}_{k} >= 0) {{')
+                    A(f'          float *o = onode + ooff{ci}_{gi}_{k} + 16 * ct;')
                 A(f'          f32x4 v = *reinterpret_cast<const f32x4 *>(&s_o[wave][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]);')
                 A('          if (pass) v += *reinterpret_cast<const f32x4 *>(o);')
                 A('          *reinterpret_cast<f32x4 *>(o) = v;')   # (streaming stores here: measured neutral, round 4)
@@ -1677,7 +1701,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_fwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
             A(f'  if (nt == 4 && vw == {w} && vg == {gl} && vo == {oc}) return launch_fwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
     def fwd_lds(nt, nwv):
-        return 2 * LPB * 4 * nt * 1024 + nwv * (32 * NSHP * 4 + MAXD1 * 1024 + NOEP * 64) + 4 * nwv
+        return 2 * LPB * 4 * nt * 1024 + nwv * (32 * NSHP * 4 + MAXD1 * 1024 + NOEP * 64) + 4 * nwv + (64 * N_OOFF if OOLDS else 0)
 
     def fwd_cfg(nt):
         # measured: occupancy decides -- one 12-wave workgroup per CU at <= 168 VGPRs (3 waves per SIMD, direct
