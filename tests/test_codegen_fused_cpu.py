@@ -185,3 +185,25 @@ def test_tuning_options_are_off_by_default_and_generate(monkeypatch):
         for k in opts:
             monkeypatch.delitem(codegen.OPTS, k)
     assert codegen_fused.gen_conv_fused(spec) == base
+
+
+def test_forward_short_tile_row_order():
+    """The forward kernel's row order (`edge_of_row` / `row_edge` in the generated source): edge k of a tile of m edges sits in row
+    4 (k // R) + k % R with R = ceil(m / 4).  What the kernel relies on: every edge has exactly one row, no row r >= R of any lane group
+    holds an edge (so the bodies may skip it in all 64 lanes), the weight mask `g R + r < m` marks exactly the occupied rows, and a
+    full tile keeps the identity order."""
+    for m in range(0, 17):
+        R = (m + 3) // 4
+        rows = {}
+        for row in range(16):
+            g, r = row >> 2, row & 3
+            k = g * R + r                      # edge_of_row(tl, row) - 16 tl
+            if r < R and k < m:                # the kernel's mask: r < rows_t && g * rows_t + r < m_t
+                assert k not in rows
+                rows[k] = row
+        assert sorted(rows) == list(range(m))                       # every edge exactly once
+        assert all((row & 3) < R for row in rows.values())          # nothing in the skipped rows
+        if m == 16:
+            assert all(rows[k] == k for k in range(16))
+        if m == 12:                                                 # the diamond-cubic second tile: rows {0, 1, 2} of every group
+            assert sorted(rows.values()) == [4 * g + r for g in range(4) for r in range(3)]
