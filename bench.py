@@ -98,7 +98,8 @@ def parse():
                          "hands over), 'edges' (the fp32 edge vectors [E,3], round-2 behaviour), 'none' (inputs resident)")
     ap.add_argument('--no-h2d', action='store_true', help="same as --h2d none")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-reps', type=int, default=6, help='CPU-baseline sample: cells per axis (6 -> 1728 atoms, 11 -> 10 648)')
+    ap.add_argument('--cpu-reps', type=int, default=11, help='CPU-baseline sample: cells per axis (11 -> the 10 648-atom cell of BASELINE '
+                    'config 2, SURVEY.md 8(d), ~4 min; 6 -> only the 1728-atom cell that picks the thread count, ~1 min)')
     return ap.parse_args()
 
 
@@ -219,40 +220,61 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(cfg, sd, reps):
-    """The oracle = this repo's CPU restatement of the reference's e3nn/PyTorch path, fp32, on a bounded sample
-    (default 6^3 cells = 1728 atoms; `--cpu-reps 11` times the 10 648-atom cell of BASELINE config 2, ~4 min).
-    Timed with BOTH thread counts SURVEY.md 8(d) names -- every physical core of the box, and the 32 threads that
-    were the best setting found for this eager many-small-ops workload -- two evaluations each after a warm-up;
-    the faster one is `value` with its thread count in `cores`, the other is reported next to it."""
+def cpu_baseline(cfg, sd, reps, small_reps=6):
+    """The oracle = this repo's CPU restatement of the reference's e3nn/PyTorch path, fp32, on a bounded sample.
+    Two legs:
+      * the small cell (`small_reps`^3 cells = 1728 atoms) at BOTH thread counts SURVEY.md 8(d) names -- every physical core of the
+        box, and the 32 threads that were the best setting found for this eager many-small-ops workload -- three evaluations each
+        after a warm-up: picks the thread count and keeps the rounds 1-5 figure comparable (`small_sample`);
+      * the cell SURVEY.md 8(d) asks the CPU baseline on -- `reps` = 11: the 10 648-atom cell of BASELINE config 2 -- at the faster
+        thread count, three evaluations after a warm-up (~4 min on the GPU box's EPYC): this is `value`.
+    `--cpu-reps 6` skips the second leg (value = the small cell's figure)."""
     from oracle.model import OracleModel
     from sevennet_amd.neighbor import diamond_cubic, neighbor_list
-    pos, cell = diamond_cubic(5.431, (reps,) * 3, 0.05, 2)
-    ei, ev, _ = neighbor_list(pos, cell, [True] * 3, cfg['cutoff'])
-    types = species_of(cfg, len(pos))
     m = OracleModel(cfg, sd, dtype=torch.float32, modal='mpa' if cfg.get('use_modality') else None)
     default_threads = torch.get_num_threads()
     phys = physical_cores()
-    runs = {}
-    for threads in sorted({min(32, phys), phys}):
+    n_eval = 3
+
+    def cell(r):
+        pos, cell_ = diamond_cubic(5.431, (r,) * 3, 0.05, 2)
+        ei, ev, _ = neighbor_list(pos, cell_, [True] * 3, cfg['cutoff'])
+        return pos, ei, ev, species_of(cfg, len(pos))
+
+    def timed(threads, types, ei, ev):
         torch.set_num_threads(threads)
         m.forward(types, ei, ev)  # warm-up
-        n_eval = 2
-        t0 = time.perf_counter()
+        ts = []
         for _ in range(n_eval):
+            t0 = time.perf_counter()
             m.forward(types, ei, ev)
-        dt = time.perf_counter() - t0
-        runs[threads] = (len(pos) * n_eval / dt, n_eval, dt)
-    torch.set_num_threads(default_threads)
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    pos_s, ei_s, ev_s, types_s = cell(min(small_reps, reps))
+    runs = {}
+    for threads in sorted({min(32, phys), phys}):
+        ts = timed(threads, types_s, ei_s, ev_s)
+        runs[threads] = (len(pos_s) * n_eval / sum(ts), ts)
     best = max(runs, key=lambda k: runs[k][0])
-    rate, n_eval, dt = runs[best]
+    small = dict(atoms=len(pos_s), edges=int(ei_s.shape[1]), value=runs[best][0], cores=best,
+                 by_threads={str(k): round(v[0], 1) for k, v in runs.items()},
+                 evaluation_s={str(k): [round(t, 2) for t in v[1]] for k, v in runs.items()})
+    if reps > small_reps:
+        pos, ei, ev, types = cell(reps)
+        ts = timed(best, types, ei, ev)
+        rate, n_at, n_ed = len(pos) * n_eval / sum(ts), len(pos), int(ei.shape[1])
+    else:
+        ts, rate, n_at, n_ed = runs[best][1], runs[best][0], len(pos_s), int(ei_s.shape[1])
+    torch.set_num_threads(default_threads)
     return dict(value=rate, unit='atom-steps/s', cores=best, kind='port', cpu=cpu_model_name(),
-                logical_cpus=os.cpu_count(), physical_cores=phys,
-                by_threads={str(k): round(v[0], 1) for k, v in runs.items()},
-                sample=f'SevenNet-0 shape, {len(pos)}-atom Si cell ({ei.shape[1]} edges), {n_eval} energy+force '
-                       f'evaluations in {dt:.1f} s after one warm-up, fp32 torch CPU oracle (oracle/model.py), '
+                logical_cpus=os.cpu_count(), physical_cores=phys, evaluations=n_eval, evaluation_s=[round(t, 2) for t in ts],
+                by_threads=small['by_threads'], small_sample=small,
+                sample=f'SevenNet-0 shape, {n_at}-atom Si cell ({n_ed} edges), {n_eval} energy+force '
+                       f'evaluations in {sum(ts):.1f} s after one warm-up, fp32 torch CPU oracle (oracle/model.py), '
                        f'{best} torch threads on {cpu_model_name()} ({phys} physical cores, {os.cpu_count()} logical CPUs); '
-                       f'atom-steps/s by thread count: ' + ', '.join(f'{k}: {v[0]:.0f}' for k, v in runs.items()))
+                       f'thread count chosen on the {len(pos_s)}-atom cell, atom-steps/s by thread count there: '
+                       + ', '.join(f'{k}: {v[0]:.0f}' for k, v in runs.items()))
 
 
 def main():
@@ -455,6 +477,17 @@ def main():
     t_enq = time.perf_counter() - t0  # host time to enqueue K steps (kernels run asynchronously)
     fence()
     dt = time.perf_counter() - t0
+    # Shader clock / socket power / temperature this line was measured under (sevennet_amd/telemetry.py: librocm_smi64 on a side
+    # thread): the two dominant kernels run at the socket's power cap, so a 5 % swing between boxes is a clock swing unless shown
+    # otherwise.  Sampled over a REPEAT of the same K steps right behind the timed bracket, not inside it: the first version sampled
+    # inside and one step of twenty took 61 instead of 39.8 ms (the SMU query contends with command submission).
+    from sevennet_amd.telemetry import Sampler
+    with Sampler(dev_id) as tele:
+        t0t = time.perf_counter()
+        for i in range(a.steps):
+            step()
+        fence()
+        tele_ms = (time.perf_counter() - t0t) / a.steps * 1e3
     per_step = torch.tensor([marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)], device=dev, dtype=torch.float64)
     if dist_mode:   # a step is over when the slowest rank is
         dist.all_reduce(per_step, op=dist.ReduceOp.MAX)
@@ -584,10 +617,11 @@ def main():
         res = {
             'metric': 'atom-steps/sec (energy+forces), SevenNet-0 100k-atom cell, 1/2/4/8 MI355X' if a.model == 'sevennet_0'
             else f'atom-steps/sec (energy+forces), {a.model} shape',
-            # value: SURVEY.md 8(d)'s statistic -- atoms / MEDIAN step time of the K timed steps (per-step HIP events, max over ranks);
-            # ms_per_step: the contract's bracket -- wall time of the K steps between two fences / K (max over ranks); value_mean from it
-            'value': n_atoms / (step_ms_median * 1e-3), 'unit': 'atom-steps/s', 'n_gpus': world, 'steps': a.steps,
-            'warmup': a.warmup, 'ms_per_step': step_ms, 'ms_per_step_median': step_ms_median, 'value_mean': n_atoms * a.steps / dt,
+            # value: the contract's bracket -- atoms x K / wall time of the K steps between two fences (max over ranks), = atoms /
+            # ms_per_step (rounds 1-4 and the driver's own clock use this statistic).  value_median: SURVEY.md 8(d)'s
+            # statistic -- atoms / MEDIAN step time (per-step HIP events, max over ranks) -- beside it
+            'value': n_atoms * a.steps / dt, 'unit': 'atom-steps/s', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': step_ms, 'ms_per_step_median': step_ms_median, 'value_median': n_atoms / (step_ms_median * 1e-3),
             'ms_per_step_min_max': [float(per_step.min()), float(per_step.max())],
             'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': DTYPE_LABEL[a.terms if a.fused != 'off' else 0], 'data': 'synthetic',
@@ -620,7 +654,9 @@ def main():
                        # torch fill kernels (main-stream classes only: '@side' brackets overlap the others)
                        'non_kernel_ms_per_step_rank0': round(step_ms_median - sum(v for k, v in totals.items() if not k.startswith('halo') and not k.endswith('@side')) / n_break, 3),
                        'dispatches_per_step_rank0': int(sum(c for k, c in counts.items() if not k.startswith('halo')) / n_break),
-                       'energy': float(e_total.cpu())},
+                       'energy': float(e_total.cpu()),
+                       # the box this line was measured on: medians over the timed region (rank 0's GPU)
+                       **tele.summary(), 'telemetry_pass_ms_per_step': round(tele_ms, 3)},
             'roofline': roof,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -33,8 +33,19 @@ ARCH = 'gfx950'
 STATIC_SOURCES = ['snet_api.cpp', 'snet_model.cpp', 'snet_halo.cpp', 'snet_gemm.hip', 'snet_mlp.hip', 'snet_edge.hip', 'snet_node.hip', 'snet_force.hip', 'snet_neighbor.hip', 'snet_md.hip', 'snet_d3.hip', 'snet_d3_ref.cpp']
 
 
+def _rocm_root() -> str:
+    """ROCM_PATH, else the prefix of the hipcc on PATH, else /opt/rocm"""
+    env = os.environ.get('ROCM_PATH')
+    if env and os.path.isdir(env):
+        return env
+    exe = shutil.which('hipcc')
+    if exe:
+        return os.path.dirname(os.path.dirname(os.path.realpath(exe)))
+    return '/opt/rocm'
+
+
 def _hipcc() -> str:
-    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    exe = shutil.which('hipcc') or os.path.join(_rocm_root(), 'bin', 'hipcc')
     if not os.path.exists(exe):
         raise RuntimeError('hipcc not found; the HIP force engine cannot be built')
     return exe
@@ -119,7 +130,7 @@ def build_lammps_harness(verbose: bool = True) -> str:
     gxx = shutil.which('g++')
     if gxx is None:
         raise RuntimeError('g++ not found: the LAMMPS mock harness cannot be built')
-    rocm = '/opt/rocm'
+    rocm = _rocm_root()
     cmd = [gxx, '-std=c++17', '-O1', '-D__HIP_PLATFORM_AMD__', f'-I{mock}', f'-I{INCLUDE}', f'-I{rocm}/include'] + srcs + \
         ['-o', out, f'-L{os.path.dirname(LIB)}', '-l:' + os.path.basename(LIB), f'-L{rocm}/lib', '-lamdhip64',
          '-Wl,-rpath,$ORIGIN/../../sevennet_amd', f'-Wl,-rpath,{rocm}/lib']

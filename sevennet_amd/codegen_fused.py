@@ -120,29 +120,6 @@ def _emit_staging(A, lines: str):
     A('  };')
 
 
-def _emit_staging_groups(A):
-    """grouped form (one workgroup barrier per GROUP of up to GLN sub-steps): stage_load(s, n, b) requests the fragment lines of
-    sub-steps s .. s + n - 1 (consecutive in the stream), stage_store(n, b) parks them in slab[b]"""
-    A('  constexpr int NSTG = (GLN * LPS * 64 + NTH - 1) / NTH;')
-    A('  u32x4 st[GLDS ? 1 : NSTG];')
-    A('  auto stage_load = [&](int s, int n, int b) {')
-    A('    if constexpr (GLDS) {')
-    A('      for (int l = wave; l < n * LPS; l += NWV)')
-    A('        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(slabs + (size_t)s * (LPS * 64) + l * 64 + lane),')
-    A('                                         (__attribute__((address_space(3))) void *)(&slab[b][l * 64]), 16, 0, 0);')
-    A('    } else {')
-    A('#pragma unroll')
-    A('      for (int i = 0; i < NSTG; ++i) if (tid + NTH * i < n * LPS * 64) st[i] = slabs[(size_t)s * (LPS * 64) + tid + NTH * i];')
-    A('    }')
-    A('  };')
-    A('  auto stage_store = [&](int n, int b) {')
-    A('    if constexpr (!GLDS) {')
-    A('#pragma unroll')
-    A('      for (int i = 0; i < NSTG; ++i) if (tid + NTH * i < n * LPS * 64) slab[b][tid + NTH * i] = st[i];')
-    A('    }')
-    A('  };')
-
-
 def reverse_plan(p):
     """Nonzero pattern the reverse tensor-product body walks: per x component a, per output component c,
     the spherical-harmonic components b it couples with and C[a,b,c] (incl. the sqrt(2 l3 + 1) path norm)."""
@@ -251,40 +228,6 @@ def _emit_reverse_body_pk(A, pi, p):
     A('}')
 
 
-def _emit_reverse_body_v1(A, pi, p, terms, byab):
-    """round-2 formulation (SNET_CODEGEN_OPTS=tpold=1, kept for A/B runs): one (a, b) entry at a time,
-    U_ab = sum_c C[a,b,c] G_c consumed at once by the three products it feeds (g_w, d/dY_b, d/dx_a)"""
-    d1, d2, d3 = 2 * p.l1 + 1, 2 * p.l2 + 1, 2 * p.l3 + 1
-    A('template <bool GX>')
-    A(f'__device__ __forceinline__ void bwdf_p{pi}(const f32x4 (&xr)[{d1}], const float (&ys)[NSH], const f32x4 w,')
-    A(f'    const f32x4 (&G)[{d3}], f32x4 &gw, float (&gy)[NSH], f32x4 (&gx)[{d1}]) {{')
-    for r in range(4):
-        A(f'  {{  // channel {r} of the lane\'s group')
-        A('    float gw_ = 0.f;')
-        for i in range(d2):
-            A(f'    float sy{i} = 0.f;')
-        for i in range(d1):
-            A(f'    float sx{i} = 0.f;')
-        for (a_, b_), cl in sorted(byab.items()):
-            yb = p.sh_off + b_
-            tl = [f'{_f(v)} * G[{cc}][{r}]' for cc, v in cl]
-            A('    {')
-            A(f'      const float U = {_sum_expr(tl)};')
-            A(f'      const float t = U * xr[{a_}][{r}];')
-            A(f'      gw_ = fmaf(t, ys[{yb}], gw_);')
-            A(f'      sy{b_} += t;')
-            A(f'      sx{a_} = fmaf(U, ys[{yb}], sx{a_});')
-            A('    }')
-        A(f'    gw[{r}] = gw_;')
-        A(f'    const float w_ = w[{r}];')
-        for b_ in sorted({b_ for (_, b_) in byab}):
-            A(f'    gy[{p.sh_off + b_}] = fmaf(w_, sy{b_}, gy[{p.sh_off + b_}]);')
-        for a_ in sorted({a_ for (a_, _) in byab}):
-            A(f'    gx[{a_}][{r}] = fmaf(w_, sx{a_}, gx[{a_}][{r}]);')
-        A('  }')
-    A('}')
-
-
 def gen_conv_fused(spec: ConvSpec) -> str:
     tag = spec.tag
     # default configuration of the two kernels: (waves per workgroup, direct global->LDS staging, waves per SIMD the
@@ -362,10 +305,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             byab.setdefault((a_, b_), []).append((cc, v))
         if PK:
             _emit_reverse_body_pk(A, pi, p)
-        elif not OPTS.get('tpold'):
-            _emit_reverse_body(A, pi, p)
         else:
-            _emit_reverse_body_v1(A, pi, p, terms, byab)
+            _emit_reverse_body(A, pi, p)
         # ---- forward: lane = channel, the 4 edges of the lane's group in the vector components
         A(f'__device__ __forceinline__ void fwdf_p{pi}(const float (&xr)[4][{d1}], const float *ysl, const f32x4 w,')
         A(f'    float (&acc)[{d3}], const int rows) {{')
@@ -412,9 +353,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  // diag: always 0 in production (bit 0 also serves as the opaque branch condition around the tensor-product bodies);')
     A('  // kernel-tuning builds: 1 skip the tensor product, 2 skip the g_h2 products, 4 skip the w products, 8 skip the')
     A('  // g_out loads, 16 skip the g_xe stores -- timing decomposition, results are then garbage')
-    # Barrier groups (round 4, SNET_CODEGEN_OPTS=bgrp=<n>): the sub-steps of a block are walked in groups of up to BG; one slab of
-    # GLN sub-steps is staged and one workgroup barrier paid per GROUP instead of per sub-step (BG = 1: the round-3 form)
-    BG = max(1, int(OPTS.get('bgrp', 1)))
     # Phase stamps (SNET_CODEGEN_OPTS=stamp=<tag>, kernel-tuning builds only): s_memtime at the phase boundaries of the reverse kernel,
     # per-phase cycle sums of every wave added to the device array snet_stamps (read back by snet_debug_stamps; tools/microbench.py
     # --stamps).  Every stamp drains the wave's LDS counter and fences the scheduler, so the instrumented kernel runs ~10 % slower
@@ -425,27 +363,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     STL = OPTS.get('stampl') == tag
     ST = OPTS.get('stamp') == tag or STL
     NPH = 16
-    # In-wave software pipeline of the sub-steps (SNET_CODEGEN_OPTS=pipe=<n>; round 5).  The phases of a sub-step -- fragments from
-    # LDS, chained matrix products, the tensor-product body on their result -- are a serial latency chain per wave, and two waves per
-    # SIMD do not cover it (SQ counters: 63 % of the wave cycles parked or issue-stalled with every pipe below 35 %).  pipe >= 1: the w
-    # products of the sub-step's SECOND tile are issued inside the (opaque-branch) region of the FIRST tile's body, so the compiler
-    # interleaves the independent matrix chain with the body's vector instructions.  pipe >= 2: the g_h2 products of the PREVIOUS
-    # sub-step (operand split kept in 8 registers, its slab kept alive by a third LDS buffer) join that region too: 18 of the 24
-    # matrix instructions of a sub-step and their LDS round trips run under the vector work.
-    PIPE = int(OPTS.get('pipe', 0))
-    SGB = int(OPTS.get('sgb', 0))     # pipe + sgb=<n>: sched_group_barrier pattern [1 matrix, <= n vector] over the first body's region
-    F16_DEFAULT = True                # (pattern sized for the f16x3 mode: 3 matrix instructions per product)
-
-    def body_valu(p_):
-        n = 0
-        for a_, cl_ in reverse_plan(p_):
-            n += 4 + 8
-            for c_, bl_ in cl_:
-                n += len(bl_) + 4 + 4 + len(bl_)
-        return n
-    NBUF = 3 if PIPE >= 2 else 2
-    NB = '(buf ^ 1)' if NBUF == 2 else '(buf == 2 ? 0 : buf + 1)'
-
     def S(i, ind='      '):
         if ST and (not STL or i in (0, 1, 10, 11, 12, 13)):
             A(f'{ind}stamp({i});')
@@ -462,13 +379,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     _live2 = 12 * max(2 * c_.l1 + 1 for c_ in cats) + 32 + NSH + 8 * (_ngp // 16) + 16 + 4 * max(2 * p_.l3 + 1 for p_ in spec.paths) + 35
     XT = bool(int(OPTS['xtile'])) if 'xtile' in OPTS else (_live2 <= 200 and _live2 - 4 * (_ngp // 16) > 168 and len(cats) > 1)
     GS = 2 if XT else 1
-    while BG > 1 and 2 * min(BG, max(len(b_['steps']) for b_ in _bs0)) * 8 * 2 * 1024 + 8 * (2 * _ngp * 64 + NSH * 64) > 150 * 1024:
-        BG -= 1   # the slabs of one 8-wave workgroup per CU must fit the LDS beside the waves' private buffers
-    GLN = min(BG, max(len(b_['steps']) for b_ in _bs0))
-    if GLN == 1:
-        BG = 1
-    A(f'  constexpr int LPS = 8 * NT, NTH = 64 * NWV, NST = (LPS * 64 + NTH - 1) / NTH, GLN = {GLN};  // 1-KB fragment lines per sub-step; sub-steps per slab')
-    A(f'  __shared__ u32x4 slab[{NBUF}][GLN * LPS * 64];')
+    A('  constexpr int LPS = 8 * NT, NTH = 64 * NWV, NST = (LPS * 64 + NTH - 1) / NTH, GLN = 1;  // 1-KB fragment lines per sub-step; sub-steps per slab')
+    A('  __shared__ u32x4 slab[2][GLN * LPS * 64];')
     A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
     A('  const int j = lane & 15, g = lane >> 4;')
     if ST:
@@ -488,20 +400,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     # Prologue order: every load is requested as soon as its address is known -- the first weight slab at once, the
     # node's g_out entries with the row pointers, the first source rows with h2 -- so the tile pays four dependent
     # memory latencies (tile -> node -> edge -> rows) instead of seven before its first matrix product.
-    if BG > 1:
-        _emit_staging_groups(A)
-        A(f'  stage_load(0, {min(BG, len(_bs0[0]["steps"]))}, 0);')
-    else:
-        _emit_staging(A, 'LPS')
-        A('  stage_load(0, 0);')
-    # Stagger experiment (SNET_CODEGEN_OPTS=stag=<n>; round 5): all workgroups of a launch start together and do the same amount of
-    # work, so their memory phases (block boundaries) and compute phases may stay aligned across the whole chip for the entire launch.
-    # stag = n delays the second workgroup of every CU of the FIRST generation (blocks 256 .. 511) by n x 8128 cycles once.
-    STAG = int(OPTS.get('stag', 0))
-    if STAG:
-        A('  if (blockIdx.x >= 256u && blockIdx.x < 512u) {')
-        A(f'    for (int i_ = 0; i_ < {STAG}; ++i_) __builtin_amdgcn_s_sleep(127);')
-        A('  }')
+    _emit_staging(A, 'LPS')
+    A('  stage_load(0, 0);')
     A('  const int t_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
     A('  const bool live = t_raw < n_tiles;')
     A('  const int t = __builtin_amdgcn_readfirstlane(live ? t_raw : n_tiles - 1);  // idle waves shadow the last tile, stores masked')
@@ -549,7 +449,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     _budget -= 24   # margin: the estimate is a lower bound of what hipcc's allocator ends up with
     XPF = VMORD and len(bsched) > 1 and _live + _xp_regs + 8 <= _budget and not OPTS.get('noxpf')
     # the hoisted slab request keeps the staging registers live across the block boundary: same budget rule
-    HOIST = VMORD and _live + 16 + 8 <= _budget and not OPTS.get('nohoist') and BG == 1   # (grouped staging requests a whole block ahead anyway)
+    HOIST = VMORD and _live + 16 + 8 <= _budget and not OPTS.get('nohoist')
     A(f'  constexpr int NGP = {NGP}, NK = {NK}, NSUB = {NSB};   // NSUB: sub-steps of the reverse kernel\'s weight stream')
     if XT:
         # (one buffer per node, not two per block parity: the entries of the next block are parked after this block's last read, and a
@@ -663,7 +563,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('#pragma unroll')
     A('  for (int k = 0; k < NSH; ++k) gy[k] = 0.f;')
     emit_g_park('  ', 0, '0')
-    A('  stage_store(0);' if BG == 1 else f'  stage_store({min(BG, len(bsched[0]["steps"]))}, 0);')
+    A('  stage_store(0);')
     A('  __syncthreads();')
     if HOIST:
         A('  if (1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(1, 1);   // the first block\'s first sub-step does not request its slab itself')
@@ -681,11 +581,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    g_unsc = snet::pow2f(-(kg + tail.w2_exp));')
     A('  }')
     A('  int sidx = 0, buf = 0, gbuf = 0;')
-    if PIPE >= 2:
-        A('  const u32x4 *slp = slab[0];   // slab of the previous sub-step (first one: any finite fragments, times a zero operand)')
-        A('  SplitN<NT> bprev;')
-        A('#pragma unroll')
-        A('  for (int tm = 0; tm < NT; ++tm) bprev.t[tm] = as_bf16x8(u32x4{0u, 0u, 0u, 0u});')
     S(0, '  ')
     for ci, bs in enumerate(bsched):
         cat, U, ncb = bs['cat'], bs['U'], bs['ncb']
@@ -704,16 +599,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A(f'  const float *xs{ci + 1}p = x + (size_t)s_src * DX + {cat_n.x_off} + 4 * g;')
             A(f'  f32x4 xp{ci + 1}[{U_n}][{d1_n}];')
         A(f'  for (int cb = 0; cb < {ncb}; ++cb) {{')
-        groups = [bs['steps'][i:i + BG] for i in range(0, len(bs['steps']), BG)]   # barrier groups of this block (BG = 1: one per sub-step)
-
-        def next_group_size(gi):
-            """C expression: number of sub-steps of the group that follows group gi of this block in the stream (0 at its end)"""
-            if gi + 1 < len(groups):
-                return str(len(groups[gi + 1]))
-            after = min(BG, len(bsched[ci + 1]['steps'])) if ci + 1 < len(bsched) else 0
-            return f'(cb + 1 < {ncb} ? {len(groups[0])} : {after})' if ncb > 1 else str(after)
-        if BG > 1:   # the slab of the group after this block's first one: requested before the gathers of the block top, a group ahead
-            A(f'    stage_load(sidx + {len(groups[0])}, ' + ('(diag & 32) ? 0 : ' if exp else '') + f'{next_group_size(0)}, buf ^ 1);')
         A(f'    f32x4 (&xr)[{U}][{d1}] = xr{ci};')
         A(f'    f32x4 gx[{U}][{d1}];')
         for u in range(U):
@@ -755,120 +640,35 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         S(1, '    ')
         for si_, (ta, tb) in enumerate(bs['steps']):
             A('    {')
-            gi_, pos_ = si_ // BG, si_ % BG       # barrier group of this sub-step and its place inside it
-            if BG > 1:
-                if pos_ == 0 and gi_ > 0:         # (group 0: requested at the block top)
-                    A(f'      stage_load(sidx + {len(groups[gi_])}, ' + ('(diag & 32) ? 0 : ' if exp else '') + f'{next_group_size(gi_)}, buf ^ 1);')
-            elif not (HOIST and si_ == 0):   # (first sub-step of a block: requested at the end of the previous block / the prologue)
-                A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + f') stage_load(sidx + 1, {NB});')
+            if not (HOIST and si_ == 0):   # (first sub-step of a block: requested at the end of the previous block / the prologue)
+                A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, (buf ^ 1));')
             # hipcc's machine scheduler, left alone, sinks the prefetch loads next to their use (zero overlap) and
             # interleaves the phases until ~200 VGPRs spill: pin the prefetch at the top and fence the phases
             A('      __builtin_amdgcn_sched_barrier(0);')
             S(2)
-            A('      const u32x4 *sl = slab[buf]' + (f' + {pos_} * (LPS * 64);' if BG > 1 else ';'))
+            A('      const u32x4 *sl = slab[buf];')
             A('      f32x4 gw0 = f32x4{0.f, 0.f, 0.f, 0.f}, gw1 = gw0;')
-            # kernel-tuning knobs, both measured neutral on MI355X (SevenNet-0 middle layer): wfirst = both tiles' weight
-            # products before the first tensor-product body (6.38 vs 6.26 ms); gpf = the g-part fragments requested
-            # before the tensor-product bodies (+30 VGPRs: only fits two waves per SIMD, 6.72 vs 6.73 ms at three)
-            wfirst, gpf = bool(OPTS.get('wfirst')), bool(OPTS.get('gpf'))
-            if wfirst:
-                for tp, tl_ in enumerate((ta, tb)):
-                    if tl_ is None:
-                        continue
-                    A(f'      f32x4 wv{tp} = f32x4{{0.f, 0.f, 0.f, 0.f}};')
-                    A('#pragma unroll')
-                    A('      for (int q = 0; q < 2; ++q) {')
-                    A('        bf16x8 a[NT];')
-                    A('#pragma unroll')
-                    A(f'        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
-                    A(f'        wv{tp} = mfma16_split<NT, F16>(a, hb[q], wv{tp});')
-                    A('      }')
-                    A(f'      if constexpr (F16) wv{tp} *= w_unscale;')
-            if gpf:
-                A('      bf16x8 ag[4][NT];')
-                A('#pragma unroll')
-                A('      for (int m = 0; m < 4; ++m)')
-                A('#pragma unroll')
-                A('        for (int tm = 0; tm < NT; ++tm) ag[m][tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
-            if wfirst or gpf:
-                A('      __builtin_amdgcn_sched_barrier(0);')
-            def w_chain(ind, tp, dst):
-                A('#pragma unroll')
-                A(f'{ind}for (int q = 0; q < 2; ++q) {{')
-                A(f'{ind}  bf16x8 a[NT];')
-                A('#pragma unroll')
-                A(f'{ind}  for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
-                A(f'{ind}  {dst} = mfma16_split<NT, F16>(a, hb[q], {dst});')
-                A(f'{ind}}}')
-
-            def g_products(ind, slab_, b_):
-                A('#pragma unroll')
-                A(f'{ind}for (int m = 0; m < 4; ++m) {{')
-                A(f'{ind}  bf16x8 a[NT];')
-                A('#pragma unroll')
-                A(f'{ind}  for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8({slab_}[(4 * NT + m * NT + tm) * 64 + lane]);')
-                A(f'{ind}  ga[m] = mfma16_split<NT, F16>(a, {b_}, ga[m]);')
-                A(f'{ind}}}')
-            if PIPE:
-                A('      f32x4 wv0 = f32x4{0.f, 0.f, 0.f, 0.f}, wv1 = wv0;')
-                w_chain('      ', 0, 'wv0')
-                A('      if constexpr (F16) wv0 *= w_unscale;')
-                for tp, tl_ in enumerate((ta, tb)):
-                    if tl_ is None:
-                        continue
-                    pi, u = tl_
-                    p = spec.paths[pi]
-                    d3 = 2 * p.l3 + 1
-                    A(f'      {{  // tile {tp}: path {pi}, channel tile {U} cb + {u}')
-                    A(f'        f32x4 G[{d3}];')
-                    for m3 in range(d3):
-                        A(f'        G[{m3}] = *reinterpret_cast<const f32x4 *>(gl_ + {g_row(ci, pi, m3, u)} * 16);')
-                    A('        float ys[NSH];')
-                    for b_ in range(2 * p.l2 + 1):
-                        A(f'        ys[{p.sh_off + b_}] = yl[{(p.sh_off + b_) * 16}];')
-                    A('        if (!(diag & 1)) {')
-                    if tp == 0:   # independent matrix chains join the first body's region
-                        if PIPE >= 2:
-                            g_products('          ', 'slp', 'bprev')
-                        if tb is not None:
-                            w_chain('          ', 1, 'wv1')
-                    A(f'          bwdf_p{pi}<GX>(xr[{u}], ys, wv{tp}, G, gw{tp}, gy, gx[{u}]);')
-                    if tp == 0 and SGB:
-                        # prescribe the interleave: one matrix instruction, then the vector instructions that fit its shadow
-                        n_m = (3 if F16_DEFAULT else 6) * ((4 if PIPE >= 2 else 0) + (2 if tb is not None else 0))
-                        n_v = body_valu(p)
-                        per = max(1, min(SGB, n_v // max(n_m, 1)))
-                        for _ in range(n_m):
-                            A('          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);')
-                            A(f'          __builtin_amdgcn_sched_group_barrier(0x002, {per}, 0);')
-                    A('        }')
-                    if tp == 0 and tb is not None:
-                        A('        if constexpr (F16) wv1 *= w_unscale;')
-                    A('      }')
-            for tp, tl_ in enumerate(() if PIPE else (ta, tb)):
+            for tp, tl_ in enumerate((ta, tb)):
                 if tl_ is None:
                     continue
                 pi, u = tl_
                 p = spec.paths[pi]
                 d3 = 2 * p.l3 + 1
                 A(f'      {{  // tile {tp}: path {pi}, channel tile {U} cb + {u}')
-                if wfirst:
-                    A(f'        const f32x4 wv = wv{tp};')
-                else:
-                    A('        f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
-                    if exp:
-                        A('        if (diag & 4) wv = f32x4{yl[0], yl[16], yl[32], yl[48]}; else')
-                    A('#pragma unroll')
-                    A('        for (int q = 0; q < 2; ++q) {')
-                    A('          bf16x8 a[NT];')
-                    A('#pragma unroll')
-                    A(f'          for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
-                    A('          wv = mfma16_split<NT, F16>(a, hb[q], wv);')
-                    A('        }')
-                    A('        if constexpr (F16) wv *= w_unscale;')
-                    if ST and not STL:
-                        A('        asm volatile("" :: "v"(wv[0]), "v"(wv[3]));')
-                    S(3 + 2 * tp, '        ')
+                A('        f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
+                if exp:
+                    A('        if (diag & 4) wv = f32x4{yl[0], yl[16], yl[32], yl[48]}; else')
+                A('#pragma unroll')
+                A('        for (int q = 0; q < 2; ++q) {')
+                A('          bf16x8 a[NT];')
+                A('#pragma unroll')
+                A(f'          for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
+                A('          wv = mfma16_split<NT, F16>(a, hb[q], wv);')
+                A('        }')
+                A('        if constexpr (F16) wv *= w_unscale;')
+                if ST and not STL:
+                    A('        asm volatile("" :: "v"(wv[0]), "v"(wv[3]));')
+                S(3 + 2 * tp, '        ')
                 A(f'        f32x4 G[{d3}];')
                 for m3 in range(d3):
                     A(f'        G[{m3}] = *reinterpret_cast<const f32x4 *>(gl_ + {g_row(ci, pi, m3, u)} * 16);')
@@ -879,12 +679,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 # straight-line code hipcc's scheduler interleaves it with the surrounding matrix products and
                 # loads until ~200 VGPRs spill to scratch (measured: 692 spilled registers without the branch, 0 with)
                 A(f'        gw{tp} = f32x4{{0.f, 0.f, 0.f, 0.f}};')
-                if OPTS.get('nobr'):   # kernel-tuning: the body fenced by scheduler barriers instead of the opaque branch
-                    A('        __builtin_amdgcn_sched_barrier(0);')
-                    A(f'        bwdf_p{pi}<GX>(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
-                    A('        __builtin_amdgcn_sched_barrier(0);')
-                else:
-                    A(f'        if (!(diag & 1)) bwdf_p{pi}<GX>(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
+                A(f'        if (!(diag & 1)) bwdf_p{pi}<GX>(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
                 if ST and not STL:
                     A(f'        asm volatile("" :: "v"(gw{tp}[0]), "v"(gw{tp}[3]));')
                 S(4 + 2 * tp, '        ')
@@ -895,41 +690,29 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A('        for (int i = 0; i < 8; ++i) v[i] *= g_sc;')
             A('      }')
             A('      const SplitN<NT> b = splitn8<NT, F16>(v);')
-            if PIPE >= 2:
-                A('      bprev = b;')
-                A('      slp = sl;')
             if exp:
                 A('      if (diag & 2) ga[0] += f32x4{v[0], v[1], v[4], v[5]}; else')
             A('#pragma unroll')
-            A('      for (int m = 0; m < ' + ('0' if PIPE >= 2 else '4') + '; ++m) {')
-            if gpf:
-                A('        ga[m] = mfma16_split<NT, F16>(ag[m], b, ga[m]);')
-            else:
-                A('        bf16x8 a[NT];')
-                A('#pragma unroll')
-                A('        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
-                A('        ga[m] = mfma16_split<NT, F16>(a, b, ga[m]);')
+            A('      for (int m = 0; m < 4; ++m) {')
+            A('        bf16x8 a[NT];')
+            A('#pragma unroll')
+            A('        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
+            A('        ga[m] = mfma16_split<NT, F16>(a, b, ga[m]);')
             A('      }')
-            if BG > 1:
-                if pos_ == len(groups[gi_]) - 1:   # last sub-step of its group: park the next group's slab, one barrier
-                    A(f'      stage_store(' + ('(diag & 32) ? 0 : ' if exp else '') + f'{next_group_size(gi_)}, buf ^ 1);')
-                    A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
-                    A('      buf ^= 1;')
-            else:
-                if ST and not STL:
-                    A('      asm volatile("" :: "v"(ga[0][0]), "v"(ga[1][0]), "v"(ga[2][0]), "v"(ga[3][0]));')
-                S(7)
-                A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + f') stage_store({NB});')
-                S(8)
-                A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
-                S(9)
-                A(f'      buf = {NB};')
+            if ST and not STL:
+                A('      asm volatile("" :: "v"(ga[0][0]), "v"(ga[1][0]), "v"(ga[2][0]), "v"(ga[3][0]));')
+            S(7)
+            A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_store((buf ^ 1));')
+            S(8)
+            A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
+            S(9)
+            A('      buf = (buf ^ 1);')
             A('      ++sidx;')
             A('    }')
         if STL:
             A('    stamp(9);   // (light stamps: all sub-steps of the block)')
         if HOIST:   # the next block's first sub-step: its slab request goes out BEFORE this block's stores
-            A('    if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + f') stage_load(sidx + 1, {NB});')
+            A('    if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, (buf ^ 1));')
             A('    __builtin_amdgcn_sched_barrier(0);')
         A('    if (GX && g_xe && valid' + (' && !(diag & 16)' if exp else '') + ') {')
         for u in range(U):
@@ -967,11 +750,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A(f'      for (int m = 0; m < {d1}; ++m) xr{ci}[u][m] = xn{ci}[u][m];')
         S(10, '    ')
         A('  }')
-    if PIPE >= 2:
-        A('  {  // the last sub-step\'s g_h2 products')
-        g_products('    ', 'slp', 'bprev')
-        A('  }')
-        A('  __syncthreads();   // (the tail reuses the slab buffers)')
     if dead_x:
         A('  if (GX && g_xe && valid) {  // x blocks that feed no path get a zero gradient')
         for i in dead_x:
@@ -1209,54 +987,9 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  __shared__ __attribute__((aligned(16))) float s_ys[NWV][32 * NSHP];  // spherical harmonics of the pass\'s edges (rows padded: NSHP)')
     A(f'  __shared__ __attribute__((aligned(16))) float s_x[NWV][{MAXD1} * 256];  // source-row slice of one tile: [m][r][g][channel]')
     A(f'  __shared__ __attribute__((aligned(16))) float s_o[NWV][{NOEP} * 16];      // output rows of one block: [entry][channel]')
-    # Long-lived workgroups (SNET_CODEGEN_OPTS=fpers=1; round 5, kernel-tuning builds only).  The 12-wave forward configuration holds
-    # the whole LDS of its CU, so nothing else runs while a workgroup is in its prologue (three dependent memory latencies: 10.8 % of a
-    # wave's cycles, profiles/r05_phase_stamps_forward.txt).  fpers: one workgroup per CU walks the node groups b, b + grid, ... (same
-    # XCD: the grid is a multiple of 8).  Measured (profiles/r05_ab_forward_variants.txt): middle layers 2.72 -> 2.75 ms, i.e. nothing --
-    # the kernel draws the socket's 1 400 W cap (profiles/r05_power_probe.txt), so a removed bubble comes back as a lower clock.
-    FPERS = int(OPTS.get('fpers', 0))
-    # fpre=1 (with fpers): the next group's row pointers, radial-weight row indices and source rows are requested during the current
-    # group's first blocks, and the weight stream is treated as cyclic (the last block of a pass requests the first block of the next
-    # pass / group): a group then starts with ONE memory latency (h2, harmonics, first source rows together) and no slab barrier.
-    # Measured: middle layers 2.72 -> 2.75 ms, last layer 1.01 -> 0.97 ms, first layer (8-wave workgroups, two per CU) 0.94 -> 1.25 ms: off.
-    FPRE = bool(FPERS and int(OPTS.get('fpre', 0)))
-    if FPERS:
-        A('  const int n_groups = (n_nodes + NWV - 1) / NWV;')
-        if FPRE:
-            A('  int nx_beg = 0, nx_end = 0, nx_wra[2] = {0, 0}, nx_srs[2] = {0, 0}, pre_stage = 0, cbuf = 0;')
-            A('  bool slab_ready = false;')
-            A('  auto row_edge = [](int n_e, int tl, int row) {  // the forward kernel\'s row order of a pass of n_e edges (see edge_of_row)')
-            if FROW:
-                A('    const int m = tl ? max(n_e - 16, 0) : min(n_e, 16);')
-                A('    return 16 * tl + (row >> 2) * ((m + 3) >> 2) + (row & 3);')
-            else:
-                A('    return 16 * tl + row;')
-            A('  };')
-            A('  auto pre_idx = [&](unsigned vbn, int wave_) {')
-            A('    const int nr = snet::xcd_node(vbn, (unsigned)n_groups) * NWV + wave_;')
-            A('    const int nn = __builtin_amdgcn_readfirstlane(min(nr, n_nodes - 1));')
-            A('    nx_beg = row_ptr[nn]; nx_end = row_ptr[nn + 1];')
-            A('  };')
-            A('  auto pre_rows = [&](int lane_, bool live_) {')
-            A('    const int ne = live_ ? max(0, min(32, nx_end - nx_beg)) : 0, el = max(nx_beg, nx_end - 1);')
-            A('    const bool he = nx_end > nx_beg;')
-            A('#pragma unroll')
-            A('    for (int tl = 0; tl < 2; ++tl) {')
-            A('      const int ea = min(nx_beg + row_edge(ne, tl, lane_ & 15), el);')
-            A('      nx_wra[tl] = he ? (w_row ? w_row[ea] : ea) : 0;')
-            A('      nx_srs[tl] = he ? src[min(nx_beg + row_edge(ne, tl, lane_ >> 2), el)] : 0;')
-            A('    }')
-            A('  };')
-        A('  for (unsigned vb = blockIdx.x; vb < (unsigned)n_groups; vb += gridDim.x) {')
-        A('  int tid_ = threadIdx.x;')
-        A('  asm volatile("" : "+v"(tid_));   // opaque per iteration: nothing lane-derived is hoisted out of the loop (and kept live across it)')
-        A('  const int tid = tid_, lane = tid & 63, wave = tid >> 6;')
-        A('  const int c = lane & 15, g = lane >> 4;')
-        A('  const int n_raw = snet::xcd_node(vb, (unsigned)n_groups) * NWV + wave;')
-    else:
-        A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
-        A('  const int c = lane & 15, g = lane >> 4;')
-        A('  const int n_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
+    A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
+    A('  const int c = lane & 15, g = lane >> 4;')
+    A('  const int n_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
     # Phase stamps of the FORWARD kernel (SNET_CODEGEN_OPTS=stampf=<tag>, stampfl=<tag> the light form: one stamp per tile instead of
     # two per path tile), same device array and read-back as the reverse kernel's; a row per destination node
     STFL = OPTS.get('stampfl') == tag
@@ -1281,14 +1014,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             A(f'{ind}stamp({i});')
     A('  const bool live = n_raw < n_nodes;')
     A('  const int node = __builtin_amdgcn_readfirstlane(live ? n_raw : n_nodes - 1);')
-    if FPRE:
-        A('  if (pre_stage < 1) pre_idx(vb, wave);')
-        A('  if (pre_stage < 2) pre_rows(lane, live);')
-        A('  pre_stage = 0;')
-        A('  const bool has_next = vb + gridDim.x < (unsigned)n_groups;')
-        A('  const int e_beg = nx_beg, e_end = nx_end;')
-    else:
-        A('  const int e_beg = row_ptr[node], e_end = row_ptr[node + 1];')
+    A('  const int e_beg = row_ptr[node], e_end = row_ptr[node + 1];')
     A('  const int my_pass = live ? (e_end - e_beg + 31) >> 5 : 0;')
     oo_fill_at = len(L)
     A('  if (lane == 0) s_pass[wave] = my_pass;')
@@ -1360,10 +1086,7 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('#pragma unroll')
     A('    for (int tl = 0; tl < 2; ++tl) {')
     A('      const int ea = min(eb + edge_of_row(tl, c), e_last);')
-    if FPRE:
-        A('      const int wra = pass == 0 ? nx_wra[tl] : (has_e ? (w_row ? w_row[ea] : ea) : 0);')
-    else:
-        A('      const int wra = has_e ? (w_row ? w_row[ea] : ea) : 0;')
+    A('      const int wra = has_e ? (w_row ? w_row[ea] : ea) : 0;')
     A('      float hv[2][8];')
     A('#pragma unroll')
     A('      for (int q = 0; q < 2; ++q) {')
@@ -1386,33 +1109,18 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('      }')
     A('      ha[tl][0] = splitn8<NT, F16>(hv[0]);')
     A('      ha[tl][1] = splitn8<NT, F16>(hv[1]);')
-    if FPRE:
-        A('      srs[tl] = pass == 0 ? nx_srs[tl] : (has_e ? src[min(eb + edge_of_row(tl, lane >> 2), e_last)] : 0);')
-    else:
-        A('      srs[tl] = has_e ? src[min(eb + edge_of_row(tl, lane >> 2), e_last)] : 0;')
+    A('      srs[tl] = has_e ? src[min(eb + edge_of_row(tl, lane >> 2), e_last)] : 0;')
     A('    }')
     A('    for (int i = lane; i < 32 * NSH; i += 64) {')
     A('      const int el = i / NSH;')
     A('      s_ys[wave][el * NSHP + (i - el * NSH)] = has_e ? sh[(size_t)min(eb + edge_of_row(el >> 4, el & 15), e_last) * NSH + (i - el * NSH)] : 0.f;')
     A('    }')
     first_n = len(fgroups[0][0])
-    if FPRE:
-        A('    if (!slab_ready) {   // the very first pass of the workgroup; later ones find their first block requested by the previous pass')
-        A(f'      stage_load(0, {first_n}, 0);')
-        A(f'      stage_store({first_n}, 0);')
-        A('      __syncthreads();')
-        A('      slab_ready = true; cbuf = 0;')
-        A('    }')
-        A('    __builtin_amdgcn_wave_barrier();  // the wave\'s s_ys stores before its reads (wave-private rows)')
-        SF(1, '    ')
-        A('    int sidx = 0, buf = cbuf, blk = 0;')
-        A('    const bool more = pass + 1 < n_pass || has_next;   // another pass of this workgroup follows')
-    else:
-        A(f'    stage_load(0, {first_n}, 0);')
-        A(f'    stage_store({first_n}, 0);')
-        A('    __syncthreads();  // also orders the wave\'s s_ys stores before its reads')
-        SF(1, '    ')
-        A('    int sidx = 0, buf = 0;')
+    A(f'    stage_load(0, {first_n}, 0);')
+    A(f'    stage_store({first_n}, 0);')
+    A('    __syncthreads();  // also orders the wave\'s s_ys stores before its reads')
+    SF(1, '    ')
+    A('    int sidx = 0, buf = 0;')
     A(f'    f32x4 xq[{MAXD1}];  // the next stage\'s slice, in flight: lane L holds channels 4 (L & 3) .. + 3 of edge L >> 2')
 
     def emit_x_loads(ind, ci_, ct_expr, tl_):
@@ -1438,12 +1146,8 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 nxt = f'(ct + 1 < {nct} ? {n_first} : {n_next_cat})'
             ol = olists[(ci, gi)]
             A('      {')
-            if FPRE:
-                A(f'        const int n_next = (sidx + {n_here} < NS) ? {nxt} : (more ? {first_n} : 0);')
-                A(f'        const int s_next = (sidx + {n_here} < NS) ? sidx + {n_here} : 0;')
-            else:
-                A(f'        const int n_next = (sidx + {n_here} < NS) ? {nxt} : 0;')
-                A(f'        const int s_next = sidx + {n_here};')
+            A(f'        const int n_next = (sidx + {n_here} < NS) ? {nxt} : 0;')
+            A(f'        const int s_next = sidx + {n_here};')
             A('        const u32x4 *sl = slab[buf];')
             for _, pr in grp:
                 for pi in pr:
@@ -1497,51 +1201,17 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A(f'            for (int m = 0; m < {d1}; ++m) xr[r][m] = s_x[wave][m * 256 + r * 64 + lane];')
                 A(f'          const float *ysl = &s_ys[wave][(16 * {tl} + 4 * g) * NSHP];')
                 SF(3, '          ')
-                # kernel-tuning knob, measured neutral (7.83 / 7.94 vs 7.75 ms per step over the three middle layers): weight
-                # fragments of a path tile requested one path tile ahead (fpf: 1 = its first k-step, 2 = both), so that the
-                # LDS latency in front of each chain of matrix products overlaps the previous tensor-product body
-                fpf = int(OPTS.get('fpf', 0))
                 chain = [(ls, tp, pi) for ls, pr in grp for tp, pi in enumerate(pr) if pi is not None]
-
-                def frag_reads(ind, k, q, dst):
-                    ls_, tp_, _ = chain[k]
-                    A(f'{ind}for (int tm = 0; tm < NT; ++tm) {dst}[tm] = as_bf16x8(sl[(({ls_ - grp[0][0]} * 4 + {tp_} * 2 + {q}) * NT + tm) * 64 + lane]);')
-                if fpf:
-                    A('          bf16x8 bn0[NT]' + (', bn1[NT]' if fpf > 1 else '') + ';')
-                    A('#pragma unroll')
-                    frag_reads('          ', 0, 0, 'bn0')
-                    if fpf > 1:
-                        A('#pragma unroll')
-                        frag_reads('          ', 0, 1, 'bn1')
                 for k, (ls, tp, pi) in enumerate(chain):
                     A(f'          {{  // sub-step {ls} of the block, tile {tp}: path {pi}')
                     A('            f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
-                    if fpf:
-                        A('            bf16x8 b0[NT], b1[NT];')
-                        A('#pragma unroll')
-                        A('            for (int tm = 0; tm < NT; ++tm) b0[tm] = bn0[tm];')
-                        A('#pragma unroll')
-                        if fpf > 1:
-                            A('            for (int tm = 0; tm < NT; ++tm) b1[tm] = bn1[tm];')
-                        else:
-                            frag_reads('            ', k, 1, 'b1')
-                        A(f'            wv = mfma16_split<NT, F16>(ha[{tl}][0], b0, wv);')
-                        A(f'            wv = mfma16_split<NT, F16>(ha[{tl}][1], b1, wv);')
-                        if k + 1 < len(chain):
-                            A('#pragma unroll')
-                            frag_reads('            ', k + 1, 0, 'bn0')
-                            if fpf > 1:
-                                A('#pragma unroll')
-                                frag_reads('            ', k + 1, 1, 'bn1')
-                        A('            __builtin_amdgcn_sched_barrier(0);')
-                    else:
-                        A('#pragma unroll')
-                        A('            for (int q = 0; q < 2; ++q) {')
-                        A('              bf16x8 bfr[NT];')
-                        A('#pragma unroll')
-                        A(f'              for (int tm = 0; tm < NT; ++tm) bfr[tm] = as_bf16x8(sl[(({ls - grp[0][0]} * 4 + {tp} * 2 + q) * NT + tm) * 64 + lane]);')
-                        A(f'              wv = mfma16_split<NT, F16>(ha[{tl}][q], bfr, wv);')
-                        A('            }')
+                    A('#pragma unroll')
+                    A('            for (int q = 0; q < 2; ++q) {')
+                    A('              bf16x8 bfr[NT];')
+                    A('#pragma unroll')
+                    A(f'              for (int tm = 0; tm < NT; ++tm) bfr[tm] = as_bf16x8(sl[(({ls - grp[0][0]} * 4 + {tp} * 2 + q) * NT + tm) * 64 + lane]);')
+                    A(f'              wv = mfma16_split<NT, F16>(ha[{tl}][q], bfr, wv);')
+                    A('            }')
                     A('#pragma unroll')
                     if FROW:
                         A(f'            for (int r = 0; r < 4; ++r) wv[r] = (r < rows_t[{tl}] && g * rows_t[{tl}] + r < m_t[{tl}]) ? (F16 ? wv[r] * w_unscale[{tl}] : wv[r]) : 0.f;')
@@ -1581,22 +1251,12 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             SF(8, '        ')
             A('        buf ^= 1;')
             A(f'        sidx += {n_here};')
-            if FPRE:
-                A('        if (pass == 0 && has_next) {   // the next group\'s indices, one dependent level per block')
-                A('          if (blk == 0) { pre_idx(vb + gridDim.x, wave); pre_stage = 1; }')
-                A('          else if (blk == 1) { pre_rows(lane, snet::xcd_node(vb + gridDim.x, (unsigned)n_groups) * NWV + wave < n_nodes); pre_stage = 2; }')
-                A('        }')
-                A('        ++blk;')
             A('      }')
         A('    }')
-    if FPRE:
-        A('    cbuf = buf;   // the buffer the next pass\'s first block was requested into')
     A('  }')
     if STF:
         A('  if (lane == 0 && live && n_raw < SNET_STAMP_TILES) {')
         A('    for (int i = 0; i < 16; ++i) snet_stamps[n_raw * 16 + i] = ph[i];')
-        A('  }')
-    if FPERS:
         A('  }')
     A('}')
     A('')
@@ -1639,15 +1299,13 @@ def gen_conv_fused(spec: ConvSpec) -> str:
                 A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
             A(f'  if (nt == 4 && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
     def bwd_lds(nt, nwv):
-        return NBUF * GLN * 8 * nt * 1024 + nwv * (2 * NGP * 64 + (128 if XT else 0) + NSH * 64)
+        return 2 * 8 * nt * 1024 + nwv * (2 * NGP * 64 + (128 if XT else 0) + NSH * 64)
 
     def bwd_cfg(nt):
         # measured on MI355X (SevenNet-0 middle layer): three 4-wave workgroups per CU (LDS <= 53 KB each, <= 168
         # VGPRs) beat two; when the slab does not leave room for three, two 4-wave workgroups at 256 VGPRs
         if 'fnwv' in OPTS:
             return def_b
-        if GLN > 1 and bwd_lds(nt, 8) <= 150 * 1024:   # grouped staging: one 8-wave workgroup per CU shares the GLN-sub-step slabs
-            return (8, 0, 2)
         # first interaction layer (scalar inputs only, one x block): one 8-wave workgroup sharing each slab beats three
         # 4-wave ones (in the step: 1.76 vs 2.01 ms).  NOT the last layer's shape (three one-path x blocks): 8 waves
         # win its stand-alone timing (3.21 vs 3.46 ms) but lose inside the step with the hidden-layer tail (4.04 vs 3.53)
@@ -1677,11 +1335,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('void launch_fwd_t(const float *x, const float *sh, const float *h2, const int32_t *w_row, const int32_t *row_ptr,')
     A('                  const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, int w2_exp, hipStream_t st) {')
     A('  unsigned grid = (unsigned)((n_dst + NWV - 1) / NWV);')
-    if FPERS:
-        A('  static int n_cu = 0;')
-        A('  if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256; }')
-        A(f'  const unsigned cap = (unsigned)(n_cu / 8 * 8) * (NWV >= 12 ? 1u : NWV >= 6 ? 2u : 4u) * {FPERS}u;')
-        A('  if (grid > cap) grid = cap;')
     A('  int diag = 0;')
     if exp:
         A('  if (const char *e = getenv("SNET_FV_DIAG")) diag = atoi(e);')

@@ -269,6 +269,7 @@ class _FusedConvFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable   # first order only: a force-loss double backward raises instead of returning zeros
     def backward(ctx, g_out):
         mod, lib, ep, N = ctx.mod, ctx.mod.lib, ctx.ep, ctx.N
         x_im, sh_s, emb_s, h2 = ctx.saved_tensors
@@ -311,7 +312,9 @@ class _FusedConvFn(torch.autograd.Function):
 class _RadialLayer(torch.nn.Module):
     def __init__(self, h_in: int, h_out: int):
         super().__init__()
-        self.weight = torch.nn.Parameter(torch.randn(h_in, h_out))   # e3nn FullyConnectedNet layout: [h_in, h_out]
+        # e3nn FullyConnectedNet layout: [h_in, h_out].  requires_grad = False: the fused kernels return no gradient for the radial
+        # weights (inference module); a trainer that turns it on is stopped in forward() instead of training a silently frozen network
+        self.weight = torch.nn.Parameter(torch.randn(h_in, h_out), requires_grad=False)
 
 
 class _RadialWeights(torch.nn.Module):
@@ -387,6 +390,9 @@ class HipFusedIrrepsConvolution(torch.nn.Module):
         hs = list(nn_kw['hs'])
         # the instruction list of the source decides the weight-column order (sorted by output block since 0.11)
         ins = [tuple(i[:3]) for i in kw['instructions']]
+        if bool(getattr(src.denominator, 'requires_grad', False)):
+            # `train_denominator` (convolution.py:52-54): the fused module folds 1 / denominator into the kernels and returns no gradient for it
+            raise NotImplementedError('fused convolution: train_denominator is set (the fused module is inference-only)')
         ret = cls(str(kw['irreps_in1']), str(kw['irreps_in2']), str(kw['irreps_out']), hs[:-1], nn_kw['act'],
                   float(src.denominator.detach().reshape(-1)[0]), src.key_x, src.key_filter, src.key_weight_input, src.key_edge_idx,
                   getattr(src, 'is_parallel', False), sort_by_out=ins == sorted(ins, key=lambda t: t[2]), fused_terms=fused_terms)
@@ -416,7 +422,10 @@ class HipFusedIrrepsConvolution(torch.nn.Module):
 
     def _ensure_plans(self):
         ws = [getattr(self.weight_nn, f'layer{k}').weight for k in range(3)]
-        key = tuple((w.data_ptr(), w._version) for w in ws) + (float(self.denominator.detach().reshape(-1)[0]), self.fused_terms)
+        # (keyed on storage + version counters only: reading the denominator's VALUE here would be a blocking device-to-host copy in
+        # every forward call of every layer; it is read below, when the key has changed)
+        den = self.denominator
+        key = tuple((w.data_ptr(), w._version) for w in ws) + (den.data_ptr(), den._version, self.fused_terms)
         if key == self._plan_key:
             return
         self._free_plans()
@@ -439,6 +448,11 @@ class HipFusedIrrepsConvolution(torch.nn.Module):
         self._plan_key = key
 
     def forward(self, data):
+        if torch.is_grad_enabled() and (self.denominator.requires_grad
+                                        or any(getattr(self.weight_nn, f'layer{k}').weight.requires_grad for k in range(3))):
+            raise RuntimeError('HipFusedIrrepsConvolution is an inference module: it returns no gradient for weight_nn.* / denominator '
+                               '(and no double backward).  For training patch with patch_convolution(conv, fused=False), whose '
+                               'HipUvuConvolution differentiates the radial weights.')
         x = data[self.key_x]
         if self.idx_in.device != x.device:
             self.to(x.device)

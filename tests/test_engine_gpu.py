@@ -575,7 +575,10 @@ def test_bench_multi_rank_path_dry_run():
         assert sc['ok'] and sum(sc['owned_atoms_by_rank']) == one['config']['atoms'] and len(sc['ghost_rows_by_rank']) == n
         assert sc['ghost_rows_by_rank'][0] == many['config']['ghost_rows_rank0'] and min(sc['peers_by_rank']) >= 1
         # value = atoms / median step; the contract's bracket (mean) rides along
-        assert many['ms_per_step_median'] > 0 and abs(many['value'] - many['config']['atoms'] / (many['ms_per_step_median'] * 1e-3)) < 1e-6 * many['value']
+        # value = the contract's bracket (atoms / ms_per_step); the median-based statistic sits beside it
+        assert many['ms_per_step_median'] > 0 and abs(many['value'] - many['config']['atoms'] / (many['ms_per_step'] * 1e-3)) < 1e-6 * many['value']
+        assert abs(many['value_median'] - many['config']['atoms'] / (many['ms_per_step_median'] * 1e-3)) < 1e-6 * many['value_median']
+        assert 'sclk_mhz' in many['config'] and 'socket_power_w' in many['config'] and many['config']['telemetry_samples'] >= 0
     # the world-1 soak of the N > 1 path on REAL RCCL: the communicator reports itself (ncclCommCount)
     soak = run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
                 '--master-port', '29613', 'bench.py', '--gpus', '1', '--dist-path', '--halo', 'native'] + common)

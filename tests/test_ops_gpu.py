@@ -400,6 +400,26 @@ def test_fused_convolution_module_vs_oracle_autograd(cfg_name, terms):
     # (rows n_loc .. N of the reference output are zero -- no edge ends there -- so the full-output gradient above is the same function)
     gx_all = torch.cat([xl.grad, xg.grad]).cpu().double()
     assert (gx_all - x64.grad).abs().max().item() < 3e-5 * max(1.0, x64.grad.abs().max().item())
+    # the fused module is inference-only, and says so instead of training a silently frozen radial network: its radial
+    # weights are created without requires_grad; turned on by a trainer, forward() raises (no-grad evaluation still works); a source
+    # convolution with a trainable denominator is refused (patch_convolution then falls back to the convolution_cls variant); a
+    # double backward (force loss) raises instead of returning zeros
+    assert not any(p.requires_grad for p in conv.parameters())
+    conv.weight_nn.layer1.weight.requires_grad_(True)
+    with pytest.raises(RuntimeError, match='inference module'):
+        conv({'x': xd.detach(), 'edge_attr': shd.detach(), 'edge_embedding': ed.detach(), 'edge_index': data['edge_index']})
+    with torch.no_grad():
+        conv({'x': xd.detach(), 'edge_attr': shd.detach(), 'edge_embedding': ed.detach(), 'edge_index': data['edge_index']})
+    conv.weight_nn.layer1.weight.requires_grad_(False)
+    stub_td = _RefConvStub(spec, ins, [nb, 64, 64, spec.weight_numel], 'silu', den)
+    stub_td.denominator.requires_grad_(True)
+    with pytest.raises(NotImplementedError, match='train_denominator'):
+        HipFusedIrrepsConvolution.from_irreps_convolution(stub_td)
+    x2 = x.to(dev).requires_grad_(True)
+    o2 = conv({'x': x2, 'edge_attr': shd.detach(), 'edge_embedding': ed.detach(), 'edge_index': data['edge_index']})['x']
+    (gx2,) = torch.autograd.grad(o2.sum(), x2, create_graph=True)
+    with pytest.raises(RuntimeError, match='once_differentiable'):
+        gx2.sum().backward()
     # shapes without fused kernels (multiplicities not multiples of 16) are refused by the fused module itself
     from sevennet_amd.model_spec import build_model_spec
     from sevennet_amd.shapes import unit_test_config

@@ -1,7 +1,7 @@
 #!/bin/bash
 # experiment library exp/libx_<name>.so built with SNET_CODEGEN_OPTS=<opts>: the object cache is seeded from the working tree's
 # build directory, so only the translation units the options change are recompiled
-#   tools/build_variant.sh pipe2 pipe=2 [extra SNET_BUILD_DEFS]
+#   tools/build_variant.sh noxt xtile=0 [extra SNET_BUILD_DEFS]
 set -e
 NAME=${1:?name}; OPTS=${2:-}; DEFS=${3:-}
 R=$(cd $(dirname $0)/.. && pwd)

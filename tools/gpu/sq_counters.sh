@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ-level counters of the fused reverse / forward kernels (one --pmc pass per group; kernel trace only)
-# GROUPS="6 7" runs only those groups (round 5: memory-path FIFO stalls, VALU / matrix co-execution)
+# GROUPS_ONLY="6 7" runs only those groups (round 5: memory-path FIFO stalls, VALU / matrix co-execution)
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/sq
 mkdir -p $OUT
