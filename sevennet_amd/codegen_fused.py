@@ -228,22 +228,252 @@ def _emit_reverse_body_pk(A, pi, p):
     A('}')
 
 
-def gen_conv_fused(spec: ConvSpec) -> str:
-    tag = spec.tag
-    # default configuration of the two kernels: (waves per workgroup, direct global->LDS staging, waves per SIMD the
-    # register allocation targets); SNET_CODEGEN_OPTS="fexp=<tag>" adds every combination for one shape, selected at
-    # run time by SNET_FV_BWD / SNET_FV_FWD="nwv,glds,occ" (kernel tuning only)
-    def_b = (int(OPTS.get('fnwv', 8)), int(OPTS.get('fglds', 0)), int(OPTS.get('focc', 2)))
-    def_f = (int(OPTS.get('fnwvf', 8)), int(OPTS.get('fgldsf', 0)), int(OPTS.get('foccf', 2)))
-    exp = OPTS.get('fexp') == tag
-    DX, DOUT, NSH, WN = spec.irreps_x.dim, spec.irreps_out.dim, spec.irreps_sh.dim, spec.weight_numel
-    cats, pairs_of, cols = schedule(spec)
-    NS = len(cols)
-    offs_x = spec.irreps_x.offsets()
-    dead_x = [i for i in range(len(spec.irreps_x)) if not any(p.i_x == i for p in spec.paths)]
+class _Gen:
+    """One shape's generator state: the spec, its two sub-step schedules, every per-shape decision (made ONCE, here) and the
+    output lines.  The emitters below are plain functions over it, in source order: header, per-path bodies, reverse kernel
+    (prologue / block top / sub-step / block end / hidden-layer tail / epilogue), forward kernel (prologue / pass top / block),
+    launchers."""
 
-    L: List[str] = []
-    A = L.append
+    def __init__(self, spec: ConvSpec):
+        self.spec = spec
+        tag = self.tag = spec.tag
+        # default configuration of the two kernels: (waves per workgroup, direct global->LDS staging, waves per SIMD the
+        # register allocation targets); SNET_CODEGEN_OPTS="fexp=<tag>" adds every combination for one shape, selected at
+        # run time by SNET_FV_BWD / SNET_FV_FWD="nwv,glds,occ" (kernel tuning only)
+        self.def_b = (int(OPTS.get('fnwv', 8)), int(OPTS.get('fglds', 0)), int(OPTS.get('focc', 2)))
+        self.def_f = (int(OPTS.get('fnwvf', 8)), int(OPTS.get('fgldsf', 0)), int(OPTS.get('foccf', 2)))
+        self.exp = OPTS.get('fexp') == tag
+        self.DX, self.DOUT, self.NSH, self.WN = spec.irreps_x.dim, spec.irreps_out.dim, spec.irreps_sh.dim, spec.weight_numel
+        NSH = self.NSH
+        cats, self.pairs_of, self.cols = schedule(spec)
+        self.cats = cats
+        self.NS = len(self.cols)
+        self.offs_x = spec.irreps_x.offsets()
+        self.dead_x = [i for i in range(len(spec.irreps_x)) if not any(p.i_x == i for p in spec.paths)]
+        self.L: List[str] = []
+        self.A = self.L.append
+        # row stride of the forward kernel's spherical-harmonics staging: the four edge groups of a wave read rows 4 apart,
+        # which for nsh = 16 (lmax 3) all fall on one LDS bank (measured: 36 % of the kernel's LDS cycles were conflicts)
+        self.NSHP = NSH + 1 if (4 * NSH) % 32 == 0 else NSH
+        self.gxe_std = bool(OPTS.get('gxestd'))   # kernel-tuning builds: standard g_xe row order (round-2 layout) for A/B runs
+        self.stamped = tag in (OPTS.get('stamp'), OPTS.get('stampl'), OPTS.get('stampf'), OPTS.get('stampfl'))
+        # forward kernel: a tile with m <= 12 edges keeps ceil(m / 4) accumulator rows per lane group instead of filling groups in turn
+        # (SNET_CODEGEN_OPTS=frow=0: the previous row order; middle layers 2.79 -> 2.73 ms same box, profiles/r05_ab_forward_variants.txt)
+        self.FROW = bool(int(OPTS.get('frow', 1)))
+        self.FRSB = int(OPTS.get('frsb', 0))   # scheduler fence between the rows of a forward body with >= frsb Clebsch-Gordan entries (0: none)
+        self._reverse_decisions()
+        self._forward_decisions()
+
+    # ---------------------------------------------------------------- decisions of the reverse kernel
+    def _reverse_decisions(self):
+        spec, cats, NSH = self.spec, self.cats, self.NSH
+        # The reverse kernel walks the weight columns in BLOCKS: one x block (cat) and U = 1 or 2 of its 16-channel tiles.  An x
+        # block with an odd number of paths leaves one path without a partner for the second 16-column tile of a sub-step;
+        # with U = 2 that path's tiles of two consecutive channel tiles share a sub-step instead (schedule_bwd): the
+        # SevenNet-0 middle layer needs 30 sub-steps instead of 34, its last layer (three one-path x blocks) 7 instead of 14.
+        bsched, cols_b = schedule_bwd(spec)
+        self.bsched, self.cols_b = bsched, cols_b
+        # the node's g_out entries a block needs, in the order its lanes fetch them: (path, output component, member tile)
+        glists = [[(pi, m3, u) for u in range(bs['U']) for pi, p in bs['cat'].paths for m3 in range(2 * p.l3 + 1)] for bs in bsched]
+        self.glists = glists
+        NGP = max((len(gl) + 15) // 16 * 16 for gl in glists)   # rows of the LDS buffer (padded to 16 entries per load)
+        NK = NGP // 16
+        self.NGP, self.NK = NGP, NK
+        maxd1 = max(2 * c_.l1 + 1 for c_ in cats)
+        maxd3 = max(2 * p_.l3 + 1 for p_ in spec.paths)
+
+        def live_regs(gs):
+            """lower bound of the kernel's live vector registers: source rows, their prefetch and their gradient (3 x 4 d1), h2^T
+            split and g_h2 accumulators (32), Y gradient, g_out prefetch (gs = 1, or 2 with packed tiles), slab staging, one path's
+            g_out entries, addresses / scales"""
+            return 12 * maxd1 + 32 + NSH + 4 * gs * NK + 16 + 4 * maxd3 + 35
+        # Packed tiles (SNET_CODEGEN_OPTS=xtile=1): a tile is a window of <= 16 consecutive CSR edges that may run from one destination
+        # node (A) into the next one that has edges (B); snet_edge_tiles_packed writes tile_ptr[t] = first edge, tile_node[2t .. 2t+1] = A, B.
+        # The wave keeps BOTH nodes' g_out entries in its LDS buffer and every edge lane reads its own node's set.
+        # Chosen per shape: the second node's prefetched entries cost 4 NK more registers, which the lmax-3 shapes (at 256 already) do
+        # not have (round 4: 20 .. 2400 spilled registers with it; estimate 227 .. 243 against 195 for the largest shape that fits).  Nor
+        # where the g_out entries are most of a block's vector-memory instructions or the shape would leave three waves per SIMD for two
+        # (same box, in the step: first layer ecc5d202727d 1.69 -> 2.03 ms, last layer 005c575f8ec2 1.50 -> 1.63 ms with packed tiles; the
+        # middle layers 5.64 -> 5.24 ms).  SNET_CODEGEN_OPTS=xtile=0 / 1 forces it.
+        packed_class = live_regs(2) <= 200 and live_regs(1) > 168 and len(cats) > 1   # two waves per SIMD, with register headroom
+        XT = self.XT = bool(int(OPTS['xtile'])) if 'xtile' in OPTS else packed_class
+        GS = self.GS = 2 if XT else 1
+        # Packed fp32 reverse bodies (round 5, `_emit_reverse_body_pk`): on by default for the same class -- the shapes that run two waves
+        # per SIMD with register headroom (SevenNet-0 middle layers 5.04 -> 4.92 ms, same box) -- and off elsewhere: the first layer's
+        # 8-wave kernel crosses 128 registers with them (127 -> 132: 1.89 -> 2.29 ms), the lmax-3 shapes at 256 registers start to
+        # spill (0 -> 6, 7 -> 37).  SNET_CODEGEN_OPTS=pk=0 / 1 forces it (profiles/r05_ab_packed_fp32_bodies.txt).
+        self.PK = bool(int(OPTS['pk'])) if 'pk' in OPTS else XT
+        # Order of the vector-memory operations (round 4).  vmcnt retires IN ORDER, and the slab fragments of the next sub-step
+        # are waited for at the end of every sub-step: whatever was issued before those slab loads -- the gathers of the next
+        # block's source rows and g_out entries, the g_xe stores of the block just finished -- is waited for with them.  So the
+        # first sub-step of a block does not request its slab itself: the request is HOISTED in front of the previous block's
+        # stores (and, for the first block, into the prologue); the long-latency operations then have two sub-steps to complete
+        # instead of (at best) one.  SNET_CODEGEN_OPTS=novmord=1 restores the round-3 order.
+        VMORD = self.VMORD = not OPTS.get('novmord')
+        self.GRAW = VMORD and not OPTS.get('nograw')    # g_out entries loaded raw, 1/denominator applied when they are parked
+        GUNC = VMORD and not OPTS.get('nogunc')         # padding entries of the g_out fetch: unconditional loads of offset 0
+        live = self.live = live_regs(GS)
+        self.three_waves = 2 * 8 * 2 * 1024 + 4 * (2 * NGP * 64 + NSH * 64) <= 53 * 1024 and live <= (160 if XT else 168)
+        if self.three_waves:
+            GUNC = GUNC and bool(OPTS.get('gunc3'))   # three-waves-per-SIMD shapes (168 registers): the unpredicated form spilled 9 there
+        self.GUNC = GUNC
+        # rows of the NEXT x block requested one block ahead (xp): only where the extra U d1 vector registers fit the budget of the
+        # occupancy this shape runs at (the lmax-3 shapes sit at 256 already and spilled 200+ registers with it)
+        budget = (168 if self.three_waves else 256) - 24   # margin: the estimate is a lower bound of what hipcc's allocator ends up with
+        xp_regs = max([4 * b_['U'] * (2 * b_['cat'].l1 + 1) for b_ in bsched[1:]] or [0])
+        self.XPF = VMORD and len(bsched) > 1 and live + xp_regs + 8 <= budget and not OPTS.get('noxpf')
+        # the hoisted slab request keeps the staging registers live across the block boundary: same budget rule
+        self.HOIST = VMORD and live + 16 + 8 <= budget and not OPTS.get('nohoist')
+        # x blocks with 2 l + 1 >= noxn get no register prefetch of the next block's source rows.  Default: the l = 3 blocks of the
+        # shapes that sit at 256 registers (round 4: with the prefetch those kernels spilled 15 .. 33 registers, and a spill reload
+        # waits for every older gather; without it 0 .. 7, l3i5 middle layer 11.22 -> 11.02 ms).  SNET_CODEGEN_OPTS=noxn=<d1> overrides
+        self.noxn = int(OPTS.get('noxn', 7 if live > 200 else 0))
+        # Phase stamps (SNET_CODEGEN_OPTS=stamp=<tag>, kernel-tuning builds only): s_memtime at the phase boundaries of the reverse kernel,
+        # per-phase cycle sums of every wave added to the device array snet_stamps (read back by snet_debug_stamps; tools/microbench.py
+        # --stamps).  Every stamp drains the wave's LDS counter and fences the scheduler, so the instrumented kernel runs ~10 % slower
+        # than the shipped one: the split between phases is what it is for.
+        # stampl=<tag>: the LIGHT form -- stamps at the block-level boundaries only (prologue, block top, the block's sub-steps as one
+        # phase [id 9], block end, tail, epilogue: ~25 stamps per tile instead of ~270), so the split between "inside the sub-steps" and
+        # "around them" is measured on a kernel that runs close to the shipped one
+        self.STL = OPTS.get('stampl') == self.tag
+        self.ST = OPTS.get('stamp') == self.tag or self.STL
+
+    def block_info(self, ci):
+        """(x block, member tiles per block, blocks, 2 l1 + 1, no register prefetch of the next block's rows) of reverse block ci"""
+        bs = self.bsched[ci]
+        d1 = 2 * bs['cat'].l1 + 1
+        return bs['cat'], bs['U'], bs['ncb'], d1, (self.noxn > 0 and d1 >= self.noxn)
+
+    def bwd_lds(self, nt, nwv):
+        return 2 * 8 * nt * 1024 + nwv * (2 * self.NGP * 64 + (128 if self.XT else 0) + self.NSH * 64)
+
+    def bwd_cfg(self, nt):
+        """(waves per workgroup, direct global->LDS staging, waves per SIMD) of the reverse kernel at nt operand terms"""
+        # measured on MI355X (SevenNet-0 middle layer): three 4-wave workgroups per CU (LDS <= 53 KB each, <= 168
+        # VGPRs) beat two; when the slab does not leave room for three, two 4-wave workgroups at 256 VGPRs
+        if 'fnwv' in OPTS:
+            return self.def_b
+        # first interaction layer (scalar inputs only, one x block): one 8-wave workgroup sharing each slab beats three
+        # 4-wave ones (in the step: 1.76 vs 2.01 ms).  NOT the last layer's shape (three one-path x blocks): 8 waves
+        # win its stand-alone timing (3.21 vs 3.46 ms) but lose inside the step with the hidden-layer tail (4.04 vs 3.53)
+        if len(self.cats) == 1 and self.bwd_lds(nt, 8) <= 80 * 1024:
+            return (8, 0, 2)
+        # three waves per SIMD only where the kernel's live state fits 168 VGPRs (live_regs above).  The SevenNet-0 middle layer
+        # needs ~200: at 168 the compiler spilled 38 registers and the spill traffic queues with the prefetch loads (round 3, same
+        # box: 6.80 ms at three waves with spills, 6.43 at two waves without)
+        if self.bwd_lds(nt, 4) <= 53 * 1024 and self.live <= (160 if self.XT else 168):   # (packed tiles: 164 estimated spilled 20 at 168)
+            return (4, 0, 3)
+        if self.bwd_lds(nt, 4) <= 80 * 1024:
+            return (4, 0, 2)
+        return (2, 0, 2)
+
+    # ---------------------------------------------------------------- decisions of the forward kernel
+    def _forward_decisions(self):
+        spec, cats = self.spec, self.cats
+        # One wavefront = one destination node, up to two 16-edge tiles per pass.  The weight stream is consumed in
+        # BLOCKS of up to FG sub-steps (all paths of one (x block, 16-channel tile) when there are <= 2 FG of them):
+        # one workgroup barrier per block; inside a block the wave walks its tiles, and for each tile stages the 16
+        # source rows' slice ONCE in wave-private LDS with d1 16-byte loads per lane (instead of 4 d1 4-byte gathers
+        # per path pair), then runs every path of the block on it.  Output rows leave through LDS too: 16-byte
+        # stores of 4 channels per lane instead of one 64-byte row segment per instruction.
+        FG = int(OPTS.get('ffg', 3))
+        fgroups = []   # per cat: list of groups, each a list of (sub-step index within the (cat, ct) block, (pa, pb))
+        for ci, cat in enumerate(cats):
+            prs = list(enumerate(self.pairs_of[ci]))
+            fgroups.append([prs[i:i + FG] for i in range(0, len(prs), FG)])
+        self.fgroups = fgroups
+        self.LPB = max(len(grp) for gl in fgroups for grp in gl)          # sub-steps per slab block
+        NOE = max(sum(2 * spec.paths[pi].l3 + 1 for _, pr in grp for pi in pr if pi is not None) for gl in fgroups for grp in gl)
+        self.NOEP = (NOE + 15) // 16 * 16
+        self.MAXD1 = max(2 * cat.l1 + 1 for cat in cats)
+        # Output-row offsets of every (x block, path group, 16-entry chunk): one register per chunk, live for the whole kernel.  The lmax-3
+        # shapes have 13 .. 25 of them (SevenNet-0: 5) beside 228 .. 256 other live registers -- MF-ompa's middle layer spilled 24 --, so
+        # where there are more than 8 the table lives in LDS and a lane reads its entry at the store (round 5).
+        self.N_OOFF = sum((sum(2 * spec.paths[pi].l3 + 1 for _, pr in grp for pi in pr if pi is not None) + 15) // 16 for gl in fgroups for grp in gl)
+        self.OOLDS = self.N_OOFF > 8 if 'oolds' not in OPTS else bool(int(OPTS['oolds']))
+        # Phase stamps of the FORWARD kernel (SNET_CODEGEN_OPTS=stampf=<tag>, stampfl=<tag> the light form: one stamp per tile instead of
+        # two per path tile), same device array and read-back as the reverse kernel's; a row per destination node
+        self.STFL = OPTS.get('stampfl') == self.tag
+        self.STF = OPTS.get('stampf') == self.tag or self.STFL
+        self.olists, self.oo_index = {}, {}
+
+    def fwd_lds(self, nt, nwv):
+        return 2 * self.LPB * 4 * nt * 1024 + nwv * (32 * self.NSHP * 4 + self.MAXD1 * 1024 + self.NOEP * 64) + 4 * nwv + (64 * self.N_OOFF if self.OOLDS else 0)
+
+    def fwd_cfg(self, nt):
+        """(waves per workgroup, direct global->LDS staging, waves per SIMD) of the forward kernel at nt operand terms"""
+        # measured: occupancy decides -- one 12-wave workgroup per CU at <= 168 VGPRs (3 waves per SIMD, direct
+        # global->LDS staging) where the LDS and the register count of this nt allow it, 8 or 4 waves otherwise
+        if 'fnwvf' in OPTS:
+            return self.def_f
+        if len(self.cats) == 1 and self.fwd_lds(nt, 8) <= 80 * 1024:   # first layer (scalar inputs only): 0.87 vs 1.03 ms at 12 waves;
+            return (8, 0, 2)                                             # slabs staged through registers: 0.85 vs 1.00 ms direct
+        if nt <= 2 and self.fwd_lds(nt, 12) <= 160 * 1024:
+            return (12, 0 if OPTS.get('f12reg') else 1, 3)
+        for w in (8, 4, 2, 1):
+            if self.fwd_lds(nt, w) <= 160 * 1024:
+                return (w, 1, 2)
+        raise NotImplementedError(f'conv shape {self.spec.key}: the fused forward kernel does not fit the LDS')
+
+    # ---------------------------------------------------------------- small emit helpers shared by several emitters
+    @staticmethod
+    def out_index(p, m3):
+        return p.out_off + m3 * p.out_mul + p.out_ch
+
+    def S(self, i, ind='      '):
+        """reverse-kernel phase stamp i (only in stamp builds; the light form keeps the block-level ones)"""
+        if self.ST and (not self.STL or i in (0, 1, 10, 11, 12, 13)):
+            self.A(f'{ind}stamp({i});')
+
+    def SF(self, i, ind, light=True):
+        if self.STF and (light or not self.STFL):
+            self.A(f'{ind}stamp({i});')
+
+    def g_row(self, ci, pi, m3, u):
+        return self.glists[ci].index((pi, m3, u))
+
+    def emit_g_loads(self, ind, ci, cb_expr):
+        A, glists, bsched, exp, GRAW, GUNC, XT = self.A, self.glists, self.bsched, self.exp, self.GRAW, self.GUNC, self.XT
+        gl = glists[ci]
+        U_ = bsched[ci]['U']
+        for k in range((len(gl) + 15) // 16):
+            # (the 1/denominator factor is applied when the entries are PARKED: multiplied here, the value is needed at once and
+            # the compiler answers with s_waitcnt vmcnt(0) right behind the load -- a full gather latency, and a drain of the
+            # g_xe stores and the source-row prefetch in front of it, at the top of every block: round 4, `vmord`)
+            dg = '(diag & 8) ? f32x4{1.f, 1.f, 1.f, 1.f} : ' if exp else ''
+            sc_ = ' * scale' if not GRAW else ''
+            pred = '' if GUNC else f'(goff{ci}_{k} < 0) ? f32x4{{0.f, 0.f, 0.f, 0.f}} : '
+            A(f'{ind}gpre[{k}] = {dg}{pred}*reinterpret_cast<const f32x4 *>(gnode + goff{ci}_{k} + {16 * U_} * ({cb_expr})){sc_};')
+        if XT:   # node B's entries: a wave-uniform branch, most tiles of a long segment have one node
+            A(f'{ind}if (two) {{')
+            for k in range((len(gl) + 15) // 16):
+                A(f'{ind}  gpre_b[{k}] = {dg}{pred}*reinterpret_cast<const f32x4 *>(gnode_b + goff{ci}_{k} + {16 * U_} * ({cb_expr})){sc_};')
+            A(f'{ind}}}')
+
+    def emit_g_park(self, ind, ci, buf_expr):
+        A, glists, GRAW, XT = self.A, self.glists, self.GRAW, self.XT
+        gl = glists[ci]
+        for k in range((len(gl) + 15) // 16):
+            sc_ = ' * scale' if GRAW else ''
+            A(f'{ind}*reinterpret_cast<f32x4 *>(&s_g[wave][{"0" if XT else buf_expr}][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]) = gpre[{k}]{sc_};')
+        if XT:
+            A(f'{ind}if (two) {{')
+            for k in range((len(gl) + 15) // 16):
+                A(f'{ind}  *reinterpret_cast<f32x4 *>(&s_g[wave][1][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]) = gpre_b[{k}]{sc_};')
+            A(f'{ind}}}')
+
+    def emit_x_loads(self, ind, ci_, ct_expr, tl_):
+        A, cats = self.A, self.cats
+        cat_ = cats[ci_]
+        A(f'{ind}{{ const float *xs_ = x + {cat_.x_off} + 16 * ({ct_expr}) + 4 * (lane & 3) + (size_t)srs[{tl_}] * DX;')
+        for m in range(2 * cat_.l1 + 1):
+            A(f'{ind}  xq[{m}] = *reinterpret_cast<const f32x4 *>(xs_ + {m * cat_.mul});')
+        A(f'{ind}}}')
+
+
+def _emit_header(cx: _Gen):
+    A, spec, tag, cats = cx.A, cx.spec, cx.tag, cx.cats
+    DX, DOUT, NSH, NSHP, WN, NS, cols, cols_rev = cx.DX, cx.DOUT, cx.NSH, cx.NSHP, cx.WN, cx.NS, cx.cols, cx.cols_b
     A('// GENERATED by sevennet_amd/codegen_fused.py -- do not edit.')
     A(f'// fused conv shape {tag}: x = {spec.irreps_x}, sh = {spec.irreps_sh}, out = {spec.irreps_out}')
     A(f'// {len(spec.paths)} paths, weight_numel = {WN}, {NS} sub-steps of two 16-column tiles')
@@ -255,20 +485,15 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('using namespace snet;')
     A('__device__ __forceinline__ f32x2 lo2(const f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }')
     A('__device__ __forceinline__ f32x2 hi2(const f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }')
-    # row stride of the forward kernel's spherical-harmonics staging: the four edge groups of a wave read rows 4 apart,
-    # which for nsh = 16 (lmax 3) all fall on one LDS bank (measured: 36 % of the kernel's LDS cycles were conflicts)
-    NSHP = NSH + 1 if (4 * NSH) % 32 == 0 else NSH
     A(f'constexpr int DX = {DX}, DOUT = {DOUT}, NSH = {NSH}, NSHP = {NSHP}, WN = {WN}, NS = {NS};')
     A('const int32_t SUB_COLS[NS * 2] = {' + ', '.join(f'{a}, {b}' for a, b in cols) + '};')
-    _, cols_rev = schedule_bwd(spec)   # the reverse kernel's own sub-step order (see schedule_bwd)
     A(f'const int32_t SUB_COLS_B[{2 * len(cols_rev)}] = {{' + ', '.join(f'{a}, {b}' for a, b in cols_rev) + '};')
     # g_xe[E, DX] is a private intermediate (reverse kernel -> segment sum): inside a row its 16-channel chunks are kept in
     # the order the kernel produces them, [x block][channel tile][component], so that the 2 l + 1 stores of one
     # (block, tile) write one contiguous run per edge (whole 128-byte lines) instead of 64-byte halves of lines whose other
     # half arrives one channel tile later.  GXE_CHUNK[standard chunk] = chunk position inside the g_xe row.
     gxe_chunk = list(range(DX // 16))
-    gxe_std = bool(OPTS.get('gxestd'))   # kernel-tuning builds: standard row order (round-2 layout) for A/B runs
-    for cat in ([] if gxe_std else cats):
+    for cat in ([] if cx.gxe_std else cats):
         d1c = 2 * cat.l1 + 1
         for ct in range(cat.mul // 16):
             for m in range(d1c):
@@ -277,23 +502,10 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A(f'const int32_t GXE_CHUNK[{DX // 16}] = {{' + ', '.join(str(v) for v in gxe_chunk) + '};')
     A('')
 
-    def out_index(p, m3):
-        return p.out_off + m3 * p.out_mul + p.out_ch
 
-    # Packed fp32 reverse bodies (round 5, `_emit_reverse_body_pk`): on by default for the shapes that run two waves per SIMD with
-    # register headroom -- the packed-tile class (SevenNet-0 middle layers 5.04 -> 4.92 ms, same box) -- and off elsewhere: the
-    # first layer's 8-wave kernel crosses 128 registers with them (127 -> 132: 1.89 -> 2.29 ms), the lmax-3 shapes at 256 registers
-    # start to spill (0 -> 6, 7 -> 37).  SNET_CODEGEN_OPTS=pk=0 / 1 forces it (profiles/r05_ab_packed_fp32_bodies.txt).
-    _bsp, _ = schedule_bwd(spec)
-    _ngpp = max((sum(2 * p_.l3 + 1 for _, p_ in b_['cat'].paths) * b_['U'] + 15) // 16 * 16 for b_ in _bsp)
-    _livep = 12 * max(2 * c_.l1 + 1 for c_ in cats) + 32 + NSH + 8 * (_ngpp // 16) + 16 + 4 * max(2 * p_.l3 + 1 for p_ in spec.paths) + 35
-    _xt_auto = _livep <= 200 and _livep - 4 * (_ngpp // 16) > 168 and len(cats) > 1
-    # forward kernel: a tile with m <= 12 edges keeps ceil(m / 4) accumulator rows per lane group instead of filling groups in turn
-    # (SNET_CODEGEN_OPTS=frow=0: the previous row order; middle layers 2.79 -> 2.73 ms same box, profiles/r05_ab_forward_variants.txt)
-    FROW = bool(int(OPTS.get('frow', 1)))
-    FRSB = int(OPTS.get('frsb', 0))   # scheduler fence between the rows of a forward body with >= frsb Clebsch-Gordan entries (0: none)
-    PK = bool(int(OPTS['pk'])) if 'pk' in OPTS else ((bool(int(OPTS['xtile'])) if 'xtile' in OPTS else _xt_auto))
-    # ------------------------------------------------------------------ per-path device functions
+def _emit_path_functions(cx: _Gen):
+    """per path: the reverse body (lane = edge, 4 channels per lane) and the forward body (lane = channel, 4 edges per lane)"""
+    A, spec, PK, FROW, FRSB = cx.A, cx.spec, cx.PK, cx.FROW, cx.FRSB
     for pi, p in enumerate(spec.paths):
         d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
         terms = _path_terms(p)
@@ -339,8 +551,15 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         A('}')
     A('')
 
-    # ------------------------------------------------------------------ reverse kernel
-    if tag in (OPTS.get('stamp'), OPTS.get('stampl'), OPTS.get('stampf'), OPTS.get('stampfl')):
+
+def _rev_prologue(cx: _Gen):
+    """kernel head, the wave's tile, the first loads (slab, g_out entries, source rows, h2, harmonics), operand scales"""
+    A, spec, tag, cats, exp = cx.A, cx.spec, cx.tag, cx.cats, cx.exp
+    NSH, XT, ST, GUNC, HOIST = cx.NSH, cx.XT, cx.ST, cx.GUNC, cx.HOIST
+    bsched, glists, NGP, NK, NSB = cx.bsched, cx.glists, cx.NGP, cx.NK, len(cx.cols_b)
+    S, emit_g_loads, emit_g_park, out_index = cx.S, cx.emit_g_loads, cx.emit_g_park, cx.out_index
+    NPH = 16
+    if cx.stamped:
         A('constexpr int SNET_STAMP_TILES = 1 << 18;')
         A('__device__ unsigned snet_stamps[16 * SNET_STAMP_TILES];   // one row per tile: no atomics (2.7 M atomics on 16 hot words stalled the whole chip)')
     A('template <int NT, bool F16, int NWV, bool GLDS, int OCC, bool GX>')
@@ -353,32 +572,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  // diag: always 0 in production (bit 0 also serves as the opaque branch condition around the tensor-product bodies);')
     A('  // kernel-tuning builds: 1 skip the tensor product, 2 skip the g_h2 products, 4 skip the w products, 8 skip the')
     A('  // g_out loads, 16 skip the g_xe stores -- timing decomposition, results are then garbage')
-    # Phase stamps (SNET_CODEGEN_OPTS=stamp=<tag>, kernel-tuning builds only): s_memtime at the phase boundaries of the reverse kernel,
-    # per-phase cycle sums of every wave added to the device array snet_stamps (read back by snet_debug_stamps; tools/microbench.py
-    # --stamps).  Every stamp drains the wave's LDS counter and fences the scheduler, so the instrumented kernel runs ~10 % slower
-    # than the shipped one: the split between phases is what it is for.
-    # stampl=<tag>: the LIGHT form -- stamps at the block-level boundaries only (prologue, block top, the block's sub-steps as one
-    # phase [id 9], block end, tail, epilogue: ~25 stamps per tile instead of ~270), so the split between "inside the sub-steps" and
-    # "around them" is measured on a kernel that runs close to the shipped one
-    STL = OPTS.get('stampl') == tag
-    ST = OPTS.get('stamp') == tag or STL
-    NPH = 16
-    def S(i, ind='      '):
-        if ST and (not STL or i in (0, 1, 10, 11, 12, 13)):
-            A(f'{ind}stamp({i});')
-    # Packed tiles (SNET_CODEGEN_OPTS=xtile=1): a tile is a window of <= 16 consecutive CSR edges that may run from one destination
-    # node (A) into the next one that has edges (B); snet_edge_tiles_packed writes tile_ptr[t] = first edge, tile_node[2t .. 2t+1] = A, B.
-    # The wave keeps BOTH nodes' g_out entries in its LDS buffer and every edge lane reads its own node's set.
-    # Chosen per shape: the second node's prefetched entries cost 4 NK more registers, which the lmax-3 shapes (at 256 already) do
-    # not have (round 4: 20 .. 2400 spilled registers with it; estimate 227 .. 243 against 195 for the largest shape that fits).  Nor
-    # where the g_out entries are most of a block's vector-memory instructions or the shape would leave three waves per SIMD for two
-    # (same box, in the step: first layer ecc5d202727d 1.69 -> 2.03 ms, last layer 005c575f8ec2 1.50 -> 1.63 ms with packed tiles; the
-    # middle layers 5.64 -> 5.24 ms).  SNET_CODEGEN_OPTS=xtile=0 / 1 forces it.
-    _bs0, _ = schedule_bwd(spec)
-    _ngp = max((sum(2 * p_.l3 + 1 for _, p_ in b_['cat'].paths) * b_['U'] + 15) // 16 * 16 for b_ in _bs0)
-    _live2 = 12 * max(2 * c_.l1 + 1 for c_ in cats) + 32 + NSH + 8 * (_ngp // 16) + 16 + 4 * max(2 * p_.l3 + 1 for p_ in spec.paths) + 35
-    XT = bool(int(OPTS['xtile'])) if 'xtile' in OPTS else (_live2 <= 200 and _live2 - 4 * (_ngp // 16) > 168 and len(cats) > 1)
-    GS = 2 if XT else 1
     A('  constexpr int LPS = 8 * NT, NTH = 64 * NWV, NST = (LPS * 64 + NTH - 1) / NTH, GLN = 1;  // 1-KB fragment lines per sub-step; sub-steps per slab')
     A('  __shared__ u32x4 slab[2][GLN * LPS * 64];')
     A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
@@ -415,41 +608,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     # are fetched ONCE per wave, one block ahead, by one or two 16-byte loads per lane (lane L: channels 4 (L & 3)
     # .. +3 of entry 16 k + (L >> 2); vector-memory instructions, not bytes, are what this kernel runs out of),
     # parked in a wave-private LDS buffer and read back as group-broadcast 16-byte reads.
-    # The reverse kernel walks the weight columns in BLOCKS: one x block (cat) and U = 1 or 2 of its 16-channel tiles.  An x
-    # block with an odd number of paths leaves one path without a partner for the second 16-column tile of a sub-step;
-    # with U = 2 that path's tiles of two consecutive channel tiles share a sub-step instead (schedule_bwd): the
-    # SevenNet-0 middle layer needs 30 sub-steps instead of 34, its last layer (three one-path x blocks) 7 instead of 14.
-    bsched, cols_b = schedule_bwd(spec)
-    NSB = len(cols_b)
-    # Order of the vector-memory operations (round 4).  vmcnt retires IN ORDER, and the slab fragments of the next sub-step
-    # are waited for at the end of every sub-step: whatever was issued before those slab loads -- the gathers of the next
-    # block's source rows and g_out entries, the g_xe stores of the block just finished -- is waited for with them.  So the
-    # first sub-step of a block does not request its slab itself: the request is HOISTED in front of the previous block's
-    # stores (and, for the first block, into the prologue); the long-latency operations then have two sub-steps to complete
-    # instead of (at best) one.  SNET_CODEGEN_OPTS=novmord=1 restores the round-3 order.
-    VMORD = not OPTS.get('novmord')
-    GRAW = VMORD and not OPTS.get('nograw')    # g_out entries loaded raw, 1/denominator applied when they are parked
-    GUNC = VMORD and not OPTS.get('nogunc')    # padding entries of the g_out fetch: unconditional loads of offset 0
-    _gl0 = [[1 for u in range(bs_['U']) for _, p_ in bs_['cat'].paths for _ in range(2 * p_.l3 + 1)] for bs_ in bsched]
-    _ngp0 = max((len(g_) + 15) // 16 * 16 for g_ in _gl0)
-    if 2 * 8 * 2 * 1024 + 4 * (2 * _ngp0 * 64 + spec.irreps_sh.dim * 64) <= 53 * 1024 and \
-            12 * max(2 * c_.l1 + 1 for c_ in cats) + 32 + spec.irreps_sh.dim + 4 * GS * (_ngp0 // 16) + 16 + 4 * max(2 * p_.l3 + 1 for p_ in spec.paths) + 35 <= (160 if XT else 168):
-        GUNC = GUNC and bool(OPTS.get('gunc3'))   # three-waves-per-SIMD shapes (168 registers): the unpredicated form spilled 9 there
-    glists = [[(pi, m3, u) for u in range(bs['U']) for pi, p in bs['cat'].paths for m3 in range(2 * p.l3 + 1)] for bs in bsched]
-    NGP = max((len(gl) + 15) // 16 * 16 for gl in glists)   # rows of the LDS buffer (padded to 16 entries per load)
-    NK = NGP // 16
-    # rows of the NEXT x block requested one block ahead (xp): only where the extra U d1 vector registers fit the budget of the
-    # occupancy this shape runs at (same live-state estimate as bwd_cfg below; the lmax-3 shapes sit at 256 already and
-    # spilled 200+ registers with it)
-    _maxd1 = max(2 * c_.l1 + 1 for c_ in cats)
-    _maxd3 = max(2 * p_.l3 + 1 for p_ in spec.paths)
-    _live = 12 * _maxd1 + 32 + NSH + 4 * GS * NK + 16 + 4 * _maxd3 + 35
-    _budget = 168 if (2 * 8 * 2 * 1024 + 4 * (2 * NGP * 64 + NSH * 64) <= 53 * 1024 and _live <= (160 if XT else 168)) else 256
-    _xp_regs = max([4 * b_['U'] * (2 * b_['cat'].l1 + 1) for b_ in bsched[1:]] or [0])
-    _budget -= 24   # margin: the estimate is a lower bound of what hipcc's allocator ends up with
-    XPF = VMORD and len(bsched) > 1 and _live + _xp_regs + 8 <= _budget and not OPTS.get('noxpf')
-    # the hoisted slab request keeps the staging registers live across the block boundary: same budget rule
-    HOIST = VMORD and _live + 16 + 8 <= _budget and not OPTS.get('nohoist')
     A(f'  constexpr int NGP = {NGP}, NK = {NK}, NSUB = {NSB};   // NSUB: sub-steps of the reverse kernel\'s weight stream')
     if XT:
         # (one buffer per node, not two per block parity: the entries of the next block are parked after this block's last read, and a
@@ -469,38 +627,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
             offs = [out_index(spec.paths[gl[q][0]], gl[q][1]) + 16 * gl[q][2] if q < len(gl) else (0 if GUNC else -1) for q in range(16 * k, 16 * k + 16)]
             A(f'  static const int32_t GOFF{ci}_{k}[16] = {{' + ', '.join(str(o) for o in offs) + '};')
             A(f'  const int goff{ci}_{k} = GOFF{ci}_{k}[lane >> 2];')
-
-    def emit_g_loads(ind, ci, cb_expr):
-        gl = glists[ci]
-        U_ = bsched[ci]['U']
-        for k in range((len(gl) + 15) // 16):
-            # (the 1/denominator factor is applied when the entries are PARKED: multiplied here, the value is needed at once and
-            # the compiler answers with s_waitcnt vmcnt(0) right behind the load -- a full gather latency, and a drain of the
-            # g_xe stores and the source-row prefetch in front of it, at the top of every block: round 4, `vmord`)
-            dg = '(diag & 8) ? f32x4{1.f, 1.f, 1.f, 1.f} : ' if exp else ''
-            sc_ = ' * scale' if not GRAW else ''
-            pred = '' if GUNC else f'(goff{ci}_{k} < 0) ? f32x4{{0.f, 0.f, 0.f, 0.f}} : '
-            A(f'{ind}gpre[{k}] = {dg}{pred}*reinterpret_cast<const f32x4 *>(gnode + goff{ci}_{k} + {16 * U_} * ({cb_expr})){sc_};')
-        if XT:   # node B's entries: a wave-uniform branch, most tiles of a long segment have one node
-            A(f'{ind}if (two) {{')
-            for k in range((len(gl) + 15) // 16):
-                A(f'{ind}  gpre_b[{k}] = {dg}{pred}*reinterpret_cast<const f32x4 *>(gnode_b + goff{ci}_{k} + {16 * U_} * ({cb_expr})){sc_};')
-            A(f'{ind}}}')
-
-    def emit_g_park(ind, ci, buf_expr):
-        gl = glists[ci]
-        for k in range((len(gl) + 15) // 16):
-            sc_ = ' * scale' if GRAW else ''
-            A(f'{ind}*reinterpret_cast<f32x4 *>(&s_g[wave][{"0" if XT else buf_expr}][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]) = gpre[{k}]{sc_};')
-        if XT:
-            A(f'{ind}if (two) {{')
-            for k in range((len(gl) + 15) // 16):
-                A(f'{ind}  *reinterpret_cast<f32x4 *>(&s_g[wave][1][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]) = gpre_b[{k}]{sc_};')
-            A(f'{ind}}}')
-
-    def g_row(ci, pi, m3, u):
-        return glists[ci].index((pi, m3, u))
-
     emit_g_loads('  ', 0, '0')
     if XT:
         A('  const int e0 = tile_ptr[t];')
@@ -582,174 +708,192 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  }')
     A('  int sidx = 0, buf = 0, gbuf = 0;')
     S(0, '  ')
-    for ci, bs in enumerate(bsched):
-        cat, U, ncb = bs['cat'], bs['U'], bs['ncb']
-        d1 = 2 * cat.l1 + 1
-        A(f'  // ---- x block {cat.i_x}: {cat.mul}x l={cat.l1}, {len(cat.paths)} paths, {U} channel tile(s) per block, {len(bs["steps"])} sub-steps per block')
-        # source rows: the next block's slices are requested one block ahead (gather latency ~1-2 us)
-        if ci > 0:   # (the first x block's rows were requested in the prologue)
-            A(f'  const float *xs{ci} = x + (size_t)s_src * DX + {cat.x_off} + 4 * g;')
-            A(f'  f32x4 xr{ci}[{U}][{d1}], xn{ci}[{U}][{d1}];')
-            for u in range(U):   # (XPF: requested at the top of the previous x block's last block, one block ahead like the others)
-                for m in range(d1):
-                    A(f'  xr{ci}[{u}][{m}] = ' + (f'xp{ci}[{u}][{m}];' if XPF else f'*reinterpret_cast<const f32x4 *>(xs{ci} + {16 * u + m * cat.mul});'))
-        if XPF and ci + 1 < len(bsched):   # the next x block's first rows are requested from inside this one: declared here
-            cat_n, U_n = bsched[ci + 1]['cat'], bsched[ci + 1]['U']
-            d1_n = 2 * cat_n.l1 + 1
-            A(f'  const float *xs{ci + 1}p = x + (size_t)s_src * DX + {cat_n.x_off} + 4 * g;')
-            A(f'  f32x4 xp{ci + 1}[{U_n}][{d1_n}];')
-        A(f'  for (int cb = 0; cb < {ncb}; ++cb) {{')
-        A(f'    f32x4 (&xr)[{U}][{d1}] = xr{ci};')
-        A(f'    f32x4 gx[{U}][{d1}];')
+
+
+def _rev_block_top(cx: _Gen, ci: int):
+    """x block ci: its first rows, then -- per block of U channel tiles -- the requests of the NEXT block's rows and g_out entries"""
+    A, exp, XT, XPF, bsched = cx.A, cx.exp, cx.XT, cx.XPF, cx.bsched
+    S, emit_g_loads = cx.S, cx.emit_g_loads
+    bs = bsched[ci]
+    cat, U, ncb, d1, NOXN = cx.block_info(ci)   # (NOXN: this block's next rows are requested at its end, straight into xr)
+    A(f'  // ---- x block {cat.i_x}: {cat.mul}x l={cat.l1}, {len(cat.paths)} paths, {U} channel tile(s) per block, {len(bs["steps"])} sub-steps per block')
+    # source rows: the next block's slices are requested one block ahead (gather latency ~1-2 us)
+    if ci > 0:   # (the first x block's rows were requested in the prologue)
+        A(f'  const float *xs{ci} = x + (size_t)s_src * DX + {cat.x_off} + 4 * g;')
+        A(f'  f32x4 xr{ci}[{U}][{d1}], xn{ci}[{U}][{d1}];')
+        for u in range(U):   # (XPF: requested at the top of the previous x block's last block, one block ahead like the others)
+            for m in range(d1):
+                A(f'  xr{ci}[{u}][{m}] = ' + (f'xp{ci}[{u}][{m}];' if XPF else f'*reinterpret_cast<const f32x4 *>(xs{ci} + {16 * u + m * cat.mul});'))
+    if XPF and ci + 1 < len(bsched):   # the next x block's first rows are requested from inside this one: declared here
+        cat_n, U_n = bsched[ci + 1]['cat'], bsched[ci + 1]['U']
+        d1_n = 2 * cat_n.l1 + 1
+        A(f'  const float *xs{ci + 1}p = x + (size_t)s_src * DX + {cat_n.x_off} + 4 * g;')
+        A(f'  f32x4 xp{ci + 1}[{U_n}][{d1_n}];')
+    A(f'  for (int cb = 0; cb < {ncb}; ++cb) {{')
+    A(f'    f32x4 (&xr)[{U}][{d1}] = xr{ci};')
+    A(f'    f32x4 gx[{U}][{d1}];')
+    for u in range(U):
+        for m in range(d1):
+            A(f'    gx[{u}][{m}] = f32x4{{0.f, 0.f, 0.f, 0.f}};')
+    def emit_next_xblock_rows(ind):
+        for u in range(U_n):
+            for m in range(d1_n):
+                A(f'{ind}xp{ci + 1}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci + 1}p + {16 * u + m * cat_n.mul});')
+    if ncb > 1:
+        A(f'    if (cb + 1 < {ncb}' + (' && !(diag & 64)' if exp else '') + ') {')
         for u in range(U):
             for m in range(d1):
-                A(f'    gx[{u}][{m}] = f32x4{{0.f, 0.f, 0.f, 0.f}};')
-        def emit_next_xblock_rows(ind):
-            for u in range(U_n):
-                for m in range(d1_n):
-                    A(f'{ind}xp{ci + 1}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci + 1}p + {16 * u + m * cat_n.mul});')
-        # x blocks with 2 l + 1 >= noxn get no register prefetch of the next block's source rows.  Default: the l = 3 blocks of the
-        # shapes that sit at 256 registers (round 4: with the prefetch those kernels spilled 15 .. 33 registers, and a spill reload
-        # waits for every older gather; without it 0 .. 7, l3i5 middle layer 11.22 -> 11.02 ms).  SNET_CODEGEN_OPTS=noxn=<d1> overrides
-        _noxn = int(OPTS.get('noxn', 7 if _live > 200 else 0))
-        NOXN = _noxn > 0 and d1 >= _noxn   # (they are requested
-        #                                 at the end of the block instead, straight into xr): 4 U d1 registers fewer, latency left to occupancy
-        if ncb > 1:
-            A(f'    if (cb + 1 < {ncb}' + (' && !(diag & 64)' if exp else '') + ') {')
-            for u in range(U):
-                for m in range(d1):
-                    if not NOXN:
-                        A(f'      xn{ci}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {16 * U} * (cb + 1) + {16 * u + m * cat.mul});')
-            if XPF and ci + 1 < len(bsched):
-                A('    } else {')
-                emit_next_xblock_rows('      ')
-            A('    }')
-        elif XPF and ci + 1 < len(bsched):
-            emit_next_xblock_rows('    ')
-        A('    const float *gl_ = &s_g[wave][' + ('in_b' if XT else 'gbuf') + '][4 * g];')
-        # next block's g_out entries: this x block's next block, or the first block of the next x block
-        if ncb > 1:
-            A(f'    if (cb + 1 < {ncb}) {{')
-            emit_g_loads('      ', ci, 'cb + 1')
-            A('    }' + (' else {' if ci + 1 < len(bsched) else ''))
-            if ci + 1 < len(bsched):
-                emit_g_loads('      ', ci + 1, '0')
-                A('    }')
-        elif ci + 1 < len(bsched):
-            emit_g_loads('    ', ci + 1, '0')
-        S(1, '    ')
-        for si_, (ta, tb) in enumerate(bs['steps']):
-            A('    {')
-            if not (HOIST and si_ == 0):   # (first sub-step of a block: requested at the end of the previous block / the prologue)
-                A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, (buf ^ 1));')
-            # hipcc's machine scheduler, left alone, sinks the prefetch loads next to their use (zero overlap) and
-            # interleaves the phases until ~200 VGPRs spill: pin the prefetch at the top and fence the phases
-            A('      __builtin_amdgcn_sched_barrier(0);')
-            S(2)
-            A('      const u32x4 *sl = slab[buf];')
-            A('      f32x4 gw0 = f32x4{0.f, 0.f, 0.f, 0.f}, gw1 = gw0;')
-            for tp, tl_ in enumerate((ta, tb)):
-                if tl_ is None:
-                    continue
-                pi, u = tl_
-                p = spec.paths[pi]
-                d3 = 2 * p.l3 + 1
-                A(f'      {{  // tile {tp}: path {pi}, channel tile {U} cb + {u}')
-                A('        f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
-                if exp:
-                    A('        if (diag & 4) wv = f32x4{yl[0], yl[16], yl[32], yl[48]}; else')
-                A('#pragma unroll')
-                A('        for (int q = 0; q < 2; ++q) {')
-                A('          bf16x8 a[NT];')
-                A('#pragma unroll')
-                A(f'          for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
-                A('          wv = mfma16_split<NT, F16>(a, hb[q], wv);')
-                A('        }')
-                A('        if constexpr (F16) wv *= w_unscale;')
-                if ST and not STL:
-                    A('        asm volatile("" :: "v"(wv[0]), "v"(wv[3]));')
-                S(3 + 2 * tp, '        ')
-                A(f'        f32x4 G[{d3}];')
-                for m3 in range(d3):
-                    A(f'        G[{m3}] = *reinterpret_cast<const f32x4 *>(gl_ + {g_row(ci, pi, m3, u)} * 16);')
-                A('        float ys[NSH];')
-                for b_ in range(2 * p.l2 + 1):
-                    A(f'        ys[{p.sh_off + b_}] = yl[{(p.sh_off + b_) * 16}];')
-                # The tensor-product body sits in its own (always taken) branch on an opaque kernel argument: as
-                # straight-line code hipcc's scheduler interleaves it with the surrounding matrix products and
-                # loads until ~200 VGPRs spill to scratch (measured: 692 spilled registers without the branch, 0 with)
-                A(f'        gw{tp} = f32x4{{0.f, 0.f, 0.f, 0.f}};')
-                A(f'        if (!(diag & 1)) bwdf_p{pi}<GX>(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
-                if ST and not STL:
-                    A(f'        asm volatile("" :: "v"(gw{tp}[0]), "v"(gw{tp}[3]));')
-                S(4 + 2 * tp, '        ')
-                A('      }')
-            A('      float v[8] = {gw0[0], gw0[1], gw0[2], gw0[3], gw1[0], gw1[1], gw1[2], gw1[3]};')
-            A('      if constexpr (F16) {')
-            A('#pragma unroll')
-            A('        for (int i = 0; i < 8; ++i) v[i] *= g_sc;')
-            A('      }')
-            A('      const SplitN<NT> b = splitn8<NT, F16>(v);')
-            if exp:
-                A('      if (diag & 2) ga[0] += f32x4{v[0], v[1], v[4], v[5]}; else')
-            A('#pragma unroll')
-            A('      for (int m = 0; m < 4; ++m) {')
-            A('        bf16x8 a[NT];')
-            A('#pragma unroll')
-            A('        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
-            A('        ga[m] = mfma16_split<NT, F16>(a, b, ga[m]);')
-            A('      }')
-            if ST and not STL:
-                A('      asm volatile("" :: "v"(ga[0][0]), "v"(ga[1][0]), "v"(ga[2][0]), "v"(ga[3][0]));')
-            S(7)
-            A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_store((buf ^ 1));')
-            S(8)
-            A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
-            S(9)
-            A('      buf = (buf ^ 1);')
-            A('      ++sidx;')
-            A('    }')
-        if STL:
-            A('    stamp(9);   // (light stamps: all sub-steps of the block)')
-        if HOIST:   # the next block's first sub-step: its slab request goes out BEFORE this block's stores
-            A('    if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, (buf ^ 1));')
-            A('    __builtin_amdgcn_sched_barrier(0);')
-        A('    if (GX && g_xe && valid' + (' && !(diag & 16)' if exp else '') + ') {')
-        for u in range(U):
-            if gxe_std:
-                A(f'      {"float *" if u == 0 else ""}o = g_xe + (size_t)e * DX + {cat.x_off} + 16 * ({U} * cb + {u}) + 4 * g;')
-            else:
-                A(f'      {"float *" if u == 0 else ""}o = g_xe + (size_t)e * DX + {cat.x_off} + {16 * d1} * ({U} * cb + {u}) + 4 * g;   // chunk order [tile][component]: GXE_CHUNK')
-            for m in range(d1):
-                # streaming stores (kept in L2, partially written lines were evicted before their other half arrived:
-                # 8.9 GB written for 5.9 GB of output in round 2)
-                A(f'      __builtin_nontemporal_store(gx[{u}][{m}], reinterpret_cast<f32x4 *>(o + {m * cat.mul if gxe_std else 16 * m}));')
+                if not NOXN:
+                    A(f'      xn{ci}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {16 * U} * (cb + 1) + {16 * u + m * cat.mul});')
+        if XPF and ci + 1 < len(bsched):
+            A('    } else {')
+            emit_next_xblock_rows('      ')
         A('    }')
-        # park the prefetched entries of the next block in the other buffer (last read one block ago)
-        if ncb > 1:
-            A(f'    if (cb + 1 < {ncb}) {{')
-            emit_g_park('      ', ci, 'gbuf ^ 1')
-            A('    }' + (' else {' if ci + 1 < len(bsched) else ''))
-            if ci + 1 < len(bsched):
-                emit_g_park('      ', ci + 1, 'gbuf ^ 1')
-                A('    }')
-        elif ci + 1 < len(bsched):
-            emit_g_park('    ', ci + 1, 'gbuf ^ 1')
-        A('    gbuf ^= 1;')
-        A('    __builtin_amdgcn_wave_barrier();')
-        if ncb > 1 and NOXN:
-            A(f'    if (cb + 1 < {ncb}) {{')
-            for u in range(U):
-                for m in range(d1):
-                    A(f'      xr{ci}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {16 * U} * (cb + 1) + {16 * u + m * cat.mul});')
+    elif XPF and ci + 1 < len(bsched):
+        emit_next_xblock_rows('    ')
+    A('    const float *gl_ = &s_g[wave][' + ('in_b' if XT else 'gbuf') + '][4 * g];')
+    # next block's g_out entries: this x block's next block, or the first block of the next x block
+    if ncb > 1:
+        A(f'    if (cb + 1 < {ncb}) {{')
+        emit_g_loads('      ', ci, 'cb + 1')
+        A('    }' + (' else {' if ci + 1 < len(bsched) else ''))
+        if ci + 1 < len(bsched):
+            emit_g_loads('      ', ci + 1, '0')
             A('    }')
-        elif ncb > 1:
-            A('#pragma unroll')
-            A(f'    for (int u = 0; u < {U}; ++u)')
-            A('#pragma unroll')
-            A(f'      for (int m = 0; m < {d1}; ++m) xr{ci}[u][m] = xn{ci}[u][m];')
-        S(10, '    ')
-        A('  }')
+    elif ci + 1 < len(bsched):
+        emit_g_loads('    ', ci + 1, '0')
+    S(1, '    ')
+
+
+def _rev_substep(cx: _Gen, ci: int, si_: int, ta, tb):
+    """one sub-step = two 16-column tiles of W2: per tile  w = W2^T h2^T (matrix cores) -> reverse tensor-product body; then the
+    operand split of the two g_w tiles and  g_h2^T += W2 g_w^T;  the next sub-step's slab is parked, one workgroup barrier"""
+    A, spec, exp, ST, STL, HOIST = cx.A, cx.spec, cx.exp, cx.ST, cx.STL, cx.HOIST
+    S, g_row = cx.S, cx.g_row
+    U = cx.bsched[ci]['U']
+    A('    {')
+    if not (HOIST and si_ == 0):   # (first sub-step of a block: requested at the end of the previous block / the prologue)
+        A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, (buf ^ 1));')
+    # hipcc's machine scheduler, left alone, sinks the prefetch loads next to their use (zero overlap) and
+    # interleaves the phases until ~200 VGPRs spill: pin the prefetch at the top and fence the phases
+    A('      __builtin_amdgcn_sched_barrier(0);')
+    S(2)
+    A('      const u32x4 *sl = slab[buf];')
+    A('      f32x4 gw0 = f32x4{0.f, 0.f, 0.f, 0.f}, gw1 = gw0;')
+    for tp, tl_ in enumerate((ta, tb)):
+        if tl_ is None:
+            continue
+        pi, u = tl_
+        p = spec.paths[pi]
+        d3 = 2 * p.l3 + 1
+        A(f'      {{  // tile {tp}: path {pi}, channel tile {U} cb + {u}')
+        A('        f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
+        if exp:
+            A('        if (diag & 4) wv = f32x4{yl[0], yl[16], yl[32], yl[48]}; else')
+        A('#pragma unroll')
+        A('        for (int q = 0; q < 2; ++q) {')
+        A('          bf16x8 a[NT];')
+        A('#pragma unroll')
+        A(f'          for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
+        A('          wv = mfma16_split<NT, F16>(a, hb[q], wv);')
+        A('        }')
+        A('        if constexpr (F16) wv *= w_unscale;')
+        if ST and not STL:
+            A('        asm volatile("" :: "v"(wv[0]), "v"(wv[3]));')
+        S(3 + 2 * tp, '        ')
+        A(f'        f32x4 G[{d3}];')
+        for m3 in range(d3):
+            A(f'        G[{m3}] = *reinterpret_cast<const f32x4 *>(gl_ + {g_row(ci, pi, m3, u)} * 16);')
+        A('        float ys[NSH];')
+        for b_ in range(2 * p.l2 + 1):
+            A(f'        ys[{p.sh_off + b_}] = yl[{(p.sh_off + b_) * 16}];')
+        # The tensor-product body sits in its own (always taken) branch on an opaque kernel argument: as
+        # straight-line code hipcc's scheduler interleaves it with the surrounding matrix products and
+        # loads until ~200 VGPRs spill to scratch (measured: 692 spilled registers without the branch, 0 with)
+        A(f'        gw{tp} = f32x4{{0.f, 0.f, 0.f, 0.f}};')
+        A(f'        if (!(diag & 1)) bwdf_p{pi}<GX>(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
+        if ST and not STL:
+            A(f'        asm volatile("" :: "v"(gw{tp}[0]), "v"(gw{tp}[3]));')
+        S(4 + 2 * tp, '        ')
+        A('      }')
+    A('      float v[8] = {gw0[0], gw0[1], gw0[2], gw0[3], gw1[0], gw1[1], gw1[2], gw1[3]};')
+    A('      if constexpr (F16) {')
+    A('#pragma unroll')
+    A('        for (int i = 0; i < 8; ++i) v[i] *= g_sc;')
+    A('      }')
+    A('      const SplitN<NT> b = splitn8<NT, F16>(v);')
+    if exp:
+        A('      if (diag & 2) ga[0] += f32x4{v[0], v[1], v[4], v[5]}; else')
+    A('#pragma unroll')
+    A('      for (int m = 0; m < 4; ++m) {')
+    A('        bf16x8 a[NT];')
+    A('#pragma unroll')
+    A('        for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(4 * NT + m * NT + tm) * 64 + lane]);')
+    A('        ga[m] = mfma16_split<NT, F16>(a, b, ga[m]);')
+    A('      }')
+    if ST and not STL:
+        A('      asm volatile("" :: "v"(ga[0][0]), "v"(ga[1][0]), "v"(ga[2][0]), "v"(ga[3][0]));')
+    S(7)
+    A('      if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_store((buf ^ 1));')
+    S(8)
+    A(('      if (!(diag & 128)) ' if exp else '      ') + '__syncthreads();')
+    S(9)
+    A('      buf = (buf ^ 1);')
+    A('      ++sidx;')
+    A('    }')
+
+
+def _rev_block_end(cx: _Gen, ci: int):
+    """g_xe stores of the block (behind the hoisted slab request), the next block's g_out entries parked, rows rotated"""
+    A, exp, STL, HOIST, bsched, gxe_std = cx.A, cx.exp, cx.STL, cx.HOIST, cx.bsched, cx.gxe_std
+    S, emit_g_park = cx.S, cx.emit_g_park
+    cat, U, ncb, d1, NOXN = cx.block_info(ci)
+    if STL:
+        A('    stamp(9);   // (light stamps: all sub-steps of the block)')
+    if HOIST:   # the next block's first sub-step: its slab request goes out BEFORE this block's stores
+        A('    if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, (buf ^ 1));')
+        A('    __builtin_amdgcn_sched_barrier(0);')
+    A('    if (GX && g_xe && valid' + (' && !(diag & 16)' if exp else '') + ') {')
+    for u in range(U):
+        if gxe_std:
+            A(f'      {"float *" if u == 0 else ""}o = g_xe + (size_t)e * DX + {cat.x_off} + 16 * ({U} * cb + {u}) + 4 * g;')
+        else:
+            A(f'      {"float *" if u == 0 else ""}o = g_xe + (size_t)e * DX + {cat.x_off} + {16 * d1} * ({U} * cb + {u}) + 4 * g;   // chunk order [tile][component]: GXE_CHUNK')
+        for m in range(d1):
+            # streaming stores (kept in L2, partially written lines were evicted before their other half arrived:
+            # 8.9 GB written for 5.9 GB of output in round 2)
+            A(f'      __builtin_nontemporal_store(gx[{u}][{m}], reinterpret_cast<f32x4 *>(o + {m * cat.mul if gxe_std else 16 * m}));')
+    A('    }')
+    # park the prefetched entries of the next block in the other buffer (last read one block ago)
+    if ncb > 1:
+        A(f'    if (cb + 1 < {ncb}) {{')
+        emit_g_park('      ', ci, 'gbuf ^ 1')
+        A('    }' + (' else {' if ci + 1 < len(bsched) else ''))
+        if ci + 1 < len(bsched):
+            emit_g_park('      ', ci + 1, 'gbuf ^ 1')
+            A('    }')
+    elif ci + 1 < len(bsched):
+        emit_g_park('    ', ci + 1, 'gbuf ^ 1')
+    A('    gbuf ^= 1;')
+    A('    __builtin_amdgcn_wave_barrier();')
+    if ncb > 1 and NOXN:
+        A(f'    if (cb + 1 < {ncb}) {{')
+        for u in range(U):
+            for m in range(d1):
+                A(f'      xr{ci}[{u}][{m}] = *reinterpret_cast<const f32x4 *>(xs{ci} + {16 * U} * (cb + 1) + {16 * u + m * cat.mul});')
+        A('    }')
+    elif ncb > 1:
+        A('#pragma unroll')
+        A(f'    for (int u = 0; u < {U}; ++u)')
+        A('#pragma unroll')
+        A(f'      for (int m = 0; m < {d1}; ++m) xr{ci}[u][m] = xn{ci}[u][m];')
+    S(10, '    ')
+    A('  }')
+
+
+def _rev_tail(cx: _Gen):
+    """after the last block: g_h2 back to scale, then either stored or -- FusedTail -- the radial MLP's hidden layers reversed on it"""
+    A, spec, dead_x, offs_x, S = cx.A, cx.spec, cx.dead_x, cx.offs_x, cx.S
     if dead_x:
         A('  if (GX && g_xe && valid) {  // x blocks that feed no path get a zero gradient')
         for i in dead_x:
@@ -917,6 +1061,11 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('    }')
     S(12, '    ')
     A('  }')
+
+
+def _rev_epilogue(cx: _Gen):
+    """dE/dY summed over the four channel groups of an edge, folded with dY/dr into g_vec (or written as g_sh for the plug-in)"""
+    A, ST, S, NPH = cx.A, cx.ST, cx.S, 16
     A('  // d/d(edge_vec) = sum_i gy_i dY_i/dr (Y_0 is constant).  The 4 channel groups of an edge (lanes j, j+16, j+32,')
     A('  // j+48) are summed with two permlane swaps per value; only the g == 0 lanes then touch dsh and g_vec.')
     A('#pragma unroll')
@@ -952,22 +1101,24 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('}')
     A('')
 
-    # ------------------------------------------------------------------ forward kernel
-    # One wavefront = one destination node, up to two 16-edge tiles per pass.  The weight stream is consumed in
-    # BLOCKS of up to FG sub-steps (all paths of one (x block, 16-channel tile) when there are <= 2 FG of them):
-    # one workgroup barrier per block; inside a block the wave walks its tiles, and for each tile stages the 16
-    # source rows' slice ONCE in wave-private LDS with d1 16-byte loads per lane (instead of 4 d1 4-byte gathers
-    # per path pair), then runs every path of the block on it.  Output rows leave through LDS too: 16-byte
-    # stores of 4 channels per lane instead of one 64-byte row segment per instruction.
-    FG = int(OPTS.get('ffg', 3))
-    fgroups = []   # per cat: list of groups, each a list of (sub-step index within the (cat, ct) block, (pa, pb))
-    for ci, cat in enumerate(cats):
-        prs = list(enumerate(pairs_of[ci]))
-        fgroups.append([prs[i:i + FG] for i in range(0, len(prs), FG)])
-    LPB = max(len(grp) for gl in fgroups for grp in gl)          # sub-steps per slab block
-    NOE = max(sum(2 * spec.paths[pi].l3 + 1 for _, pr in grp for pi in pr if pi is not None) for gl in fgroups for grp in gl)
-    NOEP = (NOE + 15) // 16 * 16
-    MAXD1 = max(2 * cat.l1 + 1 for cat in cats)
+
+def _emit_reverse_kernel(cx: _Gen):
+    _rev_prologue(cx)
+    for ci, bs in enumerate(cx.bsched):
+        _rev_block_top(cx, ci)
+        for si_, (ta, tb) in enumerate(bs['steps']):
+            _rev_substep(cx, ci, si_, ta, tb)
+        _rev_block_end(cx, ci)
+    _rev_tail(cx)
+    _rev_epilogue(cx)
+
+
+def _fwd_prologue(cx: _Gen):
+    """kernel head, LDS buffers, the wave's node and pass count, slab staging lambdas, output-offset tables"""
+    A, L, spec, tag, NSHP = cx.A, cx.L, cx.spec, cx.tag, cx.NSHP
+    fgroups, LPB, NOEP, MAXD1, N_OOFF, OOLDS, STF = cx.fgroups, cx.LPB, cx.NOEP, cx.MAXD1, cx.N_OOFF, cx.OOLDS, cx.STF
+    SF, out_index, olists, oo_index = cx.SF, cx.out_index, cx.olists, cx.oo_index
+    oo_rows = []
     A('template <int NT, bool F16, int NWV, bool GLDS, int OCC>')
     A(f'__global__ __launch_bounds__(64 * NWV, OCC) void conv_fwdf_{tag}(const float *__restrict__ x, const float *__restrict__ sh,')
     A('    const float *__restrict__ h2, const int32_t *__restrict__ w_row, const int32_t *__restrict__ row_ptr,')
@@ -976,12 +1127,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  constexpr int NSTB = (LPB * LPF * 64 + NTH - 1) / NTH;')
     A('  __shared__ u32x4 slab[2][LPB * LPF * 64];')
     A('  __shared__ int s_pass[NWV];')
-    # Output-row offsets of every (x block, path group, 16-entry chunk): one register per chunk, live for the whole kernel.  The lmax-3
-    # shapes have 13 .. 25 of them (SevenNet-0: 5) beside 228 .. 256 other live registers -- MF-ompa's middle layer spilled 24 --, so
-    # where there are more than 8 the table lives in LDS and a lane reads its entry at the store (round 5).
-    N_OOFF = sum((sum(2 * spec.paths[pi].l3 + 1 for _, pr in grp for pi in pr if pi is not None) + 15) // 16 for gl in fgroups for grp in gl)
-    OOLDS = N_OOFF > 8 if 'oolds' not in OPTS else bool(int(OPTS['oolds']))
-    oo_rows, oo_index = [], {}
     if OOLDS:
         A(f'  __shared__ int32_t s_ooff[{16 * N_OOFF}];')
     A('  __shared__ __attribute__((aligned(16))) float s_ys[NWV][32 * NSHP];  // spherical harmonics of the pass\'s edges (rows padded: NSHP)')
@@ -990,10 +1135,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
     A('  const int c = lane & 15, g = lane >> 4;')
     A('  const int n_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
-    # Phase stamps of the FORWARD kernel (SNET_CODEGEN_OPTS=stampf=<tag>, stampfl=<tag> the light form: one stamp per tile instead of
-    # two per path tile), same device array and read-back as the reverse kernel's; a row per destination node
-    STFL = OPTS.get('stampfl') == tag
-    STF = OPTS.get('stampf') == tag or STFL
     if STF:
         A('  unsigned ph[16];')
         A('#pragma unroll')
@@ -1008,10 +1149,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         A('    t_prev = tn;')
         A('    __builtin_amdgcn_sched_barrier(0);')
         A('  };')
-
-    def SF(i, ind, light=True):
-        if STF and (light or not STFL):
-            A(f'{ind}stamp({i});')
     A('  const bool live = n_raw < n_nodes;')
     A('  const int node = __builtin_amdgcn_readfirstlane(live ? n_raw : n_nodes - 1);')
     A('  const int e_beg = row_ptr[node], e_end = row_ptr[node + 1];')
@@ -1048,7 +1185,6 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     A('  const bool has_e = e_end > e_beg;')
     A('  const int e_last = max(e_beg, e_end - 1);  // clamp target for padded rows (their weight is zeroed)')
     # output offsets per (cat, group): entry = 16 k + (lane >> 2)
-    olists = {}
     for ci, gl in enumerate(fgroups):
         for gi, grp in enumerate(gl):
             ol = [(pi, m3) for _, pr in grp for pi in pr if pi is not None for m3 in range(2 * spec.paths[pi].l3 + 1)]
@@ -1066,6 +1202,11 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         L[oo_fill_at] = (f'  static const int32_t OOFF_ALL[{16 * N_OOFF}] = {{' + ', '.join(str(o) for row in oo_rows for o in row) + '};\n'
                          + f'  for (int i = tid; i < {16 * N_OOFF}; i += NTH) s_ooff[i] = OOFF_ALL[i];   // (ordered by the s_pass barrier below)\n' + L[oo_fill_at])
     # flat block schedule: first sub-step index and size of every block, in stream order
+
+
+def _fwd_pass_top(cx: _Gen):
+    """a pass = up to 32 edges of the node: h2 fragments and scales per tile, harmonics to LDS, first slab, first source-row slice"""
+    A, FROW, fgroups, MAXD1, SF = cx.A, cx.FROW, cx.fgroups, cx.MAXD1, cx.SF
     A('  for (int pass = 0; pass < n_pass; ++pass) {')
     A('    const int eb = e_beg + 32 * pass;')
     A('    const int n_e = live ? max(0, min(32, e_end - eb)) : 0;  // edges of this pass: tile 0 = [0,16), tile 1 = [16,32)')
@@ -1122,154 +1263,164 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     SF(1, '    ')
     A('    int sidx = 0, buf = 0;')
     A(f'    f32x4 xq[{MAXD1}];  // the next stage\'s slice, in flight: lane L holds channels 4 (L & 3) .. + 3 of edge L >> 2')
+    cx.emit_x_loads('    ', 0, '0', 0)
 
-    def emit_x_loads(ind, ci_, ct_expr, tl_):
-        cat_ = cats[ci_]
-        A(f'{ind}{{ const float *xs_ = x + {cat_.x_off} + 16 * ({ct_expr}) + 4 * (lane & 3) + (size_t)srs[{tl_}] * DX;')
-        for m in range(2 * cat_.l1 + 1):
-            A(f'{ind}  xq[{m}] = *reinterpret_cast<const f32x4 *>(xs_ + {m * cat_.mul});')
-        A(f'{ind}}}')
-    emit_x_loads('    ', 0, '0', 0)
-    for ci, cat in enumerate(cats):
-        d1 = 2 * cat.l1 + 1
-        nct = cat.mul // 16
-        A(f'    // ---- x block {cat.i_x}: {cat.mul}x l={cat.l1}, {len(cat.paths)} paths')
-        A(f'    for (int ct = 0; ct < {nct}; ++ct) {{')
-        for gi, grp in enumerate(fgroups[ci]):
-            n_here = len(grp)
-            # what the next block is (for the slab prefetch): next group of this ct, next ct, or the next x block
-            if gi + 1 < len(fgroups[ci]):
-                nxt = f'{len(fgroups[ci][gi + 1])}'
+
+def _fwd_block(cx: _Gen, ci: int, gi: int):
+    """one block = up to FG sub-steps of one (x block, channel tile): per tile the staged source-row slice, per path tile the w
+    product and the tensor-product body; then the reduction over the four edge groups and the 16-byte output stores"""
+    A, spec, cats, fgroups, FROW, STFL, OOLDS = cx.A, cx.spec, cx.cats, cx.fgroups, cx.FROW, cx.STFL, cx.OOLDS
+    SF, emit_x_loads, olists, oo_index = cx.SF, cx.emit_x_loads, cx.olists, cx.oo_index
+    cat, grp = cats[ci], fgroups[ci][gi]
+    d1, nct = 2 * cat.l1 + 1, cat.mul // 16
+    n_here = len(grp)
+    # what the next block is (for the slab prefetch): next group of this ct, next ct, or the next x block
+    if gi + 1 < len(fgroups[ci]):
+        nxt = f'{len(fgroups[ci][gi + 1])}'
+    else:
+        n_first = len(fgroups[ci][0])
+        n_next_cat = len(fgroups[ci + 1][0]) if ci + 1 < len(cats) else 0
+        nxt = f'(ct + 1 < {nct} ? {n_first} : {n_next_cat})'
+    ol = olists[(ci, gi)]
+    A('      {')
+    A(f'        const int n_next = (sidx + {n_here} < NS) ? {nxt} : 0;')
+    A(f'        const int s_next = sidx + {n_here};')
+    A('        const u32x4 *sl = slab[buf];')
+    for _, pr in grp:
+        for pi in pr:
+            if pi is not None:
+                A(f'        float acc{pi}[{2 * spec.paths[pi].l3 + 1}];')
+                A('#pragma unroll')
+                A(f'        for (int i = 0; i < {2 * spec.paths[pi].l3 + 1}; ++i) acc{pi}[i] = 0.f;')
+    # The 16 source rows' slice of a tile reaches LDS through registers that were loaded ONE STAGE AHEAD (stage =
+    # (block, tile)): without the prefetch every stage exposed a full gather latency -- the waves of this kernel
+    # spent 50 % of their cycles in s_waitcnt (SQ_WAIT_ANY, profiles/r02_pmc_sq_fused_kernels.txt).
+    def emit_next_block_loads(ind):
+        if gi + 1 < len(fgroups[ci]):
+            emit_x_loads(ind, ci, 'ct', 0)        # the next group of this (x block, channel tile): same slice
+            return
+        has_next_cat = ci + 1 < len(cats)
+        if nct > 1:
+            A(f'{ind}if (ct + 1 < {nct}) {{')
+            emit_x_loads(ind + '  ', ci, 'ct + 1', 0)
+            A(f'{ind}}}' + (' else {' if has_next_cat else ''))
+            if has_next_cat:
+                emit_x_loads(ind + '  ', ci + 1, '0', 0)
+                A(f'{ind}}}')
+        elif has_next_cat:
+            emit_x_loads(ind, ci + 1, '0', 0)
+    for tl in range(2):
+        A(f'        if ({"true" if tl == 0 else "two"}) {{  // tile {tl}')
+        A('          {  // stage the 16 source rows\' slice: [m][r][g][channel], conflict-free for the reads below')
+        A('            __builtin_amdgcn_wave_barrier();  // every read of the previous tile\'s slice has been issued')
+        A('            float *xw = &s_x[wave][(((lane >> 2) & 3) * 4 + (lane >> 4)) * 16 + 4 * (lane & 3)];')
+        for m in range(d1):
+            A(f'            *reinterpret_cast<f32x4 *>(xw + {m * 256}) = xq[{m}];')
+        if tl == 0:
+            A('            if (two) {')
+            emit_x_loads('              ', ci, 'ct', 1)
+            A('            } else {')
+            emit_next_block_loads('              ')
+            A('            }')
+            # the next block's weight fragments are requested AFTER the slice prefetch: vmcnt retires in order,
+            # and the wait in front of the next slice store must not also wait for a slab that was just requested
+            A('            if (n_next) stage_load(s_next, n_next, buf ^ 1);')
+        else:
+            emit_next_block_loads('            ')
+        A('            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch up here')
+        A('            __builtin_amdgcn_wave_barrier();')
+        A('          }')
+        SF(2, '          ')
+        A(f'          float xr[4][{d1}];')
+        A('#pragma unroll')
+        A('          for (int r = 0; r < 4; ++r)')
+        A('#pragma unroll')
+        A(f'            for (int m = 0; m < {d1}; ++m) xr[r][m] = s_x[wave][m * 256 + r * 64 + lane];')
+        A(f'          const float *ysl = &s_ys[wave][(16 * {tl} + 4 * g) * NSHP];')
+        SF(3, '          ')
+        chain = [(ls, tp, pi) for ls, pr in grp for tp, pi in enumerate(pr) if pi is not None]
+        for k, (ls, tp, pi) in enumerate(chain):
+            A(f'          {{  // sub-step {ls} of the block, tile {tp}: path {pi}')
+            A('            f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
+            A('#pragma unroll')
+            A('            for (int q = 0; q < 2; ++q) {')
+            A('              bf16x8 bfr[NT];')
+            A('#pragma unroll')
+            A(f'              for (int tm = 0; tm < NT; ++tm) bfr[tm] = as_bf16x8(sl[(({ls - grp[0][0]} * 4 + {tp} * 2 + q) * NT + tm) * 64 + lane]);')
+            A(f'              wv = mfma16_split<NT, F16>(ha[{tl}][q], bfr, wv);')
+            A('            }')
+            A('#pragma unroll')
+            if FROW:
+                A(f'            for (int r = 0; r < 4; ++r) wv[r] = (r < rows_t[{tl}] && g * rows_t[{tl}] + r < m_t[{tl}]) ? (F16 ? wv[r] * w_unscale[{tl}] : wv[r]) : 0.f;')
             else:
-                n_first = len(fgroups[ci][0])
-                n_next_cat = len(fgroups[ci + 1][0]) if ci + 1 < len(cats) else 0
-                nxt = f'(ct + 1 < {nct} ? {n_first} : {n_next_cat})'
-            ol = olists[(ci, gi)]
-            A('      {')
-            A(f'        const int n_next = (sidx + {n_here} < NS) ? {nxt} : 0;')
-            A(f'        const int s_next = sidx + {n_here};')
-            A('        const u32x4 *sl = slab[buf];')
-            for _, pr in grp:
-                for pi in pr:
-                    if pi is not None:
-                        A(f'        float acc{pi}[{2 * spec.paths[pi].l3 + 1}];')
-                        A('#pragma unroll')
-                        A(f'        for (int i = 0; i < {2 * spec.paths[pi].l3 + 1}; ++i) acc{pi}[i] = 0.f;')
-            # The 16 source rows' slice of a tile reaches LDS through registers that were loaded ONE STAGE AHEAD (stage =
-            # (block, tile)): without the prefetch every stage exposed a full gather latency -- the waves of this kernel
-            # spent 50 % of their cycles in s_waitcnt (SQ_WAIT_ANY, profiles/r02_pmc_sq_fused_kernels.txt).
-            def emit_next_block_loads(ind):
-                if gi + 1 < len(fgroups[ci]):
-                    emit_x_loads(ind, ci, 'ct', 0)        # the next group of this (x block, channel tile): same slice
-                    return
-                has_next_cat = ci + 1 < len(cats)
-                if nct > 1:
-                    A(f'{ind}if (ct + 1 < {nct}) {{')
-                    emit_x_loads(ind + '  ', ci, 'ct + 1', 0)
-                    A(f'{ind}}}' + (' else {' if has_next_cat else ''))
-                    if has_next_cat:
-                        emit_x_loads(ind + '  ', ci + 1, '0', 0)
-                        A(f'{ind}}}')
-                elif has_next_cat:
-                    emit_x_loads(ind, ci + 1, '0', 0)
-            for tl in range(2):
-                A(f'        if ({"true" if tl == 0 else "two"}) {{  // tile {tl}')
-                A('          {  // stage the 16 source rows\' slice: [m][r][g][channel], conflict-free for the reads below')
-                A('            __builtin_amdgcn_wave_barrier();  // every read of the previous tile\'s slice has been issued')
-                A('            float *xw = &s_x[wave][(((lane >> 2) & 3) * 4 + (lane >> 4)) * 16 + 4 * (lane & 3)];')
-                for m in range(d1):
-                    A(f'            *reinterpret_cast<f32x4 *>(xw + {m * 256}) = xq[{m}];')
-                if tl == 0:
-                    A('            if (two) {')
-                    emit_x_loads('              ', ci, 'ct', 1)
-                    A('            } else {')
-                    emit_next_block_loads('              ')
-                    A('            }')
-                    # the next block's weight fragments are requested AFTER the slice prefetch: vmcnt retires in order,
-                    # and the wait in front of the next slice store must not also wait for a slab that was just requested
-                    A('            if (n_next) stage_load(s_next, n_next, buf ^ 1);')
-                else:
-                    emit_next_block_loads('            ')
-                A('            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch up here')
-                A('            __builtin_amdgcn_wave_barrier();')
-                A('          }')
-                SF(2, '          ')
-                A(f'          float xr[4][{d1}];')
-                A('#pragma unroll')
-                A('          for (int r = 0; r < 4; ++r)')
-                A('#pragma unroll')
-                A(f'            for (int m = 0; m < {d1}; ++m) xr[r][m] = s_x[wave][m * 256 + r * 64 + lane];')
-                A(f'          const float *ysl = &s_ys[wave][(16 * {tl} + 4 * g) * NSHP];')
-                SF(3, '          ')
-                chain = [(ls, tp, pi) for ls, pr in grp for tp, pi in enumerate(pr) if pi is not None]
-                for k, (ls, tp, pi) in enumerate(chain):
-                    A(f'          {{  // sub-step {ls} of the block, tile {tp}: path {pi}')
-                    A('            f32x4 wv = f32x4{0.f, 0.f, 0.f, 0.f};')
-                    A('#pragma unroll')
-                    A('            for (int q = 0; q < 2; ++q) {')
-                    A('              bf16x8 bfr[NT];')
-                    A('#pragma unroll')
-                    A(f'              for (int tm = 0; tm < NT; ++tm) bfr[tm] = as_bf16x8(sl[(({ls - grp[0][0]} * 4 + {tp} * 2 + q) * NT + tm) * 64 + lane]);')
-                    A(f'              wv = mfma16_split<NT, F16>(ha[{tl}][q], bfr, wv);')
-                    A('            }')
-                    A('#pragma unroll')
-                    if FROW:
-                        A(f'            for (int r = 0; r < 4; ++r) wv[r] = (r < rows_t[{tl}] && g * rows_t[{tl}] + r < m_t[{tl}]) ? (F16 ? wv[r] * w_unscale[{tl}] : wv[r]) : 0.f;')
-                    else:
-                        A(f'            for (int r = 0; r < 4; ++r) wv[r] = (16 * {tl} + 4 * g + r < n_e) ? (F16 ? wv[r] * w_unscale[{tl}] : wv[r]) : 0.f;')
-                    SF(4, '            ', light=False)
-                    A(f'            if (!(diag & 1)) fwdf_p{pi}(xr, ysl, wv, acc{pi}, {f"rows_t[{tl}]" if FROW else "4"});  // opaque branch: see the reverse kernel')
-                    SF(5, '            ', light=False)
-                    A('          }')
-                SF(5, '          ', light=STFL)
-                A('        }')
-            # reduce over the 4 edge groups, park in LDS, write out with 16-byte stores
-            for q, (pi, m3) in enumerate(ol):
-                A(f'        acc{pi}[{m3}] = snet::swap_add16(acc{pi}[{m3}], acc{pi}[{m3}]);')
-                A(f'        acc{pi}[{m3}] = snet::swap_add32(acc{pi}[{m3}], acc{pi}[{m3}]);')
-            A('        __builtin_amdgcn_wave_barrier();')
-            A('        if (g == 0) {')
-            for q, (pi, m3) in enumerate(ol):
-                A(f'          s_o[wave][{q} * 16 + c] = acc{pi}[{m3}] * scale;')
-            A('        }')
-            A('        __builtin_amdgcn_wave_barrier();')
-            for k in range((len(ol) + 15) // 16):
-                if OOLDS:
-                    A(f'        if (const int oo_ = s_ooff[{16 * oo_index[(ci, gi, k)]} + (lane >> 2)]; live && oo_ >= 0) {{')
-                    A('          float *o = onode + oo_ + 16 * ct;')
-                else:
-                    A(f'        if (live && ooff{ci}_{gi}_{k} >= 0) {{')
-                    A(f'          float *o = onode + ooff{ci}_{gi}_{k} + 16 * ct;')
-                A(f'          f32x4 v = *reinterpret_cast<const f32x4 *>(&s_o[wave][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]);')
-                A('          if (pass) v += *reinterpret_cast<const f32x4 *>(o);')
-                A('          *reinterpret_cast<f32x4 *>(o) = v;')   # (streaming stores here: measured neutral, round 4)
-                A('        }')
-            SF(6, '        ')
-            A('        if (n_next) stage_store(n_next, buf ^ 1);')
-            SF(7, '        ')
-            A('        __syncthreads();')
-            SF(8, '        ')
-            A('        buf ^= 1;')
-            A(f'        sidx += {n_here};')
-            A('      }')
+                A(f'            for (int r = 0; r < 4; ++r) wv[r] = (16 * {tl} + 4 * g + r < n_e) ? (F16 ? wv[r] * w_unscale[{tl}] : wv[r]) : 0.f;')
+            SF(4, '            ', light=False)
+            A(f'            if (!(diag & 1)) fwdf_p{pi}(xr, ysl, wv, acc{pi}, {f"rows_t[{tl}]" if FROW else "4"});  // opaque branch: see the reverse kernel')
+            SF(5, '            ', light=False)
+            A('          }')
+        SF(5, '          ', light=STFL)
+        A('        }')
+    # reduce over the 4 edge groups, park in LDS, write out with 16-byte stores
+    for q, (pi, m3) in enumerate(ol):
+        A(f'        acc{pi}[{m3}] = snet::swap_add16(acc{pi}[{m3}], acc{pi}[{m3}]);')
+        A(f'        acc{pi}[{m3}] = snet::swap_add32(acc{pi}[{m3}], acc{pi}[{m3}]);')
+    A('        __builtin_amdgcn_wave_barrier();')
+    A('        if (g == 0) {')
+    for q, (pi, m3) in enumerate(ol):
+        A(f'          s_o[wave][{q} * 16 + c] = acc{pi}[{m3}] * scale;')
+    A('        }')
+    A('        __builtin_amdgcn_wave_barrier();')
+    for k in range((len(ol) + 15) // 16):
+        if OOLDS:
+            A(f'        if (const int oo_ = s_ooff[{16 * oo_index[(ci, gi, k)]} + (lane >> 2)]; live && oo_ >= 0) {{')
+            A('          float *o = onode + oo_ + 16 * ct;')
+        else:
+            A(f'        if (live && ooff{ci}_{gi}_{k} >= 0) {{')
+            A(f'          float *o = onode + ooff{ci}_{gi}_{k} + 16 * ct;')
+        A(f'          f32x4 v = *reinterpret_cast<const f32x4 *>(&s_o[wave][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]);')
+        A('          if (pass) v += *reinterpret_cast<const f32x4 *>(o);')
+        A('          *reinterpret_cast<f32x4 *>(o) = v;')   # (streaming stores here: measured neutral, round 4)
+        A('        }')
+    SF(6, '        ')
+    A('        if (n_next) stage_store(n_next, buf ^ 1);')
+    SF(7, '        ')
+    A('        __syncthreads();')
+    SF(8, '        ')
+    A('        buf ^= 1;')
+    A(f'        sidx += {n_here};')
+    A('      }')
+
+
+def _emit_forward_kernel(cx: _Gen):
+    A = cx.A
+    _fwd_prologue(cx)
+    _fwd_pass_top(cx)
+    for ci, cat in enumerate(cx.cats):
+        A(f'    // ---- x block {cat.i_x}: {cat.mul}x l={cat.l1}, {len(cat.paths)} paths')
+        A(f'    for (int ct = 0; ct < {cat.mul // 16}; ++ct) {{')
+        for gi in range(len(cx.fgroups[ci])):
+            _fwd_block(cx, ci, gi)
         A('    }')
     A('  }')
-    if STF:
+    if cx.STF:
         A('  if (lane == 0 && live && n_raw < SNET_STAMP_TILES) {')
         A('    for (int i = 0; i < 16; ++i) snet_stamps[n_raw * 16 + i] = ph[i];')
         A('  }')
     A('}')
     A('')
 
-    # ------------------------------------------------------------------ launchers
-    def variants(default, fwd=False):
-        combos = [default]
-        if exp:
-            cand = ((4, 0, 2), (8, 0, 2), (8, 1, 2), (4, 0, 3), (12, 0, 3), (12, 1, 3)) if fwd else \
-                ((4, 0, 2), (8, 0, 2), (8, 1, 2), (4, 0, 3), (4, 1, 3), (12, 0, 3), (12, 1, 3), (8, 1, 4), (8, 0, 4), (8, 0, 3))
-            combos += [v for v in cand if v != default]
-        return combos
 
+def _variants(exp, default, fwd=False):
+    combos = [default]
+    if exp:
+        cand = ((4, 0, 2), (8, 0, 2), (8, 1, 2), (4, 0, 3), (12, 0, 3), (12, 1, 3)) if fwd else \
+            ((4, 0, 2), (8, 0, 2), (8, 1, 2), (4, 0, 3), (4, 1, 3), (12, 0, 3), (12, 1, 3), (8, 1, 4), (8, 0, 4), (8, 0, 3))
+        combos += [v for v in cand if v != default]
+    return combos
+
+
+def _emit_launch_bwd(cx: _Gen):
+    A, tag, exp, def_b, bwd_cfg = cx.A, cx.tag, cx.exp, cx.def_b, cx.bwd_cfg
     A('template <int NT, bool F16, int NWV, bool GLDS, int OCC>')
     A('void launch_bwd_t(const float *x, const float *sh, const float *dsh, const float *h2, const int32_t *w_row,')
     A('                  const int32_t *row_ptr, const int32_t *src, const int32_t *tile_ptr, const int32_t *tile_node, int64_t n_tiles,')
@@ -1294,36 +1445,10 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     if exp:
         A('  int vw = %d, vg = %d, vo = %d;' % def_b)
         A('  if (const char *e = getenv("SNET_FV_BWD")) sscanf(e, "%d,%d,%d", &vw, &vg, &vo);')
-        for (w, gl, oc) in variants(def_b):
+        for (w, gl, oc) in _variants(exp, def_b):
             for nt_ in (3, 2):
                 A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
             A(f'  if (nt == 4 && vw == {w} && vg == {gl} && vo == {oc}) return launch_bwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
-    def bwd_lds(nt, nwv):
-        return 2 * 8 * nt * 1024 + nwv * (2 * NGP * 64 + (128 if XT else 0) + NSH * 64)
-
-    def bwd_cfg(nt):
-        # measured on MI355X (SevenNet-0 middle layer): three 4-wave workgroups per CU (LDS <= 53 KB each, <= 168
-        # VGPRs) beat two; when the slab does not leave room for three, two 4-wave workgroups at 256 VGPRs
-        if 'fnwv' in OPTS:
-            return def_b
-        # first interaction layer (scalar inputs only, one x block): one 8-wave workgroup sharing each slab beats three
-        # 4-wave ones (in the step: 1.76 vs 2.01 ms).  NOT the last layer's shape (three one-path x blocks): 8 waves
-        # win its stand-alone timing (3.21 vs 3.46 ms) but lose inside the step with the hidden-layer tail (4.04 vs 3.53)
-        if len(cats) == 1 and bwd_lds(nt, 8) <= 80 * 1024:
-            return (8, 0, 2)
-        # three waves per SIMD only where the kernel's live state fits 168 VGPRs: source rows, their prefetch and their
-        # gradient (3 x 4 d1), h2^T split and g_h2 accumulators (32), Y gradient, g_out prefetch, slab staging, one
-        # path's g_out entries, addresses / scales.  The SevenNet-0 middle layer needs ~200: at 168 the compiler spilled
-        # 38 registers and the spill traffic queues with the prefetch loads (round 3, same box: 6.80 ms at three waves
-        # with spills, 6.43 at two waves without)
-        maxd1 = max(2 * c.l1 + 1 for c in cats)
-        maxd3 = max(2 * p.l3 + 1 for p in spec.paths)
-        live = 12 * maxd1 + 32 + NSH + 4 * GS * NK + 16 + 4 * maxd3 + 35
-        if bwd_lds(nt, 4) <= 53 * 1024 and live <= (160 if XT else 168):   # (packed tiles: 164 estimated spilled 20 at 168)
-            return (4, 0, 3)
-        if bwd_lds(nt, 4) <= 80 * 1024:
-            return (4, 0, 2)
-        return (2, 0, 2)
     w, gl, oc = bwd_cfg(2)
     A(f'  if (nt == 4) launch_bwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
     for nt_, kw in ((3, 'else if'), (2, 'else if'), (1, 'else')):
@@ -1331,6 +1456,10 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         cond = f' (nt == {nt_})' if kw != 'else' else ''
         A(f'  {kw}{cond} launch_bwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_b});')
     A('}')
+
+
+def _emit_launch_fwd(cx: _Gen):
+    A, tag, exp, def_f, fwd_cfg = cx.A, cx.tag, cx.exp, cx.def_f, cx.fwd_cfg
     A('template <int NT, bool F16, int NWV, bool GLDS, int OCC>')
     A('void launch_fwd_t(const float *x, const float *sh, const float *h2, const int32_t *w_row, const int32_t *row_ptr,')
     A('                  const int32_t *src, int64_t n_dst, const void *slabs, float scale, float *out, int w2_exp, hipStream_t st) {')
@@ -1347,28 +1476,12 @@ def gen_conv_fused(spec: ConvSpec) -> str:
     if exp:
         A('  int vw = %d, vg = %d, vo = %d;' % def_f)
         A('  if (const char *e = getenv("SNET_FV_FWD")) sscanf(e, "%d,%d,%d", &vw, &vg, &vo);')
-        for (w, gl, oc) in variants(def_f, True):
+        for (w, gl, oc) in _variants(exp, def_f, True):
             for nt_ in (3, 2):
                 if nt_ == 3 and w > 8:
                     continue   # would not fit the 160-KB LDS
                 A(f'  if (nt == {nt_} && vw == {w} && vg == {gl} && vo == {oc}) return launch_fwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
             A(f'  if (nt == 4 && vw == {w} && vg == {gl} && vo == {oc}) return launch_fwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
-    def fwd_lds(nt, nwv):
-        return 2 * LPB * 4 * nt * 1024 + nwv * (32 * NSHP * 4 + MAXD1 * 1024 + NOEP * 64) + 4 * nwv + (64 * N_OOFF if OOLDS else 0)
-
-    def fwd_cfg(nt):
-        # measured: occupancy decides -- one 12-wave workgroup per CU at <= 168 VGPRs (3 waves per SIMD, direct
-        # global->LDS staging) where the LDS and the register count of this nt allow it, 8 or 4 waves otherwise
-        if 'fnwvf' in OPTS:
-            return def_f
-        if len(cats) == 1 and fwd_lds(nt, 8) <= 80 * 1024:   # first layer (scalar inputs only): 0.87 vs 1.03 ms at 12 waves;
-            return (8, 0, 2)                                   # slabs staged through registers: 0.85 vs 1.00 ms direct
-        if nt <= 2 and fwd_lds(nt, 12) <= 160 * 1024:
-            return (12, 0 if OPTS.get('f12reg') else 1, 3)
-        for w in (8, 4, 2, 1):
-            if fwd_lds(nt, w) <= 160 * 1024:
-                return (w, 1, 2)
-        raise NotImplementedError(f'conv shape {spec.key}: the fused forward kernel does not fit the LDS')
     w, gl, oc = fwd_cfg(2)
     A(f'  if (nt == 4) launch_fwd_t<2, true, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
     for nt_, kw in ((3, 'else if'), (2, 'else if'), (1, 'else')):
@@ -1376,10 +1489,14 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         cond = f' (nt == {nt_})' if kw != 'else' else ''
         A(f'  {kw}{cond} launch_fwd_t<{nt_}, false, {w}, {"true" if gl else "false"}, {oc}>({args_f});')
     A('}')
+
+
+def _emit_registration(cx: _Gen):
+    A, tag, XT, cols_rev = cx.A, cx.tag, cx.XT, cx.cols_b
     A(f'const snet::FusedKernels kernels = {{"{tag}", DX, DOUT, NSH, WN, NS, SUB_COLS, {len(cols_rev)}, SUB_COLS_B, GXE_CHUNK, launch_bwd, launch_fwd, {1 if XT else 0}}};')
     A('const snet::FusedRegistrar registrar(&kernels);')
     A('}  // namespace')
-    if tag in (OPTS.get('stamp'), OPTS.get('stampl'), OPTS.get('stampf'), OPTS.get('stampfl')):
+    if cx.stamped:
         A('// out[0 .. 15] = per-phase cycle sums over the tiles of the LAST launch, out[31] = number of tiles that reported')
         A('extern "C" int snet_debug_stamps(unsigned long long *out, int reset) {')
         A('  static unsigned *host = nullptr;')
@@ -1399,4 +1516,15 @@ def gen_conv_fused(spec: ConvSpec) -> str:
         A('  if (reset) { void *dev = nullptr; if (hipGetSymbolAddress(&dev, HIP_SYMBOL(snet_stamps)) != hipSuccess || hipMemset(dev, 0, bytes) != hipSuccess) return 1; }')
         A('  return 0;')
         A('}')
-    return '\n'.join(L) + '\n'
+
+
+def gen_conv_fused(spec: ConvSpec) -> str:
+    cx = _Gen(spec)
+    _emit_header(cx)
+    _emit_path_functions(cx)
+    _emit_reverse_kernel(cx)
+    _emit_forward_kernel(cx)
+    _emit_launch_bwd(cx)
+    _emit_launch_fwd(cx)
+    _emit_registration(cx)
+    return '\n'.join(cx.L) + '\n'

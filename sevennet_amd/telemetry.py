@@ -4,8 +4,8 @@ Why it exists: the two fused tensor-product kernels run at 
 build moves with the clock the box's power manager settles at -- a bench line has to carry the clock and the power it was
 measured under, or a 5 % swing between two boxes cannot be told from a regression.
 
-librocm_smi64 through ctypes (the library behind `rocm-smi`; no subprocess), read by a side thread every `period_s` while the
-main thread enqueues and waits.  The readings are SMU queries that contend with command submission (sampling inside a timed
+librocm_smi64 through ctypes (the library behind `rocm-smi`), read every `period_s` by a child process while the measured
+process enqueues and waits.  The readings are SMU queries that contend with command submission (sampling inside a timed
 bracket of twenty 39.8-ms steps produced one 61-ms step), so bench.py samples over a REPEAT of its timed steps, outside the
 bracket.  Everything is best effort: a box without the library or without the sensor reports `None` fields, never an exception
 into the measurement.
@@ -14,7 +14,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-import threading
 import time
 from typing import Dict, List, Optional
 
@@ -71,30 +70,50 @@ def sample(dev: int = 0) -> Dict[str, Optional[float]]:
     return out
 
 
+def physical_index(visible_index: int) -> int:
+    """rocm_smi numbers the node's GPUs; a process under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES numbers its own subset"""
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v:
+            ids = [x.strip() for x in v.split(',')]
+            if visible_index < len(ids) and ids[visible_index].isdigit():
+                return int(ids[visible_index])
+    return visible_index
+
+
 class Sampler:
-    """with Sampler(dev) as s: <timed region> ; s.summary() -> medians + ranges over the samples taken meanwhile"""
+    """with Sampler(dev) as s: <region> ; s.summary() -> medians + ranges over the samples taken meanwhile.
+    The readings come from a CHILD process (`python -m sevennet_amd.telemetry --watch`): librocm_smi64 initialised a second time
+    inside a process that also runs RCCL (which holds its own rocm_smi session) aborted at exit -- SIGABRT in the world-1 RCCL soak --,
+    and a child cannot hold the GIL or a driver lock of the measured process either."""
 
     def __init__(self, dev: int = 0, period_s: float = 0.02):
-        self.dev, self.period = dev, period_s
+        self.dev, self.period = physical_index(dev), period_s
         self.rows: List[Dict[str, Optional[float]]] = []
-        self._stop = threading.Event()
-        self._thr: Optional[threading.Thread] = None
-
-    def _run(self):
-        while not self._stop.is_set():
-            self.rows.append(sample(self.dev))
-            self._stop.wait(self.period)
+        self._proc = None
+        self._ok = False
 
     def __enter__(self):
-        if _load() is not None:
-            self._thr = threading.Thread(target=self._run, daemon=True)
-            self._thr.start()
+        import subprocess
+        import sys
+        try:
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            self._proc = subprocess.Popen([sys.executable, '-m', 'sevennet_amd.telemetry', '--watch', str(self.period), '--dev', str(self.dev)],
+                                          cwd=root, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            first = self._proc.stdout.readline()          # 'ready' once the library is initialised (or 'unavailable')
+            self._ok = first.strip() == 'ready'
+        except Exception:  # noqa: BLE001
+            self._proc = None
         return self
 
     def __exit__(self, *exc):
-        self._stop.set()
-        if self._thr is not None:
-            self._thr.join(timeout=2.0)
+        import json
+        if self._proc is not None:
+            try:
+                out, _ = self._proc.communicate(input='stop\n', timeout=5.0)
+                self.rows = [json.loads(ln) for ln in out.splitlines() if ln.startswith('{')]
+            except Exception:  # noqa: BLE001
+                self._proc.kill()
         return False
 
     def summary(self) -> Dict[str, object]:
@@ -102,8 +121,8 @@ class Sampler:
             v = sorted(r[key] for r in self.rows if r.get(key) is not None)
             return (round(v[len(v) // 2], 1), round(v[0], 1), round(v[-1], 1)) if v else (None, None, None)
         out: Dict[str, object] = dict(telemetry_samples=len(self.rows),
-                                      telemetry_source='librocm_smi64 (side thread, one reading per %d ms over a repeat of the timed steps)' % int(self.period * 1e3)
-                                      if _load() is not None else 'unavailable (librocm_smi64 not loadable)')
+                                      telemetry_source='librocm_smi64 in a child process, one reading per %d ms over a repeat of the timed steps' % int(self.period * 1e3)
+                                      if self._ok else 'unavailable (librocm_smi64 not loadable)')
         for key in ('sclk_mhz', 'socket_power_w', 'temp_edge_c', 'temp_junction_c'):
             m, lo, hi = med(key)
             out[key] = m
@@ -112,6 +131,29 @@ class Sampler:
         return out
 
 
-if __name__ == '__main__':   # python -m sevennet_amd.telemetry : one reading
-    t0 = time.perf_counter()
-    print(sample(0), f'{(time.perf_counter() - t0) * 1e3:.2f} ms')
+def _watch(period: float, dev: int):
+    """child side of Sampler: print one JSON reading per period until a line arrives on stdin (or it closes)"""
+    import json
+    import select
+    import sys
+    print('ready' if _load() is not None else 'unavailable', flush=True)
+    if _load() is None:
+        return
+    while True:
+        print(json.dumps(sample(dev)), flush=True)
+        r, _, _ = select.select([sys.stdin], [], [], period)
+        if r:
+            return
+
+
+if __name__ == '__main__':   # python -m sevennet_amd.telemetry [--watch PERIOD] [--dev N]: one reading, or the Sampler's child
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--watch', type=float, default=0.0)
+    ap.add_argument('--dev', type=int, default=0)
+    a = ap.parse_args()
+    if a.watch > 0:
+        _watch(a.watch, a.dev)
+    else:
+        t0 = time.perf_counter()
+        print(sample(a.dev), f'{(time.perf_counter() - t0) * 1e3:.2f} ms')

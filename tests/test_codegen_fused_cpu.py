@@ -213,3 +213,26 @@ def test_forward_short_tile_row_order():
             assert all(rows[k] == k for k in range(16))
         if m == 12:                                                 # the diamond-cubic second tile: rows {0, 1, 2} of every group
             assert sorted(rows.values()) == [4 * g + r for g in range(4) for r in range(3)]
+
+
+def test_generated_sources_are_the_committed_ones():
+    """Tripwire around generator refactors: the source generated for every ahead-of-time fused shape must be
+    byte-identical to the one whose sha1 is committed in tests/golden/fused_kernel_sha1.json.  A deliberate kernel change
+    regenerates the table (tools/update_kernel_hashes.py) in the same commit; a restructuring of the generator must not move it."""
+    import hashlib
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'fused_kernel_sha1.json')) as f:
+        want = json.load(f)
+    got = {tag: hashlib.sha1(codegen_fused.gen_conv_fused(sp).encode()).hexdigest() for tag, sp in FUSABLE.items()}
+    assert sorted(got) == sorted(want)
+    assert [t for t in got if got[t] != want[t]] == []
+
+
+def test_generator_functions_stay_reviewable():
+    """no function of the fused-kernel generator over 300 lines (it was one 1 462-line function through round 5)"""
+    import ast
+    import inspect
+    tree = ast.parse(inspect.getsource(codegen_fused))
+    long = [(n.name, n.end_lineno - n.lineno + 1) for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.end_lineno - n.lineno + 1 > 300]
+    assert long == []
