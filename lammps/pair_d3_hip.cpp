@@ -106,7 +106,10 @@ double PairD3Hip::init_one(int i, int j) {
 
 // energy, forces, virial of the whole periodic cell held by this process            (pair_d3.cu:1970-2021)
 void PairD3Hip::compute(int eflag, int vflag) {
-  ev_init(eflag, vflag);
+  if (eflag || vflag)   // (the reference's own idiom, pair_e3gnn.cpp:80-83 / pair_d3.cu:2000)
+    ev_setup(eflag, vflag);
+  else
+    evflag = vflag_fdotr = 0;
   const int n = (int)atom->natoms;
   if (n != atom->nlocal) error->all(FLERR, "pair_style d3 is a one-process style (like the reference's CUDA version)");
   xflat.resize((size_t)n * 3);

@@ -208,7 +208,10 @@ void PairE3GNNHip::build_halo_plan() {
 }
 
 void PairE3GNNHip::compute(int eflag, int vflag) {
-  ev_init(eflag, vflag);
+  if (eflag || vflag)   // (the reference's own idiom, pair_e3gnn.cpp:80-83 / pair_d3.cu:2000)
+    ev_setup(eflag, vflag);
+  else
+    evflag = vflag_fdotr = 0;
   if (ghost_mode == 1 && vflag_atom) error->all(FLERR, "atomic stress is not supported\n");
   // an empty sub-domain: the reference's parallel style fails inside LibTorch there (docs/source/user_guide/lammps_torch.md:
   // 111-113: "encounters an error when one of the subdomain cells contains no atoms"); this one stops with a message that names

@@ -108,8 +108,10 @@ def _emit_staging(A, lines: str):
     A('        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(slabs + (size_t)s * (LPS * 64) + l * 64 + lane),')
     A('                                         (__attribute__((address_space(3))) void *)(&slab[b][l * 64]), 16, 0, 0);')
     A('    } else {')
+    # (wave-uniform 64-bit base + unsigned 32-bit lane offset: the SGPR-base form of global_load, no 64-bit vector adds per sub-step)
+    A('      const u32x4 *sp = slabs + (size_t)s * (LPS * 64);')
     A('#pragma unroll')
-    A(f'      for (int i = 0; i < NST; ++i) if (({lines} * 64) % NTH == 0 || tid + NTH * i < {lines} * 64) st[i] = slabs[(size_t)s * (LPS * 64) + tid + NTH * i];')
+    A(f'      for (int i = 0; i < NST; ++i) if (({lines} * 64) % NTH == 0 || tid + NTH * i < {lines} * 64) st[i] = sp[(unsigned)(tid + NTH * i)];')
     A('    }')
     A('  };')
     A('  auto stage_store = [&](int b) {')
@@ -454,7 +456,7 @@ class _Gen:
         A, glists, GRAW, XT = self.A, self.glists, self.GRAW, self.XT
         gl = glists[ci]
         for k in range((len(gl) + 15) // 16):
-            sc_ = ' * scale' if GRAW else ''
+            sc_ = ' * g_park'
             A(f'{ind}*reinterpret_cast<f32x4 *>(&s_g[wave][{"0" if XT else buf_expr}][(16 * {k} + (lane >> 2)) * 16 + 4 * (lane & 3)]) = gpre[{k}]{sc_};')
         if XT:
             A(f'{ind}if (two) {{')
@@ -688,24 +690,31 @@ def _rev_prologue(cx: _Gen):
     A('  float gy[NSH];')
     A('#pragma unroll')
     A('  for (int k = 0; k < NSH; ++k) gy[k] = 0.f;')
+    # fp16 terms, g_h2 += W2 g_w^T: the operand g_w[edge, channel] = sum_abc C_abc G_c x_a Y_b of a path is bounded by
+    # (sum |C|) max|G| max|x| max|Y|.  ONE power of two per tile (round 6; it was one per edge) puts the largest bound of the tile's 16
+    # edges below 2^F16_TOP -- no entry can overflow fp16, entries down to 2^-17 of the tile's bound keep all 22 bits -- and, being
+    # wave-uniform, it rides on the multiply that parks the node's g_out entries (g_park = scale 2^kg): the tensor-product bodies then
+    # produce g_w 2^kg directly, and the eight multiplies per sub-step in front of the operand split are gone.  Likewise the matrix
+    # product's own factor w_unscale is no longer applied to w: the bodies run on the raw accumulators, which leaves g_x and dE/dY
+    # times 2^kg / w_unscale -- undone once per block (gx_fix at the g_xe stores) and once per tile (epilogue).  kg <= 60 keeps the
+    # parked entries finite whatever the bound is (an all-zero source row would otherwise ask for 2^114).
+    KC = max(sum(abs(v) for _, _, _, v in _path_terms(p)) for p in spec.paths)
+    A('  float g_sc = 1.f, g_unsc = 1.f, gx_fix = 1.f;')
+    A('  if constexpr (F16) {')
+    A('    float ym = 0.f;')
+    A('#pragma unroll')
+    A('    for (int k = 0; k < NSH; ++k) ym = fmaxf(ym, fabsf(yl[k * 16]));')
+    A(f'    const int kg = min(60, snet::F16_TOP - snet::bound_exp({_f(KC)} * fabsf(scale) * snet::wave_max(x_bound * ym)));')
+    A('    g_sc = snet::pow2f(kg);')
+    A('    g_unsc = snet::pow2f(-(kg + tail.w2_exp));')
+    A('    gx_fix = w_unscale * snet::pow2f(-kg);')
+    A('  }')
+    A('  const float g_park = ' + ('scale * g_sc' if cx.GRAW else 'g_sc') + ';   // factor of the g_out entries when they are parked in LDS')
     emit_g_park('  ', 0, '0')
     A('  stage_store(0);')
     A('  __syncthreads();')
     if HOIST:
         A('  if (1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(1, 1);   // the first block\'s first sub-step does not request its slab itself')
-    # fp16 terms, g_h2 += W2 g_w^T: the operand g_w[edge, channel] = sum_abc C_abc G_c x_a Y_b of a path is bounded by
-    # (sum |C|) max|G| max|x| max|Y|; every edge (= operand column = lane) scales its g_w by the power of two that puts
-    # this bound below 2^F16_TOP -- no entry can overflow fp16, and entries down to 2^-17 of the bound keep all 22 bits
-    KC = max(sum(abs(v) for _, _, _, v in _path_terms(p)) for p in spec.paths)
-    A('  float g_sc = 1.f, g_unsc = 1.f;')
-    A('  if constexpr (F16) {')
-    A('    float ym = 0.f;')
-    A('#pragma unroll')
-    A('    for (int k = 0; k < NSH; ++k) ym = fmaxf(ym, fabsf(yl[k * 16]));')
-    A(f'    const int kg = snet::F16_TOP - snet::bound_exp({_f(KC)} * fabsf(scale) * x_bound * ym);')
-    A('    g_sc = snet::pow2f(kg);')
-    A('    g_unsc = snet::pow2f(-(kg + tail.w2_exp));')
-    A('  }')
     A('  int sidx = 0, buf = 0, gbuf = 0;')
     S(0, '  ')
 
@@ -797,7 +806,6 @@ def _rev_substep(cx: _Gen, ci: int, si_: int, ta, tb):
         A(f'          for (int tm = 0; tm < NT; ++tm) a[tm] = as_bf16x8(sl[(({tp} * 2 + q) * NT + tm) * 64 + lane]);')
         A('          wv = mfma16_split<NT, F16>(a, hb[q], wv);')
         A('        }')
-        A('        if constexpr (F16) wv *= w_unscale;')
         if ST and not STL:
             A('        asm volatile("" :: "v"(wv[0]), "v"(wv[3]));')
         S(3 + 2 * tp, '        ')
@@ -809,7 +817,10 @@ def _rev_substep(cx: _Gen, ci: int, si_: int, ta, tb):
             A(f'        ys[{p.sh_off + b_}] = yl[{(p.sh_off + b_) * 16}];')
         # The tensor-product body sits in its own (always taken) branch on an opaque kernel argument: as
         # straight-line code hipcc's scheduler interleaves it with the surrounding matrix products and
-        # loads until ~200 VGPRs spill to scratch (measured: 692 spilled registers without the branch, 0 with)
+        # loads until ~200 VGPRs spill to scratch (measured: 692 spilled registers without the branch, 0 with).
+        # (Round 6 tried two guards that end in a trap instead -- block boundaries without an else path, hence without the
+        # never-executed zero fills and the register copies where the two paths meet: 288 spilled registers in the SevenNet-0
+        # middle layer, 1 482 .. 4 295 in the lmax-3 shapes; IR-level code motion crosses a guard it knows to be cold.)
         A(f'        gw{tp} = f32x4{{0.f, 0.f, 0.f, 0.f}};')
         A(f'        if (!(diag & 1)) bwdf_p{pi}<GX>(xr[{u}], ys, wv, G, gw{tp}, gy, gx[{u}]);')
         if ST and not STL:
@@ -817,10 +828,6 @@ def _rev_substep(cx: _Gen, ci: int, si_: int, ta, tb):
         S(4 + 2 * tp, '        ')
         A('      }')
     A('      float v[8] = {gw0[0], gw0[1], gw0[2], gw0[3], gw1[0], gw1[1], gw1[2], gw1[3]};')
-    A('      if constexpr (F16) {')
-    A('#pragma unroll')
-    A('        for (int i = 0; i < 8; ++i) v[i] *= g_sc;')
-    A('      }')
     A('      const SplitN<NT> b = splitn8<NT, F16>(v);')
     if exp:
         A('      if (diag & 2) ga[0] += f32x4{v[0], v[1], v[4], v[5]}; else')
@@ -854,6 +861,12 @@ def _rev_block_end(cx: _Gen, ci: int):
         A('    if (sidx + 1 < NSUB' + (' && !(diag & 32)' if exp else '') + ') stage_load(sidx + 1, (buf ^ 1));')
         A('    __builtin_amdgcn_sched_barrier(0);')
     A('    if (GX && g_xe && valid' + (' && !(diag & 16)' if exp else '') + ') {')
+    A('      if constexpr (F16) {   // the bodies ran on raw matrix accumulators and scaled g_out entries: back to g_x itself')
+    A('#pragma unroll')
+    A(f'        for (int u = 0; u < {U}; ++u)')
+    A('#pragma unroll')
+    A(f'          for (int m = 0; m < {d1}; ++m) gx[u][m] *= gx_fix;')
+    A('      }')
     for u in range(U):
         if gxe_std:
             A(f'      {"float *" if u == 0 else ""}o = g_xe + (size_t)e * DX + {cat.x_off} + 16 * ({U} * cb + {u}) + 4 * g;')
@@ -1078,7 +1091,7 @@ def _rev_epilogue(cx: _Gen):
     A('    gy[0] = snet::swap_add32(gy[0], gy[0]);')
     A('    if (valid && g == 0) {')
     A('#pragma unroll')
-    A('      for (int i = 0; i < NSH; ++i) tail.g_sh[(size_t)e * NSH + i] = gy[i];')
+    A('      for (int i = 0; i < NSH; ++i) tail.g_sh[(size_t)e * NSH + i] = gy[i] * gx_fix;')
     A('    }')
     A('  }')
     A('  if (dsh != nullptr && valid && g == 0) {')
@@ -1091,7 +1104,7 @@ def _rev_epilogue(cx: _Gen):
     A('      t2 = fmaf(gy[i], jd[3 * i + 2], t2);')
     A('    }')
     A('    float *o = g_vec + (size_t)e * 3;')
-    A('    o[0] += t0; o[1] += t1; o[2] += t2;')
+    A('    o[0] += t0 * gx_fix; o[1] += t1 * gx_fix; o[2] += t2 * gx_fix;   // (gx_fix: the bodies\' common factor, see the prologue)')
     A('  }')
     if ST:
         S(13, '  ')
@@ -1220,37 +1233,49 @@ def _fwd_pass_top(cx: _Gen):
         A('    auto edge_of_row = [&](int tl, int row) { return 16 * tl + (row >> 2) * rows_t[tl] + (row & 3); };  // (rows r >= R alias a neighbour\'s edge: never used)')
     else:
         A('    auto edge_of_row = [&](int tl, int row) { return 16 * tl + row; };')
-    A('    // per tile: A fragments of h2 (row = edge lane & 15) and the source row this lane stages (edge lane >> 2)')
+    # Round 6: (1) the h2 rows of a tile's EMPTY rows are zero, so the matrix product itself returns w = 0 there and the per-path
+    # mask of its result (4 selects + 4 multiplies per path tile) is gone; (2) ONE power-of-two scale for the h2 rows of both tiles
+    # of the pass, so its inverse rides on the multiply that scales the output rows (o_scale) instead of on every w tile.
+    A('    // per tile: A fragments of h2 (row = edge lane & 15; rows without an edge are zero) and the source row this lane stages (edge lane >> 2)')
     A('    SplitN<NT> ha[2][2];')
     A('    int srs[2];')
-    A('    float w_unscale[2] = {1.f, 1.f};  // fp16 terms: h2 is scaled per 16-edge tile (wave-uniform), W2 per matrix on the host')
+    A('    float hv[2][2][8];')
     A('#pragma unroll')
     A('    for (int tl = 0; tl < 2; ++tl) {')
     A('      const int ea = min(eb + edge_of_row(tl, c), e_last);')
-    A('      const int wra = has_e ? (w_row ? w_row[ea] : ea) : 0;')
-    A('      float hv[2][8];')
+    if FROW:
+        A('      const bool rv = (c & 3) < rows_t[tl] && (c >> 2) * rows_t[tl] + (c & 3) < m_t[tl];   // this lane\'s A row holds an edge')
+    else:
+        A('      const bool rv = 16 * tl + c < n_e;')
+    A('      const int wra = rv ? (w_row ? w_row[ea] : ea) : 0;')
     A('#pragma unroll')
     A('      for (int q = 0; q < 2; ++q) {')
     A('        f32x4 lo4 = f32x4{0.f, 0.f, 0.f, 0.f}, hi4 = lo4;')
-    A('        if (has_e) {')
+    A('        if (rv) {')
     A('          lo4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wra * 64 + 32 * q + 8 * g);')
     A('          hi4 = *reinterpret_cast<const f32x4 *>(h2 + (size_t)wra * 64 + 32 * q + 8 * g + 4);')
     A('        }')
     A('#pragma unroll')
-    A('        for (int i = 0; i < 4; ++i) { hv[q][i] = lo4[i]; hv[q][4 + i] = hi4[i]; }')
+    A('        for (int i = 0; i < 4; ++i) { hv[tl][q][i] = lo4[i]; hv[tl][q][4 + i] = hi4[i]; }')
     A('      }')
-    A('      if constexpr (F16) {')
-    A('        const int kh = snet::F16_TOP - snet::bound_exp(snet::wave_max(fmaxf(snet::max8(hv[0]), snet::max8(hv[1]))));')
-    A('        const float sc = snet::pow2f(kh);')
+    A('      srs[tl] = has_e ? src[min(eb + edge_of_row(tl, lane >> 2), e_last)] : 0;')
+    A('    }')
+    A('    float o_scale = scale;  // fp16 terms: h2 is scaled per pass (wave-uniform power of two), W2 per matrix on the host; both are undone on the output rows')
+    A('    if constexpr (F16) {')
+    A('      const int kh = snet::F16_TOP - snet::bound_exp(snet::wave_max(fmaxf(fmaxf(snet::max8(hv[0][0]), snet::max8(hv[0][1])), fmaxf(snet::max8(hv[1][0]), snet::max8(hv[1][1])))));')
+    A('      const float sc = snet::pow2f(kh);')
+    A('#pragma unroll')
+    A('      for (int tl = 0; tl < 2; ++tl)')
     A('#pragma unroll')
     A('        for (int q = 0; q < 2; ++q)')
     A('#pragma unroll')
-    A('          for (int i = 0; i < 8; ++i) hv[q][i] *= sc;')
-    A('        w_unscale[tl] = snet::pow2f(-(kh + w2_exp));')
-    A('      }')
-    A('      ha[tl][0] = splitn8<NT, F16>(hv[0]);')
-    A('      ha[tl][1] = splitn8<NT, F16>(hv[1]);')
-    A('      srs[tl] = has_e ? src[min(eb + edge_of_row(tl, lane >> 2), e_last)] : 0;')
+    A('          for (int i = 0; i < 8; ++i) hv[tl][q][i] *= sc;')
+    A('      o_scale = scale * snet::pow2f(-(kh + w2_exp));')
+    A('    }')
+    A('#pragma unroll')
+    A('    for (int tl = 0; tl < 2; ++tl) {')
+    A('      ha[tl][0] = splitn8<NT, F16>(hv[tl][0]);')
+    A('      ha[tl][1] = splitn8<NT, F16>(hv[tl][1]);')
     A('    }')
     A('    for (int i = lane; i < 32 * NSH; i += 64) {')
     A('      const int el = i / NSH;')
@@ -1349,11 +1374,6 @@ def _fwd_block(cx: _Gen, ci: int, gi: int):
             A(f'              for (int tm = 0; tm < NT; ++tm) bfr[tm] = as_bf16x8(sl[(({ls - grp[0][0]} * 4 + {tp} * 2 + q) * NT + tm) * 64 + lane]);')
             A(f'              wv = mfma16_split<NT, F16>(ha[{tl}][q], bfr, wv);')
             A('            }')
-            A('#pragma unroll')
-            if FROW:
-                A(f'            for (int r = 0; r < 4; ++r) wv[r] = (r < rows_t[{tl}] && g * rows_t[{tl}] + r < m_t[{tl}]) ? (F16 ? wv[r] * w_unscale[{tl}] : wv[r]) : 0.f;')
-            else:
-                A(f'            for (int r = 0; r < 4; ++r) wv[r] = (16 * {tl} + 4 * g + r < n_e) ? (F16 ? wv[r] * w_unscale[{tl}] : wv[r]) : 0.f;')
             SF(4, '            ', light=False)
             A(f'            if (!(diag & 1)) fwdf_p{pi}(xr, ysl, wv, acc{pi}, {f"rows_t[{tl}]" if FROW else "4"});  // opaque branch: see the reverse kernel')
             SF(5, '            ', light=False)
@@ -1367,7 +1387,7 @@ def _fwd_block(cx: _Gen, ci: int, gi: int):
     A('        __builtin_amdgcn_wave_barrier();')
     A('        if (g == 0) {')
     for q, (pi, m3) in enumerate(ol):
-        A(f'          s_o[wave][{q} * 16 + c] = acc{pi}[{m3}] * scale;')
+        A(f'          s_o[wave][{q} * 16 + c] = acc{pi}[{m3}] * o_scale;')
     A('        }')
     A('        __builtin_amdgcn_wave_barrier();')
     for k in range((len(ol) + 15) // 16):

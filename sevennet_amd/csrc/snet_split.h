@@ -108,13 +108,28 @@ __device__ __forceinline__ SplitN<NT> splitn8(const float (&v)[8]) {
   SplitN<NT> s;
   if constexpr (F16) {
     static_assert(NT == 2, "fp16 operands are split into two terms");
-    f16x2 h[4], l[4];
+    f16x2 h[4];
+    unsigned lw[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const f32x2 x = {v[2 * p], v[2 * p + 1]};
       h[p] = __builtin_convertvector(x, f16x2);   // v_cvt_pk_f16_f32, round-to-nearest-even
-      l[p] = __builtin_convertvector(x - __builtin_convertvector(h[p], f32x2), f16x2);
+      // lo = fp16(x - hi): one mixed-precision FMA per value (fp16 hi half x -1.0 + fp32 x, result rounded to fp16 into one half of
+      // the destination) instead of two conversions back to fp32, a packed subtraction and a packed conversion per PAIR -- 12
+      // instead of 20 vector instructions per 8-value operand (round 6; hipcc does not select v_fma_mix* for the C expression).
+      // x - hi is exact in fp32, so the single rounding to fp16 is the one the four-instruction form performed.
+      const unsigned hp = __builtin_bit_cast(unsigned, h[p]);
+      asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lw[p]) : "v"(hp), "v"(x[0]));
+      asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw[p]) : "v"(hp), "v"(x[1]));
     }
+    // A matrix instruction must not read a register within two wait states of the vector instruction that wrote it; hipcc pads
+    // that for instructions it knows, not for the contents of an asm statement (measured: the last-layer lmax-3 kernels returned
+    // g_h2 3e-3 off -- stale lo terms -- until this was here).  One s_nop for the whole operand, tied to all four words so that it
+    // stays between the last of the eight FMAs and the first matrix instruction that reads them.
+    asm("s_nop 1" : "+v"(lw[0]), "+v"(lw[1]), "+v"(lw[2]), "+v"(lw[3]));
+    f16x2 l[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) l[p] = __builtin_bit_cast(f16x2, lw[p]);
     s.t[0] = cat4h(h[0], h[1], h[2], h[3]);
     s.t[1] = cat4h(l[0], l[1], l[2], l[3]);
   } else {

@@ -61,7 +61,8 @@ Pair::~Pair() {
 void Pair::init_style() {}
 
 // pair.cpp Pair::ev_setup restated for the flags the glue reads: zero the accumulators, size the per-atom arrays
-void Pair::ev_init(int eflag, int vflag, int /*alloc*/) {
+void Pair::ev_setup(int eflag, int vflag, int /*alloc*/) {
+  evflag = 1;
   eflag_either = eflag != 0;
   eflag_global = eflag & 1;
   eflag_atom = (eflag & 2) != 0;

@@ -30,7 +30,8 @@ class Pair : protected Pointers {
   int eflag_either = 0, eflag_global = 0, eflag_atom = 0;
   int vflag_either = 0, vflag_global = 0, vflag_atom = 0;
   // LAMMPS' flag encoding (pair.h / integrate.cpp): eflag 1 global, 2 per atom; vflag 1 | 2 global, 4 per atom
-  void ev_init(int eflag, int vflag, int alloc = 1);
+  void ev_setup(int eflag, int vflag, int alloc = 1);
+  int evflag = 0, vflag_fdotr = 0;
   int maxeatom = 0, maxvatom = 0;
 };
 }  // namespace LAMMPS_NS
