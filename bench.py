@@ -97,6 +97,10 @@ def parse():
                          "[n,3], edge vectors formed on the GPU from the resident topology + image offsets -- what an MD host "
                          "hands over), 'edges' (the fp32 edge vectors [E,3], round-2 behaviour), 'none' (inputs resident)")
     ap.add_argument('--no-h2d', action='store_true', help="same as --h2d none")
+    ap.add_argument('--brick-proxy', type=int, default=0, metavar='W',
+                    help='N = 1 only: after the timed region also time rank 0\'s brick of a W-way spatial decomposition of the same cell '
+                         'on this GPU (ghost rows, interior / boundary split, a self-loop halo that packs, copies and accumulates the '
+                         'same rows the RCCL exchange would, on the halo stream) and report it as `brick_proxy` beside the ideal N = 1 step / W')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-reps', type=int, default=11, help='CPU-baseline sample: cells per axis (11 -> the 10 648-atom cell of BASELINE '
                     'config 2, SURVEY.md 8(d), ~4 min; 6 -> only the 1728-atom cell that picks the thread count, ~1 min)')
@@ -275,6 +279,113 @@ def cpu_baseline(cfg, sd, reps, small_reps=6):
                        f'{best} torch threads on {cpu_model_name()} ({phys} physical cores, {os.cpu_count()} logical CPUs); '
                        f'thread count chosen on the {len(pos_s)}-atom cell, atom-steps/s by thread count there: '
                        + ', '.join(f'{k}: {v[0]:.0f}' for k, v in runs.items()))
+
+
+class SelfLoopHalo:
+    """Halo of ONE brick measured alone (bench.py --brick-proxy): every exchange moves the rows the real one would -- the send rows
+    are packed (index_select over the brick's send lists), copied device to device into the ghost rows / added into the owners'
+    rows on the way back -- on a second stream with the same start / finish protocol as NativeHalo, so the interior / boundary
+    split of the hosts runs; only the wire (RCCL over xGMI) and the peers are missing.  The ghost rows receive copies of OWNED rows
+    (finite features of the right magnitude): the numbers of the step are not those of the decomposed cell, its cost is."""
+
+    def __init__(self, send_lists, n_ghost, device):
+        idx = np.concatenate([np.asarray(s_, np.int64) for s_ in send_lists]) if len(send_lists) else np.zeros(0, np.int64)
+        if len(idx) == 0:
+            idx = np.zeros(1, np.int64)
+        self.n_ghost = int(n_ghost)
+        self.n_send = int(sum(len(s_) for s_ in send_lists))
+        take = np.resize(idx, self.n_ghost)                    # as many rows as arrive from the peers
+        self.idx = torch.as_tensor(take, dtype=torch.long, device=device)
+        self.side = torch.cuda.Stream(device=device)
+        self.overlap = True
+
+    def forward_start(self, x, n_local):
+        cur = torch.cuda.current_stream(x.device)
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            if self.n_ghost:
+                x[n_local:n_local + self.n_ghost] = x.index_select(0, self.idx)     # pack + "wire" + unpack
+        done = torch.cuda.Event()
+        done.record(self.side)
+        return done, x
+
+    def forward_finish(self, handle):
+        torch.cuda.current_stream(handle[1].device).wait_event(handle[0])
+
+    def forward(self, x, n_local):
+        self.forward_finish(self.forward_start(x, n_local))
+
+    def reverse_start(self, gx, n_local):
+        cur = torch.cuda.current_stream(gx.device)
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            staged = gx[n_local:n_local + self.n_ghost].clone()                     # ghost rows leave; what the peers return is staged
+        done = torch.cuda.Event()
+        done.record(self.side)
+        return done, gx, staged, n_local
+
+    def reverse_finish(self, handle, gx=None):
+        done, gx0, staged, n_local = handle
+        gx = gx0 if gx is None else gx
+        torch.cuda.current_stream(gx.device).wait_event(done)
+        if self.n_ghost:
+            gx[:n_local].index_add_(0, self.idx, staged)                            # deterministic order is not the point here
+
+    def reverse(self, gx, n_local):
+        self.reverse_finish(self.reverse_start(gx, n_local), gx)
+
+
+def brick_proxy(a, cfg, sd, eng, pos, cell, dev, modal, n1_step_ms):
+    """rank 0's brick of an a.brick_proxy-way decomposition of the benchmark cell, alone on this GPU: ms per step of both hosts,
+    dispatches, kernel time, gaps, against the ideal (the measured N = 1 step / W)."""
+    from sevennet_amd.engine import build_graph
+    from sevennet_amd.parallel import build_brick_graph
+    W = a.brick_proxy
+    bg = build_brick_graph(pos, cell, species_of(cfg, len(pos)), cfg['cutoff'], W, 0)
+    g = build_graph(bg.types, bg.edge_index, bg.edge_vec, n_local=bg.n_local, n_interior=bg.n_interior, device=dev,
+                    num_species=eng.spec.num_species)
+    n_ghost = g.n_total - g.n_local
+    halo = SelfLoopHalo(bg.send_lists, n_ghost, dev)
+
+    def timed(fn, steps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, t_enq / steps * 1e3
+    steps = max(a.steps, 20)
+    eng.events, eng.event_filter = None, None
+    ms_py, enq_py = timed(lambda: eng.compute(g, halo=halo), steps)
+    eng.events = []
+    eng.compute(g, halo=halo)
+    torch.cuda.synchronize()
+    times = eng.kernel_times_ms()
+    eng.events = None
+    kern = {k: float(np.sum(v)) for k, v in times.items() if not k.startswith('halo') and not k.endswith('@side')}
+    n_disp = int(sum(len(v) for k, v in times.items() if not k.startswith('halo')))
+    out = dict(world=W, rank=0, atoms_local=int(g.n_local), interior_atoms=int(bg.n_interior or 0), ghost_rows=int(n_ghost),
+               edges=int(g.n_edges), send_rows=halo.n_send, ms_per_step=round(ms_py, 3), host_enqueue_ms_per_step=round(enq_py, 3),
+               ideal_ms=round(n1_step_ms / W, 3), ratio_to_ideal=round(ms_py / (n1_step_ms / W), 3),
+               dispatches_per_step=n_disp, kernel_ms_per_step=round(sum(kern.values()), 3),
+               gap_ms_per_step=round(ms_py - sum(kern.values()), 3),
+               kernel_ms_top={k: round(v, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])[:8]},
+               halo='self-loop: pack + device-to-device copy + accumulate of the rows the RCCL exchange moves '
+                    f'({2 * 4} feature exchanges + 1 force fold per step), second stream, interior / boundary split on; no wire, no peers',
+               exchange_mb=round(n_ghost * 480 * 4 / 1e6, 2))
+    try:   # the native sequencer on the same brick (its own second stream; the halo through callbacks)
+        from sevennet_amd.native_model import NativeModel
+        nat = NativeModel(cfg, sd, device=dev, modal=modal)
+        nat.set_halo(halo)
+        ms_nat, enq_nat = timed(lambda: nat.compute(g), steps)
+        out['ms_per_step_native_host'] = round(ms_nat, 3)
+        out['host_enqueue_ms_per_step_native_host'] = round(enq_nat, 3)
+    except Exception as exc:  # noqa: BLE001
+        out['native_host_error'] = repr(exc)[:200]
+    return out
 
 
 def main():
@@ -659,6 +770,8 @@ def main():
                        **tele.summary(), 'telemetry_pass_ms_per_step': round(tele_ms, 3)},
             'roofline': roof,
         }
+        if world == 1 and not dist_mode and a.brick_proxy > 1 and a.model == 'sevennet_0':
+            res['brick_proxy'] = brick_proxy(a, cfg, sd, eng, pos, cell, dev, modal, step_ms)
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, sd, a.cpu_reps)
         # RCCL writes a version banner through C stdio, which a pipe buffers until exit: flush it now so that the JSON

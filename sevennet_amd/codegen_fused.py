@@ -187,10 +187,11 @@ def _emit_reverse_body(A, pi, p):
     A('}')
 
 
-def _emit_reverse_body_pk(A, pi, p):
+def _emit_reverse_body_pk(A, pi, p, pkgy=True):
     """The reverse body of `_emit_reverse_body` on PACKED fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32): the lane's 4 channels are two
     register pairs, the per-edge scalars (V, the Clebsch-Gordan constants) enter as splat operands.  Same products, same
-    accumulation order per channel; only s_ac sums its four channels pairwise ((0 + 2) + (1 + 3)).  Why (round 5,
+    accumulation order per channel; s_ac keeps its channels as two partial sums ((0 + 2), (1 + 3)) that dE/dY accumulates SEPARATELY
+    (f32x2 gy[NSH], round 6) and the kernel's epilogue adds.  Why (round 5,
     profiles/r05_issue_rate_probe.txt): a wave issues one vector instruction per ~7.5 cycles whatever its kind, so at the two waves per
     SIMD these kernels run at, the vector pipe is capped by the issue cadence at about half its rate and the kernel's time is its
     INSTRUCTION COUNT times that cadence -- a packed instruction does two lanes' worth of multiply-adds in the same issue slot
@@ -198,7 +199,7 @@ def _emit_reverse_body_pk(A, pi, p):
     d1, d3 = 2 * p.l1 + 1, 2 * p.l3 + 1
     A('template <bool GX>')
     A(f'__device__ __forceinline__ void bwdf_p{pi}(const f32x4 (&xr)[{d1}], const float (&ys)[NSH], const f32x4 w,')
-    A(f'    const f32x4 (&G)[{d3}], f32x4 &gw, float (&gy)[NSH], f32x4 (&gx)[{d1}]) {{')
+    A(f'    const f32x4 (&G)[{d3}], f32x4 &gw, {"f32x2" if pkgy else "float"} (&gy)[NSH], f32x4 (&gx)[{d1}]) {{')
     A('  const f32x2 wl = lo2(w), wh = hi2(w);')
     A('  f32x2 gwl = f32x2{0.f, 0.f}, gwh = gwl;')
     for a, cl in reverse_plan(p):
@@ -216,9 +217,12 @@ def _emit_reverse_body_pk(A, pi, p):
             else:
                 A('      Pl = __builtin_elementwise_fma(V2, Gl, Pl); Ph = __builtin_elementwise_fma(V2, Gh, Ph);')
             A('      const f32x2 s2 = __builtin_elementwise_fma(wxh, Gh, wxl * Gl);')
-            A('      const float s = s2[0] + s2[1];')
-            for b, v in bl:
-                A(f'      gy[{p.sh_off + b}] = fmaf({_f(v)}, s, gy[{p.sh_off + b}]);')
+            for b, v in bl:   # (the two halves of s_ac are summed once per tile, in the epilogue: one add per (a, c) pair less; the
+                #               Clebsch-Gordan constant reaches the packed FMA as an SGPR splat -- s_mov, no vector instruction)
+                if pkgy:
+                    A(f'      gy[{p.sh_off + b}] = __builtin_elementwise_fma(f32x2{{{_f(v)}, {_f(v)}}}, s2, gy[{p.sh_off + b}]);')
+                else:
+                    A(f'      gy[{p.sh_off + b}] = fmaf({_f(v)}, s2[0] + s2[1], gy[{p.sh_off + b}]);')
             A('    }')
         A('    gwl = __builtin_elementwise_fma(xl, Pl, gwl); gwh = __builtin_elementwise_fma(xh, Ph, gwh);')
         A('    if constexpr (GX) {')
@@ -305,6 +309,7 @@ class _Gen:
         # 8-wave kernel crosses 128 registers with them (127 -> 132: 1.89 -> 2.29 ms), the lmax-3 shapes at 256 registers start to
         # spill (0 -> 6, 7 -> 37).  SNET_CODEGEN_OPTS=pk=0 / 1 forces it (profiles/r05_ab_packed_fp32_bodies.txt).
         self.PK = bool(int(OPTS['pk'])) if 'pk' in OPTS else XT
+        self.PKGY = self.PK and bool(int(OPTS.get('pkgy', 1)))   # dE/dY accumulated as two packed partial sums (round 6)
         # Order of the vector-memory operations (round 4).  vmcnt retires IN ORDER, and the slab fragments of the next sub-step
         # are waited for at the end of every sub-step: whatever was issued before those slab loads -- the gathers of the next
         # block's source rows and g_out entries, the g_xe stores of the block just finished -- is waited for with them.  So the
@@ -518,7 +523,7 @@ def _emit_path_functions(cx: _Gen):
         for a_, b_, cc, v in terms:
             byab.setdefault((a_, b_), []).append((cc, v))
         if PK:
-            _emit_reverse_body_pk(A, pi, p)
+            _emit_reverse_body_pk(A, pi, p, cx.PKGY)
         else:
             _emit_reverse_body(A, pi, p)
         # ---- forward: lane = channel, the 4 edges of the lane's group in the vector components
@@ -687,9 +692,14 @@ def _rev_prologue(cx: _Gen):
     A('  f32x4 ga[4];  // g_h2^T[k = 16 m + 4 g + r][edge]')
     A('#pragma unroll')
     A('  for (int m = 0; m < 4; ++m) ga[m] = f32x4{0.f, 0.f, 0.f, 0.f};')
-    A('  float gy[NSH];')
-    A('#pragma unroll')
-    A('  for (int k = 0; k < NSH; ++k) gy[k] = 0.f;')
+    if cx.PKGY:   # packed bodies keep two partial sums of dE/dY per component (added in the epilogue)
+        A('  f32x2 gy[NSH];')
+        A('#pragma unroll')
+        A('  for (int k = 0; k < NSH; ++k) gy[k] = f32x2{0.f, 0.f};')
+    else:
+        A('  float gy[NSH];')
+        A('#pragma unroll')
+        A('  for (int k = 0; k < NSH; ++k) gy[k] = 0.f;')
     # fp16 terms, g_h2 += W2 g_w^T: the operand g_w[edge, channel] = sum_abc C_abc G_c x_a Y_b of a path is bounded by
     # (sum |C|) max|G| max|x| max|Y|.  ONE power of two per tile (round 6; it was one per edge) puts the largest bound of the tile's 16
     # edges below 2^F16_TOP -- no entry can overflow fp16, entries down to 2^-17 of the tile's bound keep all 22 bits -- and, being
@@ -1081,17 +1091,23 @@ def _rev_epilogue(cx: _Gen):
     A, ST, S, NPH = cx.A, cx.ST, cx.S, 16
     A('  // d/d(edge_vec) = sum_i gy_i dY_i/dr (Y_0 is constant).  The 4 channel groups of an edge (lanes j, j+16, j+32,')
     A('  // j+48) are summed with two permlane swaps per value; only the g == 0 lanes then touch dsh and g_vec.')
+    if cx.PKGY:
+        A('  float gys[NSH];   // the packed bodies\' two partial sums per component')
+        A('#pragma unroll')
+        A('  for (int i = 0; i < NSH; ++i) gys[i] = gy[i][0] + gy[i][1];')
+    else:
+        A('  float (&gys)[NSH] = gy;')
     A('#pragma unroll')
     A('  for (int i = 1; i < NSH; ++i) {')
-    A('    gy[i] = snet::swap_add16(gy[i], gy[i]);')
-    A('    gy[i] = snet::swap_add32(gy[i], gy[i]);')
+    A('    gys[i] = snet::swap_add16(gys[i], gys[i]);')
+    A('    gys[i] = snet::swap_add32(gys[i], gys[i]);')
     A('  }')
     A('  if (tail.g_sh != nullptr) {   // b1 plug-in: the gradient with respect to the harmonics themselves (wave-uniform branch)')
-    A('    gy[0] = snet::swap_add16(gy[0], gy[0]);')
-    A('    gy[0] = snet::swap_add32(gy[0], gy[0]);')
+    A('    gys[0] = snet::swap_add16(gys[0], gys[0]);')
+    A('    gys[0] = snet::swap_add32(gys[0], gys[0]);')
     A('    if (valid && g == 0) {')
     A('#pragma unroll')
-    A('      for (int i = 0; i < NSH; ++i) tail.g_sh[(size_t)e * NSH + i] = gy[i] * gx_fix;')
+    A('      for (int i = 0; i < NSH; ++i) tail.g_sh[(size_t)e * NSH + i] = gys[i] * gx_fix;')
     A('    }')
     A('  }')
     A('  if (dsh != nullptr && valid && g == 0) {')
@@ -1099,9 +1115,9 @@ def _rev_epilogue(cx: _Gen):
     A('    const float *jd = dsh + (size_t)e * (3 * NSH);')
     A('#pragma unroll')
     A('    for (int i = 1; i < NSH; ++i) {')
-    A('      t0 = fmaf(gy[i], jd[3 * i], t0);')
-    A('      t1 = fmaf(gy[i], jd[3 * i + 1], t1);')
-    A('      t2 = fmaf(gy[i], jd[3 * i + 2], t2);')
+    A('      t0 = fmaf(gys[i], jd[3 * i], t0);')
+    A('      t1 = fmaf(gys[i], jd[3 * i + 1], t1);')
+    A('      t2 = fmaf(gys[i], jd[3 * i + 2], t2);')
     A('    }')
     A('    float *o = g_vec + (size_t)e * 3;')
     A('    o[0] += t0 * gx_fix; o[1] += t1 * gx_fix; o[2] += t2 * gx_fix;   // (gx_fix: the bodies\' common factor, see the prologue)')

@@ -563,7 +563,11 @@ def test_bench_multi_rank_path_dry_run():
         line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
         return json.loads(line)
 
-    one = run([sys.executable, 'bench.py'] + common)
+    one = run([sys.executable, 'bench.py', '--brick-proxy', '2'] + common)
+    # the brick-proxy leg: rank 0's brick of a 2-way decomposition timed alone on this GPU, both hosts
+    bp = one['brick_proxy']
+    assert bp['world'] == 2 and 0 < bp['atoms_local'] < one['config']['atoms'] and bp['ghost_rows'] > 0 and bp['interior_atoms'] >= 0
+    assert bp['ms_per_step'] > 0 and bp['ideal_ms'] > 0 and bp['dispatches_per_step'] > 10 and bp['ms_per_step_native_host'] > 0
     for n, port in ((2, 29611), (4, 29612)):
         many = run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
                     '--master-addr', '127.0.0.1', '--master-port', str(port), 'bench.py', '--gpus', str(n)] + common)
