@@ -102,16 +102,19 @@ def _emit_staging(A, lines: str):
     global -> LDS either through registers (load early, ds_write late) or (GLDS) by gfx950's direct
     global_load_lds (no staging VGPRs; lane i of a wave lands at base + 16 i)"""
     A('  u32x4 st[GLDS ? 1 : NST];')
+    A('  // (raw buffer resource over the fragment stream: stride 0, byte offsets, gfx9 data-format word)')
+    A('  const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4 *>(slabs), 0, 0x7fffffff, 0x00020000);')
     A('  auto stage_load = [&](int s, int b) {')
     A('    if constexpr (GLDS) {')
     A(f'      for (int l = wave; l < {lines}; l += NWV)')
     A('        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(slabs + (size_t)s * (LPS * 64) + l * 64 + lane),')
     A('                                         (__attribute__((address_space(3))) void *)(&slab[b][l * 64]), 16, 0, 0);')
     A('    } else {')
-    # (wave-uniform 64-bit base + unsigned 32-bit lane offset: the SGPR-base form of global_load, no 64-bit vector adds per sub-step)
-    A('      const u32x4 *sp = slabs + (size_t)s * (LPS * 64);')
+    # (buffer loads: the stream's base sits in a scalar resource, the sub-step and line offsets in the scalar offset, the lane offset
+    # in ONE vector register for the whole kernel -- the flat form spent two 64-bit vector additions per sub-step on addresses)
     A('#pragma unroll')
-    A(f'      for (int i = 0; i < NST; ++i) if (({lines} * 64) % NTH == 0 || tid + NTH * i < {lines} * 64) st[i] = sp[(unsigned)(tid + NTH * i)];')
+    A(f'      for (int i = 0; i < NST; ++i) if (({lines} * 64) % NTH == 0 || tid + NTH * i < {lines} * 64)')
+    A('        st[i] = __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, tid * 16, (s * (LPS * 64) + NTH * i) * 16, 0);')
     A('    }')
     A('  };')
     A('  auto stage_store = [&](int b) {')
