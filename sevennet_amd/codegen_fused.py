@@ -584,7 +584,7 @@ def _rev_prologue(cx: _Gen):
     A('  // g_out loads, 16 skip the g_xe stores -- timing decomposition, results are then garbage')
     A('  constexpr int LPS = 8 * NT, NTH = 64 * NWV, NST = (LPS * 64 + NTH - 1) / NTH, GLN = 1;  // 1-KB fragment lines per sub-step; sub-steps per slab')
     A('  __shared__ u32x4 slab[2][GLN * LPS * 64];')
-    A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
+    A('  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar address arithmetic)')
     A('  const int j = lane & 15, g = lane >> 4;')
     if ST:
         A(f'  unsigned ph[{NPH}];')
@@ -1164,7 +1164,7 @@ def _fwd_prologue(cx: _Gen):
     A('  __shared__ __attribute__((aligned(16))) float s_ys[NWV][32 * NSHP];  // spherical harmonics of the pass\'s edges (rows padded: NSHP)')
     A(f'  __shared__ __attribute__((aligned(16))) float s_x[NWV][{MAXD1} * 256];  // source-row slice of one tile: [m][r][g][channel]')
     A(f'  __shared__ __attribute__((aligned(16))) float s_o[NWV][{NOEP} * 16];      // output rows of one block: [entry][channel]')
-    A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
+    A('  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar address arithmetic)')
     A('  const int c = lane & 15, g = lane >> 4;')
     A('  const int n_raw = snet::xcd_node(blockIdx.x, gridDim.x) * NWV + wave;')
     if STF:

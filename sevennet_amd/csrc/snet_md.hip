@@ -590,6 +590,12 @@ extern "C" int snet_md_compute(snet_md_host *h, int32_t inum, const int32_t *ili
   }
 
   // ---- the model
+  // The index arrays were just rewritten IN PLACE (the edges inside the cutoff are re-derived from the positions every step, like
+  // pair_e3gnn.cpp:150-200): a topology cache that somebody switched on for this model keys on buffer addresses and sizes, which
+  // do not change when one edge leaves the cutoff and another enters -- round 6's MD loop (tools/md_loop.py) found forces 10-30 %
+  // off with the energy exact, through stale source grouping / tile lists.  The hot path of a LAMMPS run never had the cache on
+  // (snet_model_load leaves it off); a model shared with a caching host now stays correct as well.
+  if (const int trc = snet_model_topology_changed(h->model)) return trc;
   double *d_energy = h->scalars.p, *d_virial = h->scalars.p + 1;
   int rc = snet_model_eval(h->model, NT, N, E, h->types.p, h->types_host.data(), h->row_ptr.p, h->src.p, h->col_ptr.p,
                            h->eperm.p, h->edge_vec.p, E > 0 ? h->w_row.p : nullptr, E > 0 ? h->pair_edge.p : nullptr, n_pairs,

@@ -170,6 +170,26 @@ def test_md_host_reuses_the_list_between_rebuilds():
     assert np.array_equal(c['f'], d['f'])
 
 
+def test_md_host_new_list_of_the_same_size_is_not_served_from_a_stale_topology_cache():
+    """Round 6 (found by the MD loop, tools/md_loop.py): NativeModel switches the model's topology cache on (it keys on buffer
+    addresses and sizes), snet_md_compute rewrites the same buffers every step -- a NEW list with the same node and edge counts
+    (here: every neighbor row reversed, positions moved) used to be evaluated with the previous list's source grouping and tile
+    lists: exact energy, forces 10-30 % off.  The host now invalidates the cache on every call."""
+    cfg, sd, cutoff, types, pos, cell, ei, ev = _setup('mini')
+    n = len(types)
+    x, tag, nlocal, rows = lammps_domain(pos, cell, np.ones(n, bool), cutoff + SKIN)
+    ty_all = np.asarray(types)[tag - 1]
+    host, fresh = MdHost(cfg, sd), MdHost(cfg, sd)
+    a = host.compute(x, tag, nlocal, rows, ty_all)
+    rows2 = [r[::-1].copy() for r in rows]
+    x2 = x + np.random.default_rng(5).normal(0.0, 0.02, (n, 3))[tag - 1]
+    b = host.compute(x2, tag, nlocal, rows2, ty_all)          # second call on the same host: same sizes, other edge order
+    c = fresh.compute(x2, tag, nlocal, rows2, ty_all)
+    assert b['n_edges'] == c['n_edges'] == a['n_edges']
+    assert b['energy'] == c['energy'] and np.array_equal(b['f'], c['f']) and np.array_equal(b['virial'], c['virial'])
+    assert np.abs(b['f'] - a['f']).max() > 1e-4                # (the second configuration really is another one)
+
+
 def test_md_host_rejects_bad_input():
     cfg, sd, cutoff, types, pos, cell, ei, ev = _setup('unit')
     x, tag, nlocal, rows = lammps_domain(pos, cell, np.ones(len(types), bool), cutoff + SKIN)

@@ -34,9 +34,9 @@ def test_nve_through_the_md_host_conserves_energy_and_follows_the_oracle():
     # the first 12 steps against the fp64 oracle (same integrator, same start): positions and total energy
     o = M.run_md(cfg, sd, pos, cell, types, vel, mass, dt, 12, force_fn=M.oracle_force_fn(cfg, sd, cell, types))
     dev = max(np.abs(r['traj'][k] - o['traj'][k]).max() for k in range(13))
-    assert dev < 1e-6, dev                                                             # A
+    assert dev < 1e-7, dev                                                             # A (measured 1.4e-9; with the bug 9e-6)
     assert np.abs(r['e_tot'][:13] - o['e_tot']).max() / n < 5e-6                       # eV per atom (fp32 energy class)
 
 
-DRIFT_BOUND = 5e-3        # eV / atom / ps
-EXCURSION_BOUND = 1e-4    # eV / atom
+DRIFT_BOUND = 2e-4        # eV / atom / ps   (measured -2.3e-5: profiles/r06_md_loop.txt; the stale-cache bug this test found: +1.0e-2)
+EXCURSION_BOUND = 1e-5    # eV / atom        (measured 2e-6; with the bug 1.0e-3)
