@@ -1399,15 +1399,21 @@ def _fwd_block(cx: _Gen, ci: int, gi: int):
             A('          }')
         SF(5, '          ', light=STFL)
         A('        }')
-    # reduce over the 4 edge groups, park in LDS, write out with 16-byte stores
-    for q, (pi, m3) in enumerate(ol):
-        A(f'        acc{pi}[{m3}] = snet::swap_add16(acc{pi}[{m3}], acc{pi}[{m3}]);')
-        A(f'        acc{pi}[{m3}] = snet::swap_add32(acc{pi}[{m3}], acc{pi}[{m3}]);')
+    # Reduce over the 4 edge groups, park in LDS, write out with 16-byte stores.  Round 6: the reduction is a TRANSPOSING butterfly over
+    # four output values at a time -- swap_add16(v0, v1) and swap_add16(v2, v3), then swap_add32 of the two results: three swaps and
+    # three adds leave value q of the quad, fully summed, in lane group q, and every lane parks one word per quad.  (It was two swaps,
+    # two adds and two register copies PER VALUE -- swap_add(a, a) needs a copy of its operand -- with the g == 0 lanes parking all of
+    # them: ~7 vector instructions per output value, 45 values per channel tile of the SevenNet-0 middle layer.)
     A('        __builtin_amdgcn_wave_barrier();')
-    A('        if (g == 0) {')
-    for q, (pi, m3) in enumerate(ol):
-        A(f'          s_o[wave][{q} * 16 + c] = acc{pi}[{m3}] * o_scale;')
-    A('        }')
+    vals = [f'acc{pi}[{m3}]' for (pi, m3) in ol]
+    for k in range(0, len(vals), 4):
+        quad = vals[k:k + 4] + ['0.f'] * (4 - len(vals[k:k + 4]))
+        A(f'        {{ const float t01 = snet::swap_add16({quad[0]}, {quad[1]}), t23 = snet::swap_add16({quad[2]}, {quad[3]});')
+        if len(vals) - k >= 4:
+            A(f'          s_o[wave][({k} + g) * 16 + c] = snet::swap_add32(t01, t23) * o_scale; }}')
+        else:   # (a short last quad: the groups beyond its values park nothing)
+            A(f'          const float u = snet::swap_add32(t01, t23) * o_scale;')
+            A(f'          if (g < {len(vals) - k}) s_o[wave][({k} + g) * 16 + c] = u; }}')
     A('        __builtin_amdgcn_wave_barrier();')
     for k in range((len(ol) + 15) // 16):
         if OOLDS:
