@@ -30,6 +30,7 @@ lockstep through a double-buffered LDS slab, so each fragment is fetched once pe
 """
 from __future__ import annotations
 
+import struct
 from typing import Dict, List
 
 from .codegen import OPTS, _Cat, _f, _path_terms, _sum_expr
@@ -539,7 +540,36 @@ def _emit_path_functions(cx: _Gen):
         if FROW:
             for b_ in ybs:
                 A(f'  const float y3_{b_} = ysl[3 * NSHP + {p.sh_off + b_}];')
-        for r in range(4):
+        # One-to-one paths -- (0, l -> l) and (l, 0 -> l): every output component has exactly one term, all with one coefficient --
+        # need no intermediate sums: t = w v x_0 (resp. w v Y_0) once per edge, then ONE multiply-add per output component
+        # (round 6: 6 instead of 10 vector instructions per edge for l = 2, 4 instead of 6 for l = 1)
+        one_to_one = (p.l1 == 0 or p.l2 == 0) and len(terms) == d3 and len({c_ for _, _, c_, _ in terms}) == d3 and \
+            len({struct.unpack('f', struct.pack('f', v_))[0] for _, _, _, v_ in terms}) == 1   # (equal as fp32 constants)
+        for r in range(4 if one_to_one else 0):
+            A(f'  if ({"true" if (r < 3 or not FROW) else "rows > 3"}) {{  // edge {r} of the lane\'s group')
+            v_ = struct.unpack('f', struct.pack('f', terms[0][3]))[0]
+            if p.l1 == 0:
+                A(f'    const float t = w[{r}] * xr[{r}][0]' + (f' * {_f(v_)};' if v_ != 1.0 else ';'))
+                for a_, b_, c_, _ in terms:
+                    A(f'    acc[{c_}] = fmaf(t, ' + (f'y3_{b_}' if (FROW and r == 3) else f'ysl[{r} * NSHP + {p.sh_off + b_}]') + f', acc[{c_}]);')
+            else:
+                b0 = terms[0][1]
+                A(f'    const float t = w[{r}] * ' + (f'y3_{b0}' if (FROW and r == 3) else f'ysl[{r} * NSHP + {p.sh_off + b0}]') + (f' * {_f(v_)};' if v_ != 1.0 else ';'))
+                for a_, b_, c_, _ in terms:
+                    A(f'    acc[{c_}] = fmaf(t, xr[{r}][{a_}], acc[{c_}]);')
+            A('  }')
+        # Scalar-output paths (l, l -> 0) with one coefficient: acc += (w v) sum_a x_a Y_a -- a dot product and one multiply-add
+        dot = not one_to_one and d3 == 1 and len({struct.unpack('f', struct.pack('f', v_))[0] for _, _, _, v_ in terms}) == 1
+        for r in range(4 if dot else 0):
+            A(f'  if ({"true" if (r < 3 or not FROW) else "rows > 3"}) {{  // edge {r} of the lane\'s group')
+            yv = lambda b_: (f'y3_{b_}' if (FROW and r == 3) else f'ysl[{r} * NSHP + {p.sh_off + b_}]')  # noqa: E731
+            (a0, b0, _, v_), rest = terms[0], terms[1:]
+            A(f'    float u = xr[{r}][{a0}] * {yv(b0)};')
+            for a_, b_, _, _ in rest:
+                A(f'    u = fmaf(xr[{r}][{a_}], {yv(b_)}, u);')
+            A(f'    acc[0] = fmaf(w[{r}] * {_f(v_)}, u, acc[0]);')
+            A('  }')
+        for r in range(0 if (one_to_one or dot) else 4):
             A(f'  if ({"true" if (r < 3 or not FROW) else "rows > 3"}) {{  // edge {r} of the lane\'s group (its spherical harmonics: wave-private LDS rows)')
             for i in range(d3):
                 A(f'    float s{i} = 0.f;')
