@@ -571,19 +571,25 @@ def _emit_path_functions(cx: _Gen):
             A('  }')
         for r in range(0 if (one_to_one or dot) else 4):
             A(f'  if ({"true" if (r < 3 or not FROW) else "rows > 3"}) {{  // edge {r} of the lane\'s group (its spherical harmonics: wave-private LDS rows)')
-            for i in range(d3):
+            # the weight goes on whichever side is narrower: on the 2 l1 + 1 source components up front (then every Clebsch-Gordan
+            # entry accumulates straight into acc) or on the 2 l3 + 1 sums at the end
+            w_first = d1 < d3
+            for i in range(0 if w_first else d3):
                 A(f'    float s{i} = 0.f;')
             for b_ in ybs:
                 if FROW and r == 3:
                     A(f'    const float y{b_} = y3_{b_};')
                 else:
                     A(f'    const float y{b_} = ysl[{r} * NSHP + {p.sh_off + b_}];')
+            if w_first:
+                for a_ in sorted({a_ for (a_, _) in byab}):
+                    A(f'    const float xw{a_} = w[{r}] * xr[{r}][{a_}];')
             for (a_, b_), cl in sorted(byab.items()):
-                A(f'    {{ const float xy = xr[{r}][{a_}] * y{b_};')
+                A(f'    {{ const float xy = ' + (f'xw{a_}' if w_first else f'xr[{r}][{a_}]') + f' * y{b_};')
                 for cc, v in cl:
-                    A(f'      s{cc} = fmaf({_f(v)}, xy, s{cc});')
+                    A(f'      acc[{cc}] = fmaf({_f(v)}, xy, acc[{cc}]);' if w_first else f'      s{cc} = fmaf({_f(v)}, xy, s{cc});')
                 A('    }')
-            for i in range(d3):
+            for i in range(0 if w_first else d3):
                 A(f'    acc[{i}] = fmaf(w[{r}], s{i}, acc[{i}]);')
             A('  }')
             if r < 3 and FRSB and len(terms) >= FRSB:
