@@ -30,8 +30,9 @@ extern "C" {
 
 /* Bumped whenever an exported signature or a file format changes incompatibly; every host checks snet_abi_version() against
  * the header it was built from (sevennet_amd/_lib.py, lammps/pair_*_hip.cpp).  History: 1 = rounds 1-3; 2 = round 4 (snet_nl_grid /
- * _bin / _count / _fill gained the open-axis arguments, .snet files moved to "SNETMDL4") and round 5 (pair_failed). */
-#define SNET_ABI_VERSION 2
+ * _bin / _count / _fill gained the open-axis arguments, .snet files moved to "SNETMDL4") and round 5 (pair_failed); 3 = round 6 (the
+ * unwired two-fp16-term grouped GEMM snet_gemm_f16_size / _pack / snet_gemm_grouped_f16 left the library). */
+#define SNET_ABI_VERSION 3
 
 /* ---- housekeeping ------------------------------------------------------- */
 int snet_abi_version(void);
@@ -103,18 +104,6 @@ int snet_gemm_grouped(const snet_gemm_desc *descs_host, int32_t n_desc, const fl
  * copy as snet_gemm_desc.B_split).  All problems of one grouped launch must use the same kind. */
 int64_t snet_gemm_split_size(int32_t K, int32_t N);
 int snet_gemm_split_pack(const float *B_host, int32_t K, int32_t N, void *packed_host);
-/* The same grouped contraction with TWO fp16 terms per operand (three matrix-core products per k step instead of six, a
- * cheaper split: the bf16 x 6 kernel is bound by that instruction stream, not by bytes -- DESIGN.md 4c), fp32-rounding
- * class like the tensor-product kernels' f16x3 mode.  fp16 has five exponent bits, so the caller supplies a bound of every
- * node row of A: a_row_bound[node] * bound_mult >= max |A[node, :]| (e.g. the row norm snet_gate_bwd_norm returns); rows
- * are scaled by a power of two from it, B by one per matrix (b_exps_host[i], from snet_gemm_f16_pack), both divided out of
- * the result.  descs[i].B_split = device copy of a snet_gemm_f16_pack buffer. */
-int64_t snet_gemm_f16_size(int32_t K, int32_t N);
-int snet_gemm_f16_pack(const float *B_host, int32_t K, int32_t N, void *packed_host, int32_t *b_exp);
-int snet_gemm_grouped_f16(const snet_gemm_desc *descs_host, const int32_t *b_exps_host, int32_t n_desc, const float *A, float *C,
-                          int64_t n_nodes, int64_t a_node_stride, int64_t c_node_stride, const int32_t *row_idx,
-                          const float *a_row_bound, float bound_mult, void *stream);
-
 /* Fused radial MLP, e3nn FullyConnectedNet([nb,h1,h2,wn], act) (convolution.py:93-95,121):
  *   fwd  w[E,wn] = (act(act(emb W0) cst W1) cst) W2          W0[nb,h1] W1[h1,h2] W2[h2,wn]
  *   bwd  g_emb[E,nb] += d<g_w,w>/d emb

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 2   # == SNET_ABI_VERSION of include/snet_hip.h (tests/test_abi_cpu.py keeps the two in step)
+ABI_VERSION = 3   # == SNET_ABI_VERSION of include/snet_hip.h (tests/test_abi_cpu.py keeps the two in step)
 LIB_PATH = os.environ.get('SNET_HIP_LIB') or os.path.join(_HERE, 'libsnet_hip.so')  # env: kernel experiments
 
 c_f32p = C.c_void_p   # device float*
@@ -59,10 +59,6 @@ SIGNATURES = {
                                     c_i32p, c_stream]),
     'snet_gemm_split_size': (C.c_int64, [C.c_int32, C.c_int32]),
     'snet_gemm_split_pack': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
-    'snet_gemm_f16_size': (C.c_int64, [C.c_int32, C.c_int32]),
-    'snet_gemm_f16_pack': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int32)]),
-    'snet_gemm_grouped_f16': (C.c_int, [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.c_int32, c_f32p, c_f32p, C.c_int64, C.c_int64,
-                                        C.c_int64, c_i32p, c_f32p, C.c_float, c_stream]),
     'snet_act_fwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_stream]),
     'snet_act_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_stream]),
     'snet_conv_plan_create': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),

@@ -363,167 +363,6 @@ __global__ __launch_bounds__(256, MT == 1 ? SNET_GEMM_OCC : 2) void gemm_split_g
                            row_idx, P.accumulate);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Two-fp16-term variant ("f16x3": hi*lo + lo*hi + hi*hi on v_mfma_f32_32x32x16_f16, snet_split.h): three products and a
-// two-term split per k step instead of six and three -- the bf16 x 6 kernel is bound by exactly that instruction stream
-// (0.285 ms for the SI2 launch with every row aliased to one, 0.371 ms with its HBM traffic).  fp16 has five exponent bits:
-// every ROW of A is scaled by a power of two taken from a caller-supplied bound of its magnitudes (row of the node, all
-// components; a_bound[node] * bound_mult >= max |A[node, :]|, e.g. the row norm the gate's reverse pass already computes),
-// B by one power of two per matrix on the host; both are divided out of the accumulators in the epilogue.  Entries more than
-// 17 binades below the bound lose relative precision gradually; nothing can overflow.
-template <int NT>
-__device__ __forceinline__ void gemm_f16_body(snet::u32x4 *Bs, float *s_un, int bx, int by, const float *__restrict__ A,
-    const snet::u32x4 *__restrict__ Bp, float *__restrict__ C, int64_t n_rows, int d, int K, int N, int64_t a_node_stride,
-    int64_t a_off, int64_t c_node_stride, int64_t c_off, const int32_t *__restrict__ row_idx, int accumulate,
-    const float *__restrict__ a_bound, float bound_mult, int b_exp) {
-  using namespace snet;
-  constexpr int SLAB = NT * 128;  // u32x4 per k step: [tile][term(2)][lane]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, li = lane & 31;
-  const int64_t row0 = ((int64_t)bx * 4 + wave) * 32;
-  const int nq = (K + 15) >> 4, n_tiles = (N + 31) >> 5, tile0 = by * NT;
-  const RowMap rows(row0, d);
-  const bool a_ok = row0 + li < n_rows;
-  int64_t n = 0;
-  int m = 0;
-  if (a_ok) rows.at(li, n, m);
-  const int64_t node = row_idx ? (int64_t)row_idx[n] : n;
-  const float *a_ptr = A + node * a_node_stride + a_off + (int64_t)m * K + 8 * half;
-  float sa = 0.f, un = 0.f;
-  if (a_ok) {
-    const int ka = F16_TOP - bound_exp(a_bound[node] * bound_mult);
-    sa = pow2f(ka);
-    un = pow2f(-ka) * pow2f(-b_exp);
-  }
-  if (half == 0) s_un[wave * 32 + li] = un;   // read back by the same wave only (epilogue)
-  const bool a_vec = ((K & 3) == 0) && ((a_off & 3) == 0) && ((a_node_stride & 3) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-  auto load_a = [&](int q, float (&v)[8]) {
-    const int k = 16 * q + 8 * half;
-    if (a_ok && a_vec && k + 7 < K) {
-      const f32x4 lo = *reinterpret_cast<const f32x4 *>(a_ptr + 16 * q);
-      const f32x4 hi = *reinterpret_cast<const f32x4 *>(a_ptr + 16 * q + 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] = lo[i]; v[4 + i] = hi[i]; }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (a_ok && k + i < K) ? a_ptr[16 * q + i] : 0.f;
-    }
-  };
-  constexpr int NST = (SLAB + 255) / 256;
-  auto load_b = [&](int q, u32x4 (&st)[NST]) {
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      const int idx = tid + 256 * i;
-      const int t = idx >> 7, rem = idx & 127;
-      u32x4 z = {0u, 0u, 0u, 0u};
-      if (idx < SLAB && tile0 + t < n_tiles) z = Bp[((int64_t)(tile0 + t) * nq + q) * 128 + rem];
-      st[i] = z;
-    }
-  };
-  auto store_b = [&](int buf, const u32x4 (&st)[NST]) {
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < SLAB) Bs[buf * SLAB + idx] = st[i];
-    }
-  };
-  f32x16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = zero16();
-  // Both operands run TWO k steps ahead (the memory counter retires loads in order: a weight slab stored to LDS in the
-  // iteration that requested it exposes its L2 latency on every k step).  With six bf16 products per step the instruction
-  // stream hid that latency (SQ counters: 64 % of the issue slots busy); with three fp16 products it does not (74 % of the
-  // wave cycles waiting, no gain) -- unless the chain is taken off the critical path like this.
-  // Iteration q: request A(q + 2), B(q + 2); multiply A(q) (registers) with B(q) (LDS); park B(q + 1), requested one iteration ago.
-  float ring[2][8];
-  u32x4 stb[2][NST];
-  load_a(0, ring[0]);
-  load_b(0, stb[0]);
-  if (nq > 1) {
-    load_a(1, ring[1]);
-    load_b(1, stb[1]);
-  }
-  store_b(0, stb[0]);
-  __syncthreads();
-  auto step = [&](int q, auto J) {
-    constexpr int jj = decltype(J)::value;
-    float av[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) av[i] = ring[jj][i] * sa;
-    const SplitN<2> a = splitn8<2, true>(av);
-    const f16x8 ah = __builtin_bit_cast(f16x8, a.t[0]), al = __builtin_bit_cast(f16x8, a.t[1]);
-    if (q + 2 < nq) {
-      load_a(q + 2, ring[jj]);
-      load_b(q + 2, stb[jj]);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const f16x8 bh = __builtin_bit_cast(f16x8, Bs[jj * SLAB + (t * 2 + 0) * 64 + lane]);
-      const f16x8 bl = __builtin_bit_cast(f16x8, Bs[jj * SLAB + (t * 2 + 1) * 64 + lane]);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-    }
-    if (q + 1 < nq) store_b(jj ^ 1, stb[jj ^ 1]);
-    __syncthreads();
-  };
-  for (int q = 0; q < nq; q += 2) {
-    step(q, std::integral_constant<int, 0>{});
-    if (q + 1 < nq) step(q + 1, std::integral_constant<int, 1>{});
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int off = (j & 3) + 8 * (j >> 2) + 4 * half;
-    if (row0 + off >= n_rows) continue;
-    int64_t nn;
-    int mm;
-    rows.at(off, nn, mm);
-    const int64_t nd = row_idx ? (int64_t)row_idx[nn] : nn;
-    float *crow = C + nd * c_node_stride + c_off + (int64_t)mm * N;
-    const float u = s_un[wave * 32 + off];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int col = 32 * (tile0 + t) + li;
-      if (col < N) {
-        const float v = acc[t][j] * u;
-        crow[col] = accumulate ? crow[col] + v : v;
-      }
-    }
-  }
-}
-
-struct GroupArgs16 {
-  GroupArgs g;
-  int b_exp[SNET_MAX_GEMM_GROUP];
-};
-
-__global__ __launch_bounds__(256, 3) void gemm_f16_grouped_kernel(GroupArgs16 G16, const float *__restrict__ A,
-                                                                             float *__restrict__ C, int64_t n_nodes,
-                                                                             int64_t a_node_stride, int64_t c_node_stride,
-                                                                             const int32_t *__restrict__ row_idx,
-                                                                             const float *__restrict__ a_bound, float bound_mult) {
-  __shared__ snet::u32x4 Bs[2 * 4 * 128];
-  __shared__ float s_un[4 * 32];
-  const GroupArgs &G = G16.g;
-  int q = 0;
-  while (q + 1 < G.n && (int)blockIdx.x >= G.first_block[q + 1]) ++q;
-  const snet_gemm_desc P = G.p[q];
-  const int b = blockIdx.x - G.first_block[q];
-  const int bx = b % G.nbx[q], by = b / G.nbx[q];
-  const int64_t n_rows = n_nodes * P.d;
-  const snet::u32x4 *Bp = static_cast<const snet::u32x4 *>(P.B_split);
-  if (P.N > 64)
-    gemm_f16_body<4>(Bs, s_un, bx, by, A, Bp, C, n_rows, P.d, P.K, P.N, a_node_stride, P.a_off, c_node_stride, P.c_off, row_idx,
-                     P.accumulate, a_bound, bound_mult, G16.b_exp[q]);
-  else if (P.N > 32)
-    gemm_f16_body<2>(Bs, s_un, bx, by, A, Bp, C, n_rows, P.d, P.K, P.N, a_node_stride, P.a_off, c_node_stride, P.c_off, row_idx,
-                     P.accumulate, a_bound, bound_mult, G16.b_exp[q]);
-  else
-    gemm_f16_body<1>(Bs, s_un, bx, by, A, Bp, C, n_rows, P.d, P.K, P.N, a_node_stride, P.a_off, c_node_stride, P.c_off, row_idx,
-                     P.accumulate, a_bound, bound_mult, G16.b_exp[q]);
-}
-
 inline uint16_t bf16_rne(float v) {
   uint32_t u;
   memcpy(&u, &v, 4);
@@ -611,66 +450,6 @@ extern "C" int snet_gemm_grouped(const snet_gemm_desc *descs_host, int32_t n_des
   else
     gemm_split_grouped_kernel<1><<<(unsigned)total, 256, 0, st>>>(G, A, C, n_nodes, a_node_stride, c_node_stride, row_idx);
   SNET_CHECK_LAUNCH("snet_gemm_grouped");
-  return 0;
-}
-
-
-extern "C" int64_t snet_gemm_f16_size(int32_t K, int32_t N) {
-  if (K < 1 || N < 1) return 0;
-  return (int64_t)((N + 31) / 32) * ((K + 15) / 16) * 2 * 64 * 16;
-}
-
-extern "C" int snet_gemm_f16_pack(const float *B_host, int32_t K, int32_t N, void *packed_host, int32_t *b_exp) {
-  SNET_REQUIRE(B_host != nullptr && packed_host != nullptr && b_exp != nullptr && K >= 1 && N >= 1, "snet_gemm_f16_pack: bad argument");
-  uint16_t *out = static_cast<uint16_t *>(packed_host);
-  const int kb = snet::f16_scale_exp(B_host, (size_t)K * N);
-  *b_exp = kb;
-  const int nq = (K + 15) / 16, n_tiles = (N + 31) / 32;
-  for (int t = 0; t < n_tiles; ++t)
-    for (int q = 0; q < nq; ++q)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int i = 0; i < 8; ++i) {
-          const int k = 16 * q + 8 * (lane >> 5) + i, n = 32 * t + (lane & 31);
-          const float x = (k < K && n < N) ? std::ldexp(B_host[(size_t)k * N + n], kb) : 0.f;
-          const uint16_t h = snet::f16_rne(x);
-          const uint16_t l = snet::f16_rne(x - snet::f16_f(h));
-          const size_t base = ((size_t)(t * nq + q) * 2) * 64;
-          out[((base + 0 * 64 + lane) * 8) + i] = h;
-          out[((base + 1 * 64 + lane) * 8) + i] = l;
-        }
-  return 0;
-}
-
-extern "C" int snet_gemm_grouped_f16(const snet_gemm_desc *descs_host, const int32_t *b_exps_host, int32_t n_desc, const float *A,
-                                     float *C, int64_t n_nodes, int64_t a_node_stride, int64_t c_node_stride,
-                                     const int32_t *row_idx, const float *a_row_bound, float bound_mult, void *stream) {
-  SNET_REQUIRE(descs_host != nullptr && b_exps_host != nullptr && n_desc >= 1 && n_desc <= SNET_MAX_GEMM_GROUP,
-               "snet_gemm_grouped_f16: 1..8 problems required");
-  SNET_REQUIRE(a_row_bound != nullptr && bound_mult > 0.f, "snet_gemm_grouped_f16: the row bounds of A are required");
-  if (n_nodes <= 0) return 0;
-  GroupArgs16 G16;
-  GroupArgs &G = G16.g;
-  G.n = n_desc;
-  int64_t total = 0;
-  for (int i = 0; i < n_desc; ++i) {
-    const snet_gemm_desc &p = descs_host[i];
-    SNET_REQUIRE(p.d >= 1 && p.d <= 150 && p.K >= 1 && p.N >= 1 && p.B_split != nullptr,
-                 "snet_gemm_grouped_f16: bad problem (weights packed by snet_gemm_f16_pack required)");
-    const int bn = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
-    const int64_t nbx = (n_nodes * p.d + 127) / 128;
-    const int64_t nby = (p.N + bn - 1) / bn;
-    SNET_REQUIRE(nbx < (1ll << 30), "snet_gemm_grouped_f16: too many rows");
-    G.p[i] = p;
-    G.nbx[i] = (int)nbx;
-    G.first_block[i] = (int)total;
-    G16.b_exp[i] = b_exps_host[i];
-    total += nbx * nby;
-  }
-  G.first_block[n_desc] = (int)total;
-  SNET_REQUIRE(total < (1ll << 31), "snet_gemm_grouped_f16: grid too large");
-  gemm_f16_grouped_kernel<<<(unsigned)total, 256, 0, static_cast<hipStream_t>(stream)>>>(G16, A, C, n_nodes, a_node_stride,
-                                                                                        c_node_stride, row_idx, a_row_bound, bound_mult);
-  SNET_CHECK_LAUNCH("snet_gemm_grouped_f16");
   return 0;
 }
 

@@ -249,33 +249,6 @@ def test_scalar_output_shapes_carry_their_transposed_form():
             lib.snet_conv_plan_destroy(plan)
 
 
-def test_two_fp16_term_weight_packing_reconstructs_the_matrix():
-    """snet_gemm_f16_pack (host side of snet_gemm_grouped_f16): every weight is stored as hi + lo (two fp16 terms) of the value
-    scaled by one power of two per matrix; the pair reconstructs it to 2^-22 of the matrix scale, the largest entry sits in
-    [2^13, 2^14), fragments follow the 32x32x16 MFMA B layout, padding is zero"""
-    from sevennet_amd import _lib
-    lib = _lib.load()
-    rng = np.random.default_rng(7)
-    for K, N, mag in ((224, 224, 1.0), (33, 7, 1e-4), (16, 32, 3e3)):
-        B = (rng.standard_normal((K, N)) * mag).astype(np.float32)
-        buf = np.zeros(int(lib.snet_gemm_f16_size(K, N)), np.uint8)
-        e = C.c_int32()
-        _lib.check(lib.snet_gemm_f16_pack(B.ctypes.data_as(C.c_void_p), K, N, buf.ctypes.data_as(C.c_void_p), C.byref(e)),
-                   'snet_gemm_f16_pack')
-        top = np.abs(B).max() * 2.0 ** e.value
-        assert 2.0 ** 13 <= top < 2.0 ** 14
-        nq, nt = (K + 15) // 16, (N + 31) // 32
-        frag = buf.view(np.float16).reshape(nt, nq, 2, 64, 8).astype(np.float64)
-        rec = np.zeros((nq * 16, nt * 32))
-        for lane in range(64):
-            for i in range(8):
-                rec[8 * (lane >> 5) + i::16, (lane & 31)::32] = (frag[:, :, 0, lane, i] + frag[:, :, 1, lane, i]).T
-        want = np.zeros_like(rec)
-        want[:K, :N] = B.astype(np.float64) * 2.0 ** e.value
-        assert np.abs(rec - want).max() <= 2.0 ** -22 * 2.0 ** 14
-        assert np.all(rec[K:] == 0) and np.all(rec[:, N:] == 0)
-
-
 def test_row_map_reciprocal_is_exact_in_its_stated_range():
     """csrc/snet_gemm.hip::RowMap divides (m0 + off) by d with a 16-bit reciprocal, m0 < d, off < 256, and the entry points
     refuse d > 150: the identity ((x * (65536 / d + 1)) >> 16) == x / d must hold for every such x"""

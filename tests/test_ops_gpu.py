@@ -82,72 +82,6 @@ def _pack_split(L, lib, B):
     return torch.from_numpy(buf).to(B.device)
 
 
-def _pack_f16(L, lib, B):
-    """[K,N] fp32 -> (device buffer of two-fp16-term MFMA B fragments, matrix exponent)"""
-    Bh = np.ascontiguousarray(B.detach().cpu().numpy(), dtype=np.float32)
-    K, N = Bh.shape
-    buf = np.empty(int(lib.snet_gemm_f16_size(K, N)), np.uint8)
-    e = C.c_int32()
-    L.check(lib.snet_gemm_f16_pack(Bh.ctypes.data_as(C.c_void_p), K, N, buf.ctypes.data_as(C.c_void_p), C.byref(e)))
-    return torch.from_numpy(buf).to(B.device), e.value
-
-
-@pytest.mark.parametrize('bound', ['absmax', 'norm_x64', 'tiny_rows'])
-@pytest.mark.parametrize('shape', ['sevennet0_sc', 'si2_T_like', 'ragged'])
-def test_gemm_two_fp16_terms_vs_fp64(shape, bound):
-    """snet_gemm_grouped_f16 (three fp16 products per k step, A rows scaled from a caller-supplied bound, B per matrix):
-    fp32-rounding class against fp64 whatever the rows' magnitudes (1e-7 ... 1e5 in one launch) and however loose the bound
-    (x64), species row lists and accumulation like the bf16 x 6 kernel"""
-    L, lib = _lib()
-    dev = 'cuda:0'
-    g = torch.Generator().manual_seed(12)
-    if shape == 'sevennet0_sc':
-        n, din, dout, probs = 3000, 480, 576, [(1, 128, 224, 0, 0), (3, 64, 64, 128, 224), (5, 32, 32, 320, 416)]
-    elif shape == 'si2_T_like':
-        n, din, dout, probs = 2000, 576, 3136, [(1, 224, 224, 0, 0), (3, 64, 384, 224, 224), (5, 32, 352, 416, 1376)]
-    else:
-        n, din, dout, probs = 777, 61, 83, [(1, 4, 7, 0, 0), (3, 9, 20, 4, 7), (5, 6, 3, 31, 67)]
-    A = torch.randn(n, din, generator=g)
-    mag = 10.0 ** (torch.rand(n, 1, generator=g) * 12 - 7)          # every row its own magnitude
-    if bound == 'tiny_rows':
-        mag = mag * 1e-20
-    A = (A * mag).to(dev)
-    A[5].zero_()
-    Bs = [(torch.randn(K, N, generator=g) * 10.0 ** float(torch.randint(-3, 3, (1,), generator=g))).to(dev) for (_, K, N, _, _) in probs]
-    packed = [_pack_f16(L, lib, B) for B in Bs]
-    if bound == 'norm_x64':
-        rb, mult = (A.double().norm(dim=1) * 64).float().contiguous(), 1.0
-    else:
-        rb, mult = (A.abs().amax(1) * 4).contiguous(), 0.25
-    C1 = torch.full((n, dout), 7.0, device=dev)
-    descs = (L.GemmDesc * 3)(*[L.GemmDesc(None, P[0].data_ptr(), ao, co, d, K, N, 0) for (d, K, N, ao, co), P in zip(probs, packed)])
-    exps = (C.c_int32 * 3)(*[P[1] for P in packed])
-    L.check(lib.snet_gemm_grouped_f16(descs, exps, 3, _p(A), _p(C1), n, din, dout, None, _p(rb), mult, None))
-    torch.cuda.synchronize()
-    assert torch.isfinite(C1).all()
-    for (d, K, N, ao, co), B in zip(probs, Bs):
-        ref = torch.einsum('nmk,kj->nmj', A[:, ao:ao + d * K].reshape(n, d, K).double(), B.double()).reshape(n, d * N)
-        got = C1[:, co:co + d * N].double()
-        # per row: relative to the row's own scale (|A row| |B| sqrt(K)), fp32-class
-        scale = A[:, ao:ao + d * K].double().abs().amax(1, keepdim=True) * B.double().abs().max() * K ** 0.5
-        err = ((got - ref).abs() / scale.clamp_min(1e-300)).max().item()
-        assert err <= (3e-6 if bound != 'norm_x64' else 2e-5), (shape, bound, d, K, N, err)
-        assert got[5].abs().max().item() == 0.0
-    # accumulate + row list
-    rows = torch.arange(0, n, 3, dtype=torch.int32, device=dev)
-    C2 = C1.clone()
-    descs_acc = (L.GemmDesc * 3)(*[L.GemmDesc(None, P[0].data_ptr(), ao, co, d, K, N, 1) for (d, K, N, ao, co), P in zip(probs, packed)])
-    L.check(lib.snet_gemm_grouped_f16(descs_acc, exps, 3, _p(A), _p(C2), rows.numel(), din, dout, _p(rows), _p(rb), mult, None))
-    torch.cuda.synchronize()
-    sel = rows.long()
-    d, K, N, ao, co = probs[0]
-    assert torch.allclose(C2[sel, co:co + N], 2 * C1[sel, co:co + N], rtol=1e-5, atol=0)
-    mask = torch.ones(n, dtype=torch.bool, device=dev)
-    mask[sel] = False
-    assert torch.equal(C2[mask], C1[mask])
-    assert lib.snet_gemm_grouped_f16(descs, exps, 3, _p(A), _p(C1), n, din, dout, None, None, 1.0, None) != 0   # bounds are mandatory
-
-
 @pytest.mark.parametrize('n', [1234, 70000])   # 32 and 64 rows per wave
 @pytest.mark.parametrize('shape', ['sevennet0_sc', 'si2_like', 'ragged'])
 def test_gemm_split_precision_vs_fp64(shape, n):
