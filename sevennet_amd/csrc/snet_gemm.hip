@@ -54,7 +54,7 @@ __device__ __forceinline__ void gemm_body(float *As, float *Bs, int bx, int by,
   constexpr int BN = 32 * NT;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t row0 = (int64_t)bx * BM;
   const int col0 = by * BN;
   const RowMap rows(row0, d);
@@ -161,6 +161,33 @@ template <int NT, int MT>
 __device__ __forceinline__ void gemm_split_store(const snet::f32x16 (&acc)[MT][NT], const RowMap &rows, int64_t row0, int half, int li,
     int tile0, float *__restrict__ C, int64_t n_rows, int N, int64_t c_node_stride, int64_t c_off,
     const int32_t *__restrict__ row_idx, int accumulate) {
+  // Fast path (round 6; wave-uniform condition): scalar blocks (d = 1: row = node), no row list, the wave's 32 MT rows and NT column
+  // tiles all in range -- the l = 0 blocks of every linear away from the last tile, i.e. most of the node-GEMM work.  A row's address is
+  // then a per-lane base plus a wave-uniform multiple of the node stride: no row map, no gather, no predicate per store (the general
+  // path below spends ~12 vector instructions and a branch per row on them; the epilogue is a third of the stream of a K = 128 tile).
+  if (rows.d == 1u && row_idx == nullptr && row0 + 32 * MT <= n_rows && 32 * (tile0 + NT) <= N) {
+    float *base = C + (row0 + 4 * half) * c_node_stride + c_off + 32 * tile0 + li;
+    if (accumulate) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float *crow = base + (int64_t)(32 * mt + (j & 3) + 8 * (j >> 2)) * c_node_stride;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) crow[32 * t] += acc[mt][t][j];
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float *crow = base + (int64_t)(32 * mt + (j & 3) + 8 * (j >> 2)) * c_node_stride;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) crow[32 * t] = acc[mt][t][j];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -195,7 +222,7 @@ __device__ __forceinline__ void gemm_split_body(snet::u32x4 *Bs, int bx, int by,
     int accumulate) {
   using namespace snet;
   constexpr int SLAB = NT * 192;  // u32x4 per k step
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, li = lane & 31;
   const int64_t row0 = ((int64_t)bx * 4 + wave) * (32 * MT);
   const int nq = (K + 15) >> 4, n_tiles = (N + 31) >> 5, tile0 = by * NT;

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void radial_mlp_fwd_kernel(const float *__rest
   __shared__ float W1s[H * H];
   for (int i = threadIdx.x; i < H * H; i += 256) W1s[i] = W1[i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, li = lane & 31;
   const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
   if (e0 >= E) return;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void radial_mlp_bwd_kernel(const float *__rest
   __shared__ float gws[4 * GW_TILE];
   __shared__ float w2t[2][CH * H];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, li = lane & 31;
   const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
   const bool wave_ok = e0 < E;  // every wave stays in the block-wide barriers
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_kernel(const floa
   // (cuts the L2 -> CU fragment traffic 4x relative to per-wave loads)
   __shared__ u32x4 slab[2][W2B_TILE_U4];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, li = lane & 31;
   const int64_t e0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
   const bool wave_ok = e0 < E;  // all waves stay for the block barriers
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_hidden_split_kernel(const f
                                                                       const u32x4 *__restrict__ W1A, int act, float cst,
                                                                       float *__restrict__ h2) {
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, li = lane & 31;
   const int64_t e_lane = ((int64_t)blockIdx.x * 4 + wave) * 32 + li;
   const bool e_ok = e_lane < E;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(64 * SNET_MLP_BWD_WAVES, SNET_MLP_BWD_OCC) void rad
   __shared__ float gws[NWV * GS_TILE];
   __shared__ u32x4 slab[2][SLAB_U4];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, li = lane & 31;
   const int64_t e0 = ((int64_t)blockIdx.x * NWV + wave) * 32;
   const bool wave_ok = e0 < E;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_hidden_bwd_split_kernel(
     const u32x4 *__restrict__ W1A, const u32x4 *__restrict__ W1A2, const u32x4 *__restrict__ W0A, int act, float cst,
     float *__restrict__ g_emb) {
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, li = lane & 31;
   const int64_t e_lane = ((int64_t)blockIdx.x * 4 + wave) * 32 + li;
   const bool e_ok = e_lane < E;

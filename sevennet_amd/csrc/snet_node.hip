@@ -97,7 +97,7 @@ __device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p)
 __global__ __launch_bounds__(256) void gate_fwd_vec_kernel(GateTable T, float *__restrict__ y, const float *__restrict__ addend,
                                                           float *__restrict__ out, int64_t n_nodes, int dim_in, int dim_out) {
   const int lane = threadIdx.x & 63;
-  const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t node = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (node >= n_nodes) return;
   float *yr = y + node * dim_in;
   const float *ar = addend ? addend + node * dim_in : nullptr;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void gate_bwd_vec_kernel(GateTable T, const fl
                                                           float *__restrict__ g_y, int64_t n_nodes, int dim_in, int dim_out,
                                                           float norm_mult, float *__restrict__ row_norm) {
   const int lane = threadIdx.x & 63;
-  const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t node = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (node >= n_nodes) return;
   const float *yr = y + node * dim_in;
   const float *gor = g_out + node * dim_out;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *__re
 // out[r] = max_k |x[r, k]|: one wavefront per row (16-byte loads when the rows allow it)
 __global__ void row_absmax_kernel(const float *__restrict__ x, int64_t n_rows, int dim, float *__restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (r >= n_rows) return;
   const float *row = x + r * dim;
   float m = 0.f;
@@ -279,7 +279,7 @@ __global__ void row_absmax_kernel(const float *__restrict__ x, int64_t n_rows, i
 // out[r] = mult * ||x[r, :]||_2 (fp32 sum of squares: a bound needs no more)
 __global__ void row_norm2_kernel(const float *__restrict__ x, int64_t n_rows, int dim, float mult, float *__restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (r >= n_rows) return;
   const float *row = x + r * dim;
   float m = 0.f;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void readout_energy_kernel(const float *__rest
                                                              const float *__restrict__ shift, int n_scale,
                                                              float *__restrict__ e_atom, double *__restrict__ partial) {
   __shared__ double sm[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += (int64_t)gridDim.x * 4) {
     const float *row = x + i * dim;
