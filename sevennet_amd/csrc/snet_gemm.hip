@@ -238,7 +238,7 @@ __device__ __forceinline__ void gemm_split_body(snet::u32x4 *Bs, int bx, int by,
     int m = 0;
     if (a_ok[mt]) rows.at(32 * mt + li, n, m);
     const int64_t node = row_idx ? (int64_t)row_idx[n] : n;
-    a_ptr[mt] = A + node * a_node_stride + a_off + (int64_t)m * K + 8 * half;
+    a_ptr[mt] = A + node * a_node_stride + a_off + (int64_t)m * K + 8 * half;   // (rows past the end: node 0, m 0 -- valid memory, results never stored)
   }
   const bool a_vec = ((K & 3) == 0) && ((a_off & 3) == 0) && ((a_node_stride & 3) == 0) &&
                      ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
@@ -260,6 +260,19 @@ __device__ __forceinline__ void gemm_split_body(snet::u32x4 *Bs, int bx, int by,
   };
   constexpr int NST = (SLAB + 255) / 256;
   auto load_b = [&](int q, u32x4 (&st)[NST]) {
+    // Fast path (round 6), wave-uniform condition: all NT column tiles exist -- no per-thread tile test.  Same box, three interleaved
+    // runs: node_linear_bwd 2.53 -> 2.39 ms, node_linear_fwd 2.19 -> 2.20.  The matching fast path for the A operand (two
+    // unconditional 16-byte loads when the k step lies inside K) was measured too and is NOT taken: fwd 2.19 -> 2.25, and with both
+    // the backward gain shrinks to 2.48 (profiles/r06_ab_node_kernels.txt).
+    if (tile0 + NT <= n_tiles) {
+#pragma unroll
+      for (int i = 0; i < NST; ++i) {
+        const int idx = tid + 256 * i;
+        const int t = idx / 192, rem = idx - 192 * t;
+        if (SLAB % 256 == 0 || idx < SLAB) st[i] = Bp[((int64_t)(tile0 + t) * nq + q) * 192 + rem];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
       const int idx = tid + 256 * i;
