@@ -186,6 +186,11 @@ int snet_conv_fwd(const snet_conv_plan *plan, const float *x, const float *sh, c
 #define SNET_FUSED_TERMS_DEFAULT 4
 typedef struct snet_fused_plan snet_fused_plan;
 int snet_radial_mlp_hidden_fwd(const snet_mlp_plan *plan, const float *emb, int64_t n_edges, float *h2, void *stream);
+/* the hidden activations of n_layers (1 .. 8) interaction layers in ONE launch: the layers read the same edge embedding
+ * (nn/edge_embedding.py:176-181 feeds every convolution's weight_nn, nn/convolution.py:124) and differ in weights only;
+ * h2[l] <- what snet_radial_mlp_hidden_fwd(plans[l], ...) writes, bit for bit (it is the same kernel with one layer). */
+int snet_radial_mlp_hidden_fwd_layers(const snet_mlp_plan *const *plans, int32_t n_layers, const float *emb, int64_t n_edges,
+                                      float *const *h2, void *stream);
 int snet_radial_mlp_hidden_bwd(const snet_mlp_plan *plan, const float *emb, const float *g_h2, int64_t n_edges,
                                float *g_emb, void *stream);
 int snet_conv_fused_available(const snet_conv_plan *plan);

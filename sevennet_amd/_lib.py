@@ -69,6 +69,7 @@ SIGNATURES = {
     'snet_conv_fwd': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_float,
                                 c_f32p, c_stream]),
     'snet_radial_mlp_hidden_fwd': (C.c_int, [C.c_void_p, c_f32p, C.c_int64, c_f32p, c_stream]),
+    'snet_radial_mlp_hidden_fwd_layers': (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, c_f32p, C.c_int64, C.POINTER(C.c_void_p), c_stream]),
     'snet_radial_mlp_hidden_bwd': (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int64, c_f32p, c_stream]),
     'snet_conv_fused_available': (C.c_int, [C.c_void_p]),
     'snet_conv_plan_transposed': (C.c_int, [C.c_void_p, C.c_char_p, c_f32p, c_i32p, C.c_int32, C.POINTER(C.c_int32)]),

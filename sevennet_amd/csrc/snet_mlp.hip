@@ -315,7 +315,16 @@ __device__ __forceinline__ void load_frag3(const u32x4 *__restrict__ base, int f
   for (int t = 0; t < 3; ++t) out[t] = as_bf16x8(base[(frag * 3 + t) * 64 + lane]);
 }
 
-// z1 (fp32 MFMA, K = nb) and z2 (split MFMA) in the transposed layout
+// the activation id as a compile-time constant (ACT >= 0: no per-element scalar branch, and the compiler may move the matrix
+// instructions of one k step under the vector work of the next) or read at run time (ACT < 0)
+template <int ACT>
+__device__ __forceinline__ float act_sel(float z, int act) {
+  if constexpr (ACT >= 0) return snet::act_fwd_fast(z, ACT);
+  else return snet::act_fwd_fast(z, act);
+}
+
+// z1 (fp32 MFMA, K = nb) and z2 (split MFMA) in the transposed layout.  NB > 0: the number of basis functions at compile time.
+template <int ACT = -1, int NB = 0>
 __device__ __forceinline__ void hidden_forward_split(const float *__restrict__ emb, int64_t e_lane, bool e_ok, int nb,
                                                      const float *__restrict__ W0, const u32x4 *__restrict__ W1A,
                                                      int act, float cst, int lane, f32x16 (&z1)[2],
@@ -323,14 +332,20 @@ __device__ __forceinline__ void hidden_forward_split(const float *__restrict__ e
   const int half = lane >> 5, li = lane & 31;
   z1[0] = zero16();
   z1[1] = zero16();
-  for (int s = 0; 2 * s < nb; ++s) {
+  auto l1_step = [&](int s, int n_basis) {
     const int k = 2 * s + half;
-    const float b = (e_ok && k < nb) ? emb[e_lane * nb + k] : 0.f;
+    const float b = (e_ok && k < n_basis) ? emb[e_lane * n_basis + k] : 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const float a = (k < nb) ? W0[k * H + 32 * t + li] : 0.f;
+      const float a = (k < n_basis) ? W0[k * H + 32 * t + li] : 0.f;
       z1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, z1[t], 0, 0, 0);
     }
+  };
+  if constexpr (NB > 0) {
+#pragma unroll
+    for (int s = 0; 2 * s < NB; ++s) l1_step(s, NB);
+  } else {
+    for (int s = 0; 2 * s < nb; ++s) l1_step(s, nb);
   }
   z2[0] = zero16();
   z2[1] = zero16();
@@ -338,7 +353,7 @@ __device__ __forceinline__ void hidden_forward_split(const float *__restrict__ e
   for (int q = 0; q < 4; ++q) {
     float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = snet::act_fwd_fast(z1[q >> 1][8 * (q & 1) + i], act) * cst;
+    for (int i = 0; i < 8; ++i) v[i] = act_sel<ACT>(z1[q >> 1][8 * (q & 1) + i], act) * cst;
     const Split3 b = split8(v);
 #pragma unroll
     for (int to = 0; to < 2; ++to) {
@@ -414,29 +429,49 @@ __global__ __launch_bounds__(256, 2) void radial_mlp_fwd_split_kernel(const floa
 }
 
 // hidden activations only: h2[E,64] = act(act(emb W0) cst W1) cst -- the operand of the radial MLP's last
-// layer when that layer is fused into the tensor-product kernels (generated conv_ffwd_*)
-__global__ __launch_bounds__(256, 2) void radial_mlp_hidden_split_kernel(const float *__restrict__ emb, int64_t E, int nb,
-                                                                      const float *__restrict__ W0,
-                                                                      const u32x4 *__restrict__ W1A, int act, float cst,
-                                                                      float *__restrict__ h2) {
+// layer when that layer is fused into the tensor-product kernels (generated conv_ffwd_*).
+// Round 6: ALL interaction layers' hidden activations in one launch (they share the edge embedding and differ in weights only).
+// At an eighth of the benchmark cell (340 k edges) five launches of 2 660 workgroups cost 55 us each against 24 us of work;
+// one launch with five times the work per wave removes four dependent dispatches from the step.  The activation id and the
+// basis count are template constants for the common case (silu, 8 Bessel functions): with the id read at run time every one of
+// the 128 activations per edge sat behind its own scalar compare-and-branch, and the kernel was bound by vector issue, not by
+// its 50 matrix instructions (19 241 static instructions, `tools/isa_census.py snet_mlp radial_mlp_hidden`).
+constexpr int MAX_HIDDEN_LAYERS = 8;
+struct HiddenLayers {
+  const float *W0[MAX_HIDDEN_LAYERS];
+  const u32x4 *W1A[MAX_HIDDEN_LAYERS];
+  float *h2[MAX_HIDDEN_LAYERS];
+  float cst[MAX_HIDDEN_LAYERS];
+  int act[MAX_HIDDEN_LAYERS];
+  int n;
+};
+
+template <int ACT, int NB>
+__global__ __launch_bounds__(256, 2) void radial_mlp_hidden_layers_kernel(const float *__restrict__ emb, int64_t E, int nb,
+                                                                       HiddenLayers P) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, li = lane & 31;
   const int64_t e_lane = ((int64_t)blockIdx.x * 4 + wave) * 32 + li;
   const bool e_ok = e_lane < E;
-  f32x16 z1[2], z2[2];
-  hidden_forward_split(emb, e_ok ? e_lane : 0, e_ok, nb, W0, W1A, act, cst, lane, z1, z2);
-  if (!e_ok) return;
-  // lane (li, half) holds hidden units 32t + (r&3) + 8(r>>2) + 4 half of edge li: 16-byte groups
+  for (int l = 0; l < P.n; ++l) {
+    const int act = P.act[l];
+    const float cst = P.cst[l];
+    f32x16 z1[2], z2[2];
+    hidden_forward_split<ACT, NB>(emb, e_ok ? e_lane : 0, e_ok, nb, P.W0[l], P.W1A[l], act, cst, lane, z1, z2);
+    if (!e_ok) continue;
+    float *__restrict__ h2 = P.h2[l];
+    // lane (li, half) holds hidden units 32t + (r&3) + 8(r>>2) + 4 half of edge li: 16-byte groups
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 v;
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = snet::act_fwd_fast(z2[t][4 * g + i], act) * cst;
-      *reinterpret_cast<f32x4 *>(h2 + e_lane * H + 32 * t + 8 * g + 4 * half) = v;
-    }
+        for (int i = 0; i < 4; ++i) v[i] = act_sel<ACT>(z2[t][4 * g + i], act) * cst;
+        *reinterpret_cast<f32x4 *>(h2 + e_lane * H + 32 * t + 8 * g + 4 * half) = v;
+      }
+  }
 }
 
 #ifndef SNET_MLP_BWD_OCC
@@ -793,16 +828,36 @@ extern "C" int snet_radial_mlp_fwd(const snet_mlp_plan *p, const float *emb, int
   return 0;
 }
 
-extern "C" int snet_radial_mlp_hidden_fwd(const snet_mlp_plan *p, const float *emb, int64_t E, float *h2, void *stream) {
-  SNET_REQUIRE(p != nullptr, "snet_radial_mlp_hidden_fwd: null plan");
-  SNET_REQUIRE(p->mode == 1, "snet_radial_mlp_hidden_fwd: split-precision plans only (mode 1)");
+extern "C" int snet_radial_mlp_hidden_fwd_layers(const snet_mlp_plan *const *plans, int32_t n_layers, const float *emb, int64_t E,
+                                                 float *const *h2, void *stream) {
+  SNET_REQUIRE(plans != nullptr && h2 != nullptr, "snet_radial_mlp_hidden_fwd_layers: null argument");
+  SNET_REQUIRE(n_layers >= 1 && n_layers <= MAX_HIDDEN_LAYERS, "snet_radial_mlp_hidden_fwd_layers: 1 .. 8 layers per call");
+  HiddenLayers P{};
+  P.n = n_layers;
+  bool silu = true;
+  for (int l = 0; l < n_layers; ++l) {
+    const snet_mlp_plan *p = plans[l];
+    SNET_REQUIRE(p != nullptr && h2[l] != nullptr, "snet_radial_mlp_hidden_fwd_layers: null plan / output");
+    SNET_REQUIRE(p->mode == 1, "snet_radial_mlp_hidden_fwd_layers: split-precision plans only (mode 1)");
+    SNET_REQUIRE(p->nb == plans[0]->nb, "snet_radial_mlp_hidden_fwd_layers: the layers must share the edge embedding (same n_basis)");
+    P.W0[l] = p->W0; P.W1A[l] = p->W1A; P.h2[l] = h2[l]; P.cst[l] = p->cst; P.act[l] = p->act;
+    silu = silu && p->act == 0;
+  }
   if (E <= 0) return 0;
   const int64_t grid = (E + 127) / 128;
-  SNET_REQUIRE(grid < (1ll << 31), "snet_radial_mlp_hidden_fwd: too many edges");
-  radial_mlp_hidden_split_kernel<<<(unsigned)grid, 256, 0, static_cast<hipStream_t>(stream)>>>(emb, E, p->nb, p->W0, p->W1A,
-                                                                                              p->act, p->cst, h2);
-  SNET_CHECK_LAUNCH("snet_radial_mlp_hidden_fwd");
+  SNET_REQUIRE(grid < (1ll << 31), "snet_radial_mlp_hidden_fwd_layers: too many edges");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nb = plans[0]->nb;
+  if (silu && nb == 8) radial_mlp_hidden_layers_kernel<0, 8><<<(unsigned)grid, 256, 0, st>>>(emb, E, nb, P);
+  else if (silu) radial_mlp_hidden_layers_kernel<0, 0><<<(unsigned)grid, 256, 0, st>>>(emb, E, nb, P);
+  else radial_mlp_hidden_layers_kernel<-1, 0><<<(unsigned)grid, 256, 0, st>>>(emb, E, nb, P);
+  SNET_CHECK_LAUNCH("snet_radial_mlp_hidden_fwd_layers");
   return 0;
+}
+
+extern "C" int snet_radial_mlp_hidden_fwd(const snet_mlp_plan *p, const float *emb, int64_t E, float *h2, void *stream) {
+  SNET_REQUIRE(p != nullptr, "snet_radial_mlp_hidden_fwd: null plan");
+  return snet_radial_mlp_hidden_fwd_layers(&p, 1, emb, E, &h2, stream);   // (the same kernel: one layer)
 }
 
 namespace snet {

@@ -861,6 +861,19 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   }
   const size_t mark = A.off;  // transient region starts here
 
+  {  // hidden activations of every fused layer's radial MLP in one launch (the layers share the edge embedding; up to 8 per call)
+    const snet_mlp_plan *hp[8];
+    float *ho[8];
+    int nh = 0;
+    for (int t = 0; t <= Lc; ++t) {
+      if (t < Lc && m->layers[t].fused) { hp[nh] = m->layers[t].mlp_plan; ho[nh] = saved[t].w; ++nh; }
+      if (nh == 8 || (t == Lc && nh > 0)) {
+        if ((rc = snet_radial_mlp_hidden_fwd_layers(hp, nh, emb_w, WR, ho, st))) return rc;
+        nh = 0;
+      }
+    }
+  }
+
   // ---------------- forward
   for (int t = 0; t < Lc; ++t) {
     Layer &L = m->layers[t];
@@ -898,7 +911,6 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
         SNET_REQUIRE(hipMemset2DAsync(mid + z.first, (size_t)L.dmid * 4, 0, (size_t)z.second * 4, (size_t)N, st) == hipSuccess,
                      "snet_model_eval: memset");
     if (L.fused) {  // w = h2 @ W2 is formed inside the tensor-product kernel
-      if ((rc = snet_radial_mlp_hidden_fwd(L.mlp_plan, emb_w, WR, saved[t].w, st))) return rc;
       const int64_t na = fsplit ? n_int : 0;   // rows [0, na) before the exchange has landed, [na, N) after
       if (na > 0 && (rc = snet_conv_fwd_fused(L.fused, h, sh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, na, L.conv_scale, mid, st)))
         return rc;

@@ -671,6 +671,18 @@ class HipForceEngine:
             # numbering, a halo with the split protocol, and edges (the reverse side walks a tile list)
             split = bool(halo is not None and g.n_interior and hasattr(halo, 'forward_start') and hasattr(halo, 'reverse_start')
                          and E > 0 and self.halo_split)
+            # hidden activations of every layer's radial MLP, one row per pair, in ONE launch: the layers share the edge embedding
+            # (five launches of a latency-bound kernel at brick sizes; the rows are kept for the reverse pass anyway)
+            h2_rows = g.n_pairs if pairs else E
+            h2_of = {t_: self._new(h2_rows, 64) for t_, L_ in enumerate(self.layers) if L_.fused_fwd or L_.fused_bwd}
+            with _Span(self, 'radial_mlp_hidden_fwd'):
+                ts = sorted(h2_of)
+                for i in range(0, len(ts), 8):
+                    grp = ts[i:i + 8]
+                    plans = (C.c_void_p * len(grp))(*[self.layers[t_].mlp_plan for t_ in grp])
+                    outs = (C.c_void_p * len(grp))(*[h2_of[t_].data_ptr() for t_ in grp])
+                    _lib.check(lib.snet_radial_mlp_hidden_fwd_layers(plans, len(grp), _ptr(emb_p if pairs else emb), h2_rows, outs, st),
+                               'snet_radial_mlp_hidden_fwd_layers')
             for t, L in enumerate(self.layers):
                 ls = L.spec
                 n_in = NT if t == 0 else N  # rows of x that are valid
@@ -708,11 +720,7 @@ class HipForceEngine:
                         m[:, off:off + ln].zero_()
                 h2 = w = zs = None
                 rows_w = g.n_pairs if pairs else E
-                if L.fused_fwd or L.fused_bwd:  # hidden activations of the radial MLP, one row per pair
-                    h2 = self._new(rows_w, 64)
-                    with _Span(self, 'radial_mlp_hidden_fwd'):
-                        _lib.check(lib.snet_radial_mlp_hidden_fwd(L.mlp_plan, _ptr(emb_p if pairs else emb), rows_w,
-                                                                  _ptr(h2), st), 'snet_radial_mlp_hidden_fwd')
+                h2 = h2_of.pop(t, None)   # (computed before the layer loop)
                 if not (L.fused_fwd and L.fused_bwd):  # someone still reads w[rows, wn]
                     if side is not None:
                         (w, ev), zs = w_ready.pop(t), None

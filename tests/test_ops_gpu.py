@@ -994,3 +994,58 @@ def test_edges_by_source_and_transposed_scalar_convolution():
     assert want[7].abs().max().item() == 0.0 and got[7].abs().max().item() == 0.0
     lib.snet_conv_plan_destroy(plan)
     lib.snet_conv_plan_destroy(plan_t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nb,acts,E', [(8, (0, 0, 0, 0, 0), 1000), (8, (0, 1, 4), 333), (6, (0, 0), 130), (8, (0,), 5)])
+def test_radial_mlp_hidden_layers_one_launch(nb, acts, E):
+    """snet_radial_mlp_hidden_fwd_layers: the hidden activations of several interaction layers' radial MLPs from ONE launch ==
+    one snet_radial_mlp_hidden_fwd per layer, bit for bit, and == act(act(emb W0) c W1) c in fp64 (nn/convolution.py:124 feeds the
+    same edge embedding to every layer's weight_nn).  Covers the compile-time (silu, 8 basis functions) and the run-time
+    (mixed activations, 6 basis functions) instantiations and a ragged edge count."""
+    L, lib = _lib()
+    dev = 'cuda:0'
+    rng = np.random.default_rng(nb * 100 + E)
+    cst_of = {0: 1.6791767923989418, 1: 1.5937334472592695, 4: 1.6822012}
+    emb = torch.from_numpy(rng.normal(0, 0.6, (E, nb)).astype(np.float32)).to(dev)
+    plans, Ws = [], []
+    for a in acts:
+        W0 = (rng.normal(0, 1, (nb, 64)) / np.sqrt(nb)).astype(np.float32)
+        W1 = (rng.normal(0, 1, (64, 64)) / 8).astype(np.float32)
+        W2 = (rng.normal(0, 1, (64, 32)) / 8).astype(np.float32)
+        fp = lambda t: t.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        mlp = C.c_void_p()
+        L.check(lib.snet_radial_mlp_plan_create(nb, 64, 64, 32, fp(W0), fp(W1), fp(W2), a, cst_of[a], 1, C.byref(mlp)))
+        plans.append(mlp)
+        Ws.append((W0, W1))
+    n = len(acts)
+    one = [torch.full((E, 64), float('nan'), device=dev) for _ in acts]
+    for p, o in zip(plans, one):
+        L.check(lib.snet_radial_mlp_hidden_fwd(p, _p(emb), E, _p(o), None))
+    many = [torch.full((E, 64), float('nan'), device=dev) for _ in acts]
+    L.check(lib.snet_radial_mlp_hidden_fwd_layers((C.c_void_p * n)(*plans), n, _p(emb), E, (C.c_void_p * n)(*[o.data_ptr() for o in many]), None))
+    torch.cuda.synchronize()
+
+    def act(z, a):
+        if a == 0:
+            return z / (1 + np.exp(-z))
+        if a == 1:
+            return np.tanh(z)
+        return np.logaddexp(z, 0) - np.log(2.0)
+    e64 = emb.cpu().numpy().astype(np.float64)
+    for a, (W0, W1), o, mny in zip(acts, Ws, one, many):
+        assert torch.equal(o, mny)
+        ref = act(act(e64 @ W0.astype(np.float64), a) * cst_of[a] @ W1.astype(np.float64), a) * cst_of[a]
+        err = np.abs(mny.cpu().numpy() - ref).max()
+        assert err < 3e-6 * max(1.0, np.abs(ref).max()), (a, err)     # fp32 rounding class (bf16 x6 products, hardware exp2 / rcp for silu)
+    with pytest.raises(RuntimeError, match='1 .. 8 layers'):
+        L.check(lib.snet_radial_mlp_hidden_fwd_layers((C.c_void_p * n)(*plans), 0, _p(emb), E, (C.c_void_p * n)(*[o.data_ptr() for o in many]), None))
+    if nb == 8 and n > 1:   # layers with different basis counts cannot share an edge embedding
+        other = C.c_void_p()
+        W0 = np.zeros((6, 64), np.float32)
+        L.check(lib.snet_radial_mlp_plan_create(6, 64, 64, 32, fp(W0), fp(Ws[0][1]), fp(np.zeros((64, 32), np.float32)), 0, cst_of[0], 1, C.byref(other)))
+        with pytest.raises(RuntimeError, match='same n_basis'):
+            L.check(lib.snet_radial_mlp_hidden_fwd_layers((C.c_void_p * 2)(plans[0], other), 2, _p(emb), E, (C.c_void_p * 2)(many[0].data_ptr(), many[1].data_ptr()), None))
+        lib.snet_radial_mlp_plan_destroy(other)
+    for p in plans:
+        lib.snet_radial_mlp_plan_destroy(p)
