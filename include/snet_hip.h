@@ -248,6 +248,10 @@ int snet_segment_sum_rows_chunked(const float *x, const int32_t *seg_ptr, const 
  * power of two derived from a BOUND of |g_w| -- (sum |C|) max|g_out[node]| max|x[src]| max|Y_e| -- so that no entry can
  * overflow fp16 whatever the model's feature magnitudes are; the two row maxima come from this kernel. */
 int snet_row_absmax(const float *x, int64_t n_rows, int32_t dim, float *out, void *stream);
+/* the same for n (1 .. 8) matrices x[j][n_rows[j], dims[j]] -> out[j] in one launch (both hosts: the source-row bounds of all
+ * interaction layers at the start of the reverse pass); matrices with n_rows[j] <= 0 are skipped */
+int snet_row_absmax_multi(const float *const *x, const int64_t *n_rows, const int32_t *dims, float *const *out, int32_t n,
+                          void *stream);
 /* out[r] = mult * ||x[r,:]||_2.  With mult = the largest row norm of a linear map's matrix this bounds every entry of
  * the map's output row (Cauchy-Schwarz): both hosts bound g_out = SI2^T g_y this way from the 5x narrower g_y instead
  * of reading g_out[N, dmid] once more (g_rowmax of snet_conv_bwd_fused may be ANY upper bound of max|g_out[node]|). */

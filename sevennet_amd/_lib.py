@@ -90,6 +90,7 @@ SIGNATURES = {
     'snet_segment_sum_rows_chunked': (C.c_int, [c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, c_i32p, c_f32p, c_stream]),
     'snet_edge_vectors': (C.c_int, [c_f64p, c_i32p, c_i32p, c_f64p, C.c_int64, c_f32p, c_stream]),
     'snet_row_absmax': (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, c_stream]),
+    'snet_row_absmax_multi': (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.c_int32, c_stream]),
     'snet_row_norm2': (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_float, c_f32p, c_stream]),
     'snet_conv_bwd_edge': (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_float,
                                      c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),

@@ -168,13 +168,29 @@ __device__ __forceinline__ void gemm_split_store(const snet::f32x16 (&acc)[MT][N
   if (rows.d == 1u && row_idx == nullptr && row0 + 32 * MT <= n_rows && 32 * (tile0 + NT) <= N) {
     float *base = C + (row0 + 4 * half) * c_node_stride + c_off + 32 * tile0 + li;
     if (accumulate) {
+      // read-modify-write in chunks of CH rows: ALL loads of a chunk are issued before its first store.  Written row by row
+      // (`crow[..] += acc`), every row's store had to wait for its own load and the next row's load came after that store --
+      // C may alias C -- i.e. 16 memory latencies in series per 32-row tile.
+      constexpr int CH = NT >= 4 ? 8 : 16;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          float *crow = base + (int64_t)(32 * mt + (j & 3) + 8 * (j >> 2)) * c_node_stride;
+        for (int j0 = 0; j0 < 16; j0 += CH) {
+          float old[CH][NT];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) crow[32 * t] += acc[mt][t][j];
+          for (int jj = 0; jj < CH; ++jj) {
+            const int j = j0 + jj;
+            const float *crow = base + (int64_t)(32 * mt + (j & 3) + 8 * (j >> 2)) * c_node_stride;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) old[jj][t] = crow[32 * t];
+          }
+#pragma unroll
+          for (int jj = 0; jj < CH; ++jj) {
+            const int j = j0 + jj;
+            float *crow = base + (int64_t)(32 * mt + (j & 3) + 8 * (j >> 2)) * c_node_stride;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) crow[32 * t] = old[jj][t] + acc[mt][t][j];
+          }
         }
     } else {
 #pragma unroll
@@ -188,25 +204,51 @@ __device__ __forceinline__ void gemm_split_store(const snet::f32x16 (&acc)[MT][N
     }
     return;
   }
+  auto row_of = [&](int mt, int j) -> float * {   // the lane's C row of accumulator entry (mt, j), nullptr past the end
+    const int off = 32 * mt + (j & 3) + 8 * (j >> 2) + 4 * half;
+    if (row0 + off >= n_rows) return nullptr;
+    int64_t n;
+    int m;
+    rows.at(off, n, m);
+    const int64_t node = row_idx ? (int64_t)row_idx[n] : n;
+    return C + node * c_node_stride + c_off + (int64_t)m * N;
+  };
+  if (accumulate) {   // chunks of 4 rows, loads before stores (see the fast path)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j0 = 0; j0 < 16; j0 += 4) {
+        float *crow[4];
+        float old[4][NT];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          crow[jj] = row_of(mt, j0 + jj);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int col = 32 * (tile0 + t) + li;
+            old[jj][t] = (crow[jj] != nullptr && col < N) ? crow[jj][col] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int col = 32 * (tile0 + t) + li;
+            if (crow[jj] != nullptr && col < N) crow[jj][col] = old[jj][t] + acc[mt][t][j0 + jj];
+          }
+      }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int off = 32 * mt + (j & 3) + 8 * (j >> 2) + 4 * half;
-      const int64_t r = row0 + off;
-      if (r >= n_rows) continue;
-      int64_t n;
-      int m;
-      rows.at(off, n, m);
-      const int64_t node = row_idx ? (int64_t)row_idx[n] : n;
-      float *crow = C + node * c_node_stride + c_off + (int64_t)m * N;
+      float *crow = row_of(mt, j);
+      if (crow == nullptr) continue;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = 32 * (tile0 + t) + li;
-        if (col < N) {
-          const float v = acc[mt][t][j];
-          crow[col] = accumulate ? crow[col] + v : v;
-        }
+        if (col < N) crow[col] = acc[mt][t][j];
       }
     }
 }
@@ -290,6 +332,9 @@ __device__ __forceinline__ void gemm_split_body(snet::u32x4 *Bs, int bx, int by,
     }
   };
 
+  // (accumulating launches add C in the epilogue, ONE rounding per entry.  Starting the accumulators from C instead hides the read
+  // -- node_linear_fwd 2.51 -> 2.33 ms -- but every matrix instruction then rounds at the magnitude of the row already there:
+  // measured, the energy error of the 10 648-atom cell went from 0.6e-4 to 1.1e-4 eV/atom, outside the fp32 class; not taken)
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)

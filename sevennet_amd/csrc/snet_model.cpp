@@ -673,6 +673,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   for (auto &L : m->layers) {
     dmax = dmax > (size_t)L.dout ? dmax : (size_t)L.dout;
     add((size_t)NT * L.dx); add(L.fused ? (size_t)WR * 64 : (size_t)WR * L.wn); add((size_t)N * L.gin);  // saved h, w | h2, y
+    add((size_t)NT + 64);  // x_max (kept through the reverse pass)
     const size_t t = ((size_t)N * L.gin + 64) * 2 + (size_t)N * L.dmid * 2 + (size_t)E * (L.fused ? 64 : L.wn) + (size_t)E * L.dx +
                      (size_t)NT * L.dx * 2 + (size_t)N * L.dout + (size_t)NT + (size_t)N + 4096;  // + x_max, g_max
     trans = trans > t ? trans : t;
@@ -882,13 +883,13 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     float *h = saved[t].h;
     if (t == 0) {  // species-only inputs: table lookups (ghost rows included)
       if (L.sc.present()) {
-        sc = A.f((size_t)N * L.gin);
+        sc = saved[t].y;
         if ((rc = snet_embed_rows(m->sc0_table, types, sc, N, L.gin, st))) return rc;
       }
       if ((rc = snet_embed_rows(m->h0_table, types, h, NT, L.dx, st))) return rc;
     } else {
       if (L.sc.present()) {
-        sc = A.f((size_t)N * L.gin);
+        sc = saved[t].y;
         if ((rc = run_linear(m, L.sc, x, sc, N, false, false, st))) return rc;
       }
       if ((rc = run_linear(m, L.si1, x, h, N, false, false, st))) return rc;
@@ -926,9 +927,9 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
       if ((rc = snet_conv_fwd(L.conv, h, sh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, N, L.conv_scale, mid, st)))
         return rc;
     }
-    float *y = saved[t].y;
-    if ((rc = run_linear(m, L.si2, mid, y, N, false, false, st))) return rc;
-    if ((rc = snet_gate_fwd(y, sc, x2, N, L.gin, L.dout, L.segs.data(), (int)L.segs.size(), st))) return rc;
+    float *y = saved[t].y;   // (sc == y when the layer has a self-connection: SI2 accumulates into its rows, as engine.py does)
+    if ((rc = run_linear(m, L.si2, mid, y, N, false, sc != nullptr, st))) return rc;
+    if ((rc = snet_gate_fwd(y, nullptr, x2, N, L.gin, L.dout, L.segs.data(), (int)L.segs.size(), st))) return rc;
     std::swap(x, x2);
   }
   A.off = mark;
@@ -970,6 +971,25 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
   SNET_REQUIRE(hipMemsetAsync(g_vec, 0, (size_t)E * 3 * 4, st) == hipSuccess &&
                    hipMemsetAsync(g_emb, 0, (size_t)E * nb * 4, st) == hipSuccess,
                "snet_model_eval: memset failed");
+  // fp16 operands of the fused reverse kernels: the source-row bounds of all layers from one launch (up to 8 matrices per call)
+  std::vector<float *> x_max_of((size_t)Lc, nullptr);
+  if (E > 0 && m->fused_terms == 4) {
+    const float *xs[8];
+    float *outs[8];
+    int64_t rows[8];
+    int32_t dims[8];
+    int nj = 0;
+    for (int t = 0; t <= Lc; ++t) {
+      if (t < Lc && m->layers[t].fused) {
+        x_max_of[t] = A.f((size_t)NT + 64);
+        xs[nj] = saved[t].h; outs[nj] = x_max_of[t]; rows[nj] = NT; dims[nj] = m->layers[t].dx; ++nj;
+      }
+      if (nj == 8 || (t == Lc && nj > 0)) {
+        if ((rc = snet_row_absmax_multi(xs, rows, dims, outs, nj, st))) return rc;
+        nj = 0;
+      }
+    }
+  }
   const size_t mark2 = A.off;
   for (int t = Lc - 1; t >= 0; --t) {
     Layer &L = m->layers[t];
@@ -987,11 +1007,7 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
     if (L.fused) {  // g_w is contracted with W2^T inside the kernel; with the hidden-layer tail not even g_h2 leaves it
       const bool tail = snet_fused_plan_has_mlp_tail(L.fused) != 0;
       float *g_h2 = tail ? nullptr : A.f((size_t)E * 64);
-      float *x_max = nullptr;
-      if (E > 0 && m->fused_terms == 4) {  // fp16 operands: bounds of every edge's g_w (see snet_row_absmax)
-        x_max = A.f((size_t)NT);
-        if ((rc = snet_row_absmax(saved[t].h, NT, L.dx, x_max, st))) return rc;
-      }
+      float *x_max = x_max_of[t];   // (bounds of every edge's g_w, see snet_row_absmax; computed before the layer loop)
       auto bwd_tiles = [&](const int32_t *tp, const int32_t *tn, int64_t nt) -> int {
         if (E <= 0 || nt <= 0) return 0;
         return snet_conv_bwd_fused(L.fused, saved[t].h, sh, dsh, saved[t].w, pairs ? w_row : nullptr, row_ptr, src, tp, tn, nt,
@@ -1043,9 +1059,11 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
             return rc;
           }
         if (!tail && (rc = snet_radial_mlp_hidden_bwd(L.mlp_plan, emb, g_h2, E, g_emb, st))) return rc;
-        if ((rc = run_linear(m, L.si1, g_h, gx_next, N, true, false, st))) return rc;
+        // g_x = sc^T g_y, then SI1^T g_h accumulated onto it -- in THIS order in every branch and in engine.py: an accumulating
+        // launch starts its accumulators from the rows already there, so the order is part of the result's last bits
         if (L.sc.present())
-          if ((rc = run_linear(m, L.sc, g_y, gx_next, N, true, true, st))) return rc;
+          if ((rc = run_linear(m, L.sc, g_y, gx_next, N, true, false, st))) return rc;
+        if ((rc = run_linear(m, L.si1, g_h, gx_next, N, true, L.sc.present(), st))) return rc;
         std::swap(g_x, gx_next);
         continue;
       }
@@ -1076,10 +1094,10 @@ extern "C" int snet_model_eval(snet_model *m, int64_t NT, int64_t N, int64_t E, 
         snet::set_error("snet_model_eval: reverse halo callback failed");
         return rc;
       }
-    // g_x (for the previous layer's gate output) = SI1^T g_h + sc^T g_y
-    if ((rc = run_linear(m, L.si1, g_h, gx_next, N, true, false, st))) return rc;
+    // g_x (for the previous layer's gate output) = sc^T g_y + SI1^T g_h (same order as above)
     if (L.sc.present())
-      if ((rc = run_linear(m, L.sc, g_y, gx_next, N, true, true, st))) return rc;
+      if ((rc = run_linear(m, L.sc, g_y, gx_next, N, true, false, st))) return rc;
+    if ((rc = run_linear(m, L.si1, g_h, gx_next, N, true, L.sc.present(), st))) return rc;
     std::swap(g_x, gx_next);
   }
   for (int b = 0; b < 2; ++b)

@@ -257,12 +257,8 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *__re
   }
 }
 
-// out[r] = max_k |x[r, k]|: one wavefront per row (16-byte loads when the rows allow it)
-__global__ void row_absmax_kernel(const float *__restrict__ x, int64_t n_rows, int dim, float *__restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (r >= n_rows) return;
-  const float *row = x + r * dim;
+// max_k |row[k]| over one wavefront (16-byte loads when the rows allow it); every lane returns the result
+__device__ __forceinline__ float row_absmax_wave(const float *__restrict__ row, int dim, int lane) {
   float m = 0.f;
   if ((dim & 3) == 0) {
     for (int k = 4 * lane; k < dim; k += 256) {
@@ -273,7 +269,38 @@ __global__ void row_absmax_kernel(const float *__restrict__ x, int64_t n_rows, i
     for (int k = lane; k < dim; k += 64) m = fmaxf(m, fabsf(row[k]));
   }
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return m;
+}
+
+// out[r] = max_k |x[r, k]|: one wavefront per row
+__global__ void row_absmax_kernel(const float *__restrict__ x, int64_t n_rows, int dim, float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const float m = row_absmax_wave(x + r * dim, dim, lane);
   if (lane == 0) out[r] = m;
+}
+
+// the same for up to 8 matrices in one launch (the source-row bounds of every interaction layer at the start of the reverse
+// pass: five launches of a 50-us kernel, latency-bound at brick sizes): workgroups [blk0[j], blk0[j+1]) take matrix j
+constexpr int MAX_ABSMAX_JOBS = 8;
+struct AbsmaxJobs {
+  const float *x[MAX_ABSMAX_JOBS];
+  float *out[MAX_ABSMAX_JOBS];
+  long long rows[MAX_ABSMAX_JOBS];
+  long long blk0[MAX_ABSMAX_JOBS + 1];
+  int dim[MAX_ABSMAX_JOBS];
+  int n;
+};
+__global__ void row_absmax_multi_kernel(AbsmaxJobs J) {
+  const int lane = threadIdx.x & 63;
+  int j = 0;
+  while (j + 1 < J.n && (long long)blockIdx.x >= J.blk0[j + 1]) ++j;
+  const int64_t r = ((int64_t)blockIdx.x - J.blk0[j]) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (r >= J.rows[j]) return;
+  const int dim = J.dim[j];
+  const float m = row_absmax_wave(J.x[j] + r * dim, dim, lane);
+  if (lane == 0) J.out[j][r] = m;
 }
 
 // out[r] = mult * ||x[r, :]||_2 (fp32 sum of squares: a bound needs no more)
@@ -548,6 +575,29 @@ extern "C" int snet_row_absmax(const float *x, int64_t n_rows, int32_t dim, floa
   SNET_REQUIRE(x != nullptr && out != nullptr, "snet_row_absmax: null argument");
   row_absmax_kernel<<<(unsigned)((n_rows + 3) / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(x, n_rows, dim, out);
   SNET_CHECK_LAUNCH("snet_row_absmax");
+  return 0;
+}
+extern "C" int snet_row_absmax_multi(const float *const *x, const int64_t *n_rows, const int32_t *dims, float *const *out, int32_t n,
+                                     void *stream) {
+  SNET_REQUIRE(n >= 1 && n <= MAX_ABSMAX_JOBS, "snet_row_absmax_multi: 1 .. 8 matrices per call");
+  SNET_REQUIRE(x != nullptr && n_rows != nullptr && dims != nullptr && out != nullptr, "snet_row_absmax_multi: null argument");
+  AbsmaxJobs J{};
+  long long blocks = 0;
+  int k = 0;
+  for (int j = 0; j < n; ++j) {
+    SNET_REQUIRE(dims[j] >= 1 && n_rows[j] < (1ll << 33), "snet_row_absmax_multi: bad shape");
+    if (n_rows[j] <= 0) continue;
+    SNET_REQUIRE(x[j] != nullptr && out[j] != nullptr, "snet_row_absmax_multi: null matrix");
+    J.x[k] = x[j]; J.out[k] = out[j]; J.rows[k] = n_rows[j]; J.dim[k] = dims[j]; J.blk0[k] = blocks;
+    blocks += (n_rows[j] + 3) / 4;
+    ++k;
+  }
+  if (k == 0) return 0;
+  J.blk0[k] = blocks;
+  J.n = k;
+  SNET_REQUIRE(blocks < (1ll << 31), "snet_row_absmax_multi: too many rows");
+  row_absmax_multi_kernel<<<(unsigned)blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(J);
+  SNET_CHECK_LAUNCH("snet_row_absmax_multi");
   return 0;
 }
 extern "C" int snet_segment_sum_rows_chunked(const float *x, const int32_t *seg_ptr, const int32_t *perm, int64_t n_seg,

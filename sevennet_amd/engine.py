@@ -343,6 +343,7 @@ class HipForceEngine:
         self.overlap = bool(overlap)
         self.halo_split = True   # False: exchange, then the whole convolution (A/B measurements of the overlap)
         self._side = None  # second stream, created on first use
+        self._acc_descs = {}  # id(descriptor array) -> its all-accumulating copy (the arrays live as long as the engine)
         self.events = None  # set to [] to collect (name, start, end) HIP events per kernel class
         self.event_filter = None  # optional set of class names: only those spans are recorded
         self.lib = _lib.load()
@@ -531,19 +532,23 @@ class HipForceEngine:
                 m = rows.numel()
                 if m == 0:
                     continue
-            if force_acc:
-                arr2 = (_lib.GemmDesc * cnt)(*[_lib.GemmDesc(d.B, d.B_split, d.a_off, d.c_off, d.d, d.K, d.N, 1) for d in arr[:cnt]])
+            if force_acc:   # the same launches with every descriptor accumulating (built once per descriptor array)
+                arr2 = self._acc_descs.get(id(arr))
+                if arr2 is None:
+                    arr2 = (_lib.GemmDesc * cnt)(*[_lib.GemmDesc(d.B, d.B_split, d.a_off, d.c_off, d.d, d.K, d.N, 1) for d in arr[:cnt]])
+                    self._acc_descs[id(arr)] = arr2
                 arr = arr2
             _lib.check(self.lib.snet_gemm_grouped(arr, cnt, _ptr(A), _ptr(Cm), m, a_stride, c_stride, _ptr(rows),
                                                   _stream()), 'snet_gemm_grouped')
 
-    def _linear(self, lin: _Linear, x, n, g: Graph, out=None):
-        """y[:n] = Linear(x[:n]) on ir_mul rows."""
+    def _linear(self, lin: _Linear, x, n, g: Graph, out=None, accumulate=False):
+        """y[:n] (+)= Linear(x[:n]) on ir_mul rows."""
         sp = lin.spec
         y = self._new(max(n, 0), sp.dim_out) if out is None else out
-        for off, ln in sp.zero_out:
-            y[:, off:off + ln].zero_()
-        self._run_groups(lin.groups_fwd, x, y, n, sp.dim_in, sp.dim_out, g)
+        if not accumulate:
+            for off, ln in sp.zero_out:
+                y[:, off:off + ln].zero_()
+        self._run_groups(lin.groups_fwd, x, y, n, sp.dim_in, sp.dim_out, g, force_acc=accumulate)
         if lin.bias is not None and n > 0:
             _lib.check(self.lib.snet_add_row_bias(_ptr(y), _ptr(lin.bias), n, sp.dim_out, _stream()), 'snet_add_row_bias')
         return y
@@ -751,10 +756,11 @@ class HipForceEngine:
                 if L.fused_bwd:
                     w = None  # the reverse pass rebuilds its weight tiles from h2
                 with _Span(self, 'node_linear_fwd'):
-                    y = self._linear(L.si2, m, N, g)
+                    # y = SI2(m) + self-connection: the linear map ACCUMULATES into the self-connection's rows (the gate kernel used to
+                    # add them: one read of sc and one write of y per node and layer more); y is kept for the reverse pass
+                    y = self._linear(L.si2, m, N, g) if sc is None else self._linear(L.si2, m, N, g, out=sc, accumulate=True)
                 xo = self._new(N, ls.gate.irreps_out.dim)
-                # y += self-connection happens inside the gate kernel (in place: y is kept for the reverse pass)
-                _lib.check(lib.snet_gate_fwd(_ptr(y), _ptr(sc), _ptr(xo), N, ls.gate.irreps_in.dim,
+                _lib.check(lib.snet_gate_fwd(_ptr(y), None, _ptr(xo), N, ls.gate.irreps_in.dim,
                                              ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st), 'snet_gate_fwd')
                 saved.append((h, w, zs, y, h2))
                 if keep:
@@ -810,6 +816,22 @@ class HipForceEngine:
             sh_T = None   # spherical harmonics in source-grouped edge order (transposed scalar convolution)
             g_vec = torch.zeros(E, 3, dtype=torch.float32, device=self.dev)  # spherical part, all layers
             g_emb = torch.zeros(E, nb, dtype=torch.float32, device=self.dev)
+            # fp16 operands of the fused reverse kernels: row maxima of the source rows and of the incoming gradient bound every
+            # edge's g_w, from which the kernel derives that edge's power-of-two scale (no overflow possible).  The source-row
+            # bounds of ALL layers come from one launch here (the rows have been complete since the forward pass).
+            x_max_of = {}
+            if self.fused_terms == 4 and E > 0:
+                ts = [t_ for t_, L_ in enumerate(self.layers) if L_.fused_bwd]
+                for t_ in ts:
+                    x_max_of[t_] = self._new(NT)
+                with _Span(self, 'row_bounds'):
+                    for i in range(0, len(ts), 8):
+                        grp = ts[i:i + 8]
+                        k = len(grp)
+                        _lib.check(lib.snet_row_absmax_multi((C.c_void_p * k)(*[saved[t_][0].data_ptr() for t_ in grp]), (C.c_int64 * k)(*[NT] * k),
+                                                             (C.c_int32 * k)(*[self.layers[t_].spec.si1.dim_out for t_ in grp]),
+                                                             (C.c_void_p * k)(*[x_max_of[t_].data_ptr() for t_ in grp]), k, st),
+                                   'snet_row_absmax_multi')
             for t in range(len(self.layers) - 1, -1, -1):
                 L = self.layers[t]
                 ls = L.spec
@@ -861,13 +883,7 @@ class HipForceEngine:
 
                 if L.fused_bwd:
                     g_h2 = None if L.mlp_tail else self._new(E, 64)
-                    x_max = None
-                    if self.fused_terms == 4 and E > 0:
-                        # fp16 operands: row maxima of the source rows and of the incoming gradient bound every edge's
-                        # g_w, from which the kernel derives that edge's power-of-two scale (no overflow possible)
-                        x_max = self._new(NT)
-                        with _Span(self, 'row_bounds'):
-                            _lib.check(lib.snet_row_absmax(_ptr(h), NT, ls.si1.dim_out, _ptr(x_max), st), 'snet_row_absmax')
+                    x_max = x_max_of.pop(t, None)   # (computed before the layer loop)
 
                     def bwd_tiles(tp_, tn_, nt_):
                         if nt_ <= 0:

@@ -1049,3 +1049,24 @@ def test_radial_mlp_hidden_layers_one_launch(nb, acts, E):
         lib.snet_radial_mlp_plan_destroy(other)
     for p in plans:
         lib.snet_radial_mlp_plan_destroy(p)
+
+
+@pytest.mark.gpu
+def test_row_absmax_multi_equals_per_matrix_calls():
+    """snet_row_absmax_multi: row maxima of several matrices of different shapes from one launch (ragged row counts, a row
+    length that is not a multiple of 4, an empty matrix in the middle) == torch, exactly (a maximum has no rounding)."""
+    L, lib = _lib()
+    dev = 'cuda:0'
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1001, 480), (3, 128), (0, 64), (517, 30), (64, 1152)]
+    xs = [torch.randn(r, d, generator=g).to(dev) * (10.0 ** (i - 2)) for i, (r, d) in enumerate(shapes)]
+    outs = [torch.full((r,), float('nan'), device=dev) for r, _ in shapes]
+    n = len(shapes)
+    L.check(lib.snet_row_absmax_multi((C.c_void_p * n)(*[x.data_ptr() if x.numel() else None for x in xs]), (C.c_int64 * n)(*[r for r, _ in shapes]),
+                                      (C.c_int32 * n)(*[d for _, d in shapes]), (C.c_void_p * n)(*[o.data_ptr() if o.numel() else None for o in outs]), n, None))
+    torch.cuda.synchronize()
+    for x, o in zip(xs, outs):
+        if x.numel():
+            assert torch.equal(o, x.abs().amax(1))
+    with pytest.raises(RuntimeError, match='1 .. 8 matrices'):
+        L.check(lib.snet_row_absmax_multi((C.c_void_p * n)(), (C.c_int64 * n)(), (C.c_int32 * n)(), (C.c_void_p * n)(), 9, None))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # hidden radial layers in one launch: parity subset, bench line, brick proxy
-timeout 1500 python -m pytest tests -x -q -m gpu -k "hidden or fused or engine or native or md_host or plugin or bricks or interior" > gpurun_out/tests_b.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/tests_b.log
+timeout 1500 python -m pytest tests -x -q -m gpu  > gpurun_out/tests_b.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/tests_b.log
 for rep in 1 2; do
 timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "
 import json,sys
