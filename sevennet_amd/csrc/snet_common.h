@@ -244,9 +244,38 @@ __device__ __forceinline__ void act_both_fast(float z, int act, float &f, float 
 }
 // activation value alone, same hardware exp2 / rcp form for silu (the hidden radial layers evaluate 128 of these per row: with
 // libm exp and the IEEE division their kernel was bound by exactly that, 0.19 ms per launch); every other id: act_fwd
+__device__ __forceinline__ float sigmoid_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z)); }
 __device__ __forceinline__ float act_fwd_fast(float z, int act) {
-  if (act == 0) return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+  if (act == 0) return z * sigmoid_fast(z);
   return act_fwd(z, act);
+}
+// The gate kernels' forms (round 6): silu (0) and sigmoid (5) -- the scalar and gate activations of every SevenNet preset
+// (sevenn/_const.py:33-47 defaults) -- on hardware exp2 / rcp, every other id through libm.  The id differs per LANE there (a lane
+// owns four channels of one segment), so the libm branch is entered only by waves that hold such a segment.  With libm exp and the
+// IEEE division for all ids the reverse gate kernel was bound by vector issue: 3 408 static instructions, 0.145 ms against 0.08 ms of
+// memory traffic.
+__device__ __forceinline__ float act_fwd_gate(float z, int act) {
+  if (act == 0) return z * sigmoid_fast(z);
+  if (act == 5) return sigmoid_fast(z);
+  return act_fwd(z, act);
+}
+__device__ __forceinline__ float act_grad_gate(float z, int act) {
+  if (act == 0 || act == 5) {
+    const float s = sigmoid_fast(z);
+    return act == 0 ? s * fmaf(z, 1.0f - s, 1.0f) : s * (1.0f - s);
+  }
+  return act_grad(z, act);
+}
+// value f and derivative g of the same pre-activation (one exponential for silu / sigmoid)
+__device__ __forceinline__ void act_pair_gate(float z, int act, float &f, float &g) {
+  if (act == 0 || act == 5) {
+    const float s = sigmoid_fast(z);
+    f = act == 0 ? z * s : s;
+    g = act == 0 ? s * fmaf(z, 1.0f - s, 1.0f) : s * (1.0f - s);
+  } else {
+    f = act_fwd(z, act);
+    g = act_grad(z, act);
+  }
 }
 
 }  // namespace snet

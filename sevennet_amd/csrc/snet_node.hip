@@ -33,11 +33,11 @@ __global__ __launch_bounds__(1024) void gate_fwd_kernel(GateTable T, float *__re
   if (sg.kind == 0) {
     float v = yr[sg.in_off + u];
     if (ar) { v += ar[sg.in_off + u]; yr[sg.in_off + u] = v; }
-    orow[sg.out_off + u] = snet::act_fwd(v, sg.act) * sg.cst;
+    orow[sg.out_off + u] = snet::act_fwd_gate(v, sg.act) * sg.cst;
   } else {
     float z = yr[sg.gate_off + u];
     if (ar) { z += ar[sg.gate_off + u]; yr[sg.gate_off + u] = z; }
-    const float g = snet::act_fwd(z, sg.act) * sg.cst;
+    const float g = snet::act_fwd_gate(z, sg.act) * sg.cst;
     const int d = 2 * sg.l + 1;
     for (int m = 0; m < d; ++m) {
       const int k = sg.in_off + m * sg.mul + u;
@@ -63,10 +63,10 @@ __global__ __launch_bounds__(1024) void gate_bwd_kernel(GateTable T, const float
   const float *gor = g_out + node * dim_out;
   float *gyr = g_y + node * dim_in;
   if (sg.kind == 0) {
-    gyr[sg.in_off + u] = gor[sg.out_off + u] * sg.cst * snet::act_grad(yr[sg.in_off + u], sg.act);
+    gyr[sg.in_off + u] = gor[sg.out_off + u] * sg.cst * snet::act_grad_gate(yr[sg.in_off + u], sg.act);
   } else {
     const float z = yr[sg.gate_off + u];
-    const float g = snet::act_fwd(z, sg.act) * sg.cst;
+    const float g = snet::act_fwd_gate(z, sg.act) * sg.cst;
     const int d = 2 * sg.l + 1;
     float acc = 0.f;
     for (int m = 0; m < d; ++m) {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(1024) void gate_bwd_kernel(GateTable T, const float
       acc += go * yr[sg.in_off + m * sg.mul + u];
       gyr[sg.in_off + m * sg.mul + u] = go * g;
     }
-    gyr[sg.gate_off + u] = acc * sg.cst * snet::act_grad(z, sg.act);
+    gyr[sg.gate_off + u] = acc * sg.cst * snet::act_grad_gate(z, sg.act);
   }
 }
 
@@ -112,14 +112,14 @@ __global__ __launch_bounds__(256) void gate_fwd_vec_kernel(GateTable T, float *_
       if (ar) { v += ld4(ar + sg.in_off + u); st4(yr + sg.in_off + u, v); }
       f4 o;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = snet::act_fwd(v[i], sg.act) * sg.cst;
+      for (int i = 0; i < 4; ++i) o[i] = snet::act_fwd_gate(v[i], sg.act) * sg.cst;
       st4(orow + sg.out_off + u, o);
     } else {
       f4 z = ld4(yr + sg.gate_off + u);
       if (ar) { z += ld4(ar + sg.gate_off + u); st4(yr + sg.gate_off + u, z); }
       f4 g;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g[i] = snet::act_fwd(z[i], sg.act) * sg.cst;
+      for (int i = 0; i < 4; ++i) g[i] = snet::act_fwd_gate(z[i], sg.act) * sg.cst;
       const int d = 2 * sg.l + 1;
       for (int m = 0; m < d; ++m) {
         const int k = sg.in_off + m * sg.mul + u;
@@ -154,13 +154,18 @@ __global__ __launch_bounds__(256) void gate_bwd_vec_kernel(GateTable T, const fl
       const f4 go = ld4(gor + sg.out_off + u), yv = ld4(yr + sg.in_off + u);
       f4 r;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) r[i] = go[i] * sg.cst * snet::act_grad(yv[i], sg.act);
+      for (int i = 0; i < 4; ++i) r[i] = go[i] * sg.cst * snet::act_grad_gate(yv[i], sg.act);
       put(sg.in_off + u, r);
     } else {
       const f4 z = ld4(yr + sg.gate_off + u);
-      f4 g, acc = {0.f, 0.f, 0.f, 0.f};
+      f4 g, dg, acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g[i] = snet::act_fwd(z[i], sg.act) * sg.cst;
+      for (int i = 0; i < 4; ++i) {
+        float f_, g_;
+        snet::act_pair_gate(z[i], sg.act, f_, g_);
+        g[i] = f_ * sg.cst;
+        dg[i] = g_;
+      }
       const int d = 2 * sg.l + 1;
       for (int m = 0; m < d; ++m) {
         const f4 go = ld4(gor + sg.out_off + m * sg.mul + u);
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256) void gate_bwd_vec_kernel(GateTable T, const fl
       }
       f4 r;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) r[i] = acc[i] * sg.cst * snet::act_grad(z[i], sg.act);
+      for (int i = 0; i < 4; ++i) r[i] = acc[i] * sg.cst * dg[i];
       put(sg.gate_off + u, r);
     }
   }

@@ -760,8 +760,9 @@ class HipForceEngine:
                     # add them: one read of sc and one write of y per node and layer more); y is kept for the reverse pass
                     y = self._linear(L.si2, m, N, g) if sc is None else self._linear(L.si2, m, N, g, out=sc, accumulate=True)
                 xo = self._new(N, ls.gate.irreps_out.dim)
-                _lib.check(lib.snet_gate_fwd(_ptr(y), None, _ptr(xo), N, ls.gate.irreps_in.dim,
-                                             ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st), 'snet_gate_fwd')
+                with _Span(self, 'gate_fwd'):
+                    _lib.check(lib.snet_gate_fwd(_ptr(y), None, _ptr(xo), N, ls.gate.irreps_in.dim,
+                                                 ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st), 'snet_gate_fwd')
                 saved.append((h, w, zs, y, h2))
                 if keep:
                     inter[f'{t}_si1'], inter[f'{t}_conv'], inter[f'{t}_gate_in'], inter[f'{t}_x'] = h[:N], m, y, xo
@@ -840,9 +841,10 @@ class HipForceEngine:
                 # fp16 operands of the fused reverse kernel: row bound of g_m = SI2^T g_y through the narrower g_y and SI2's
                 # largest row norm (Cauchy-Schwarz), taken while the gate's reverse pass has the row in registers
                 g_max = self._new(N) if (L.fused_bwd and self.fused_terms == 4 and E > 0) else None
-                _lib.check(lib.snet_gate_bwd_norm(_ptr(y), _ptr(g_x), _ptr(g_y), N, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim,
-                                                  L.gate_segs, len(ls.gate.segs), L.si2.t_norm if g_max is not None else 0.0,
-                                                  _ptr(g_max), st), 'snet_gate_bwd_norm')
+                with _Span(self, 'gate_bwd'):
+                    _lib.check(lib.snet_gate_bwd_norm(_ptr(y), _ptr(g_x), _ptr(g_y), N, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim,
+                                                      L.gate_segs, len(ls.gate.segs), L.si2.t_norm if g_max is not None else 0.0,
+                                                      _ptr(g_max), st), 'snet_gate_bwd_norm')
                 with _Span(self, 'node_linear_bwd'):
                     g_m = self._linear_T(L.si2, g_y, N, g)
                 # layer 0: inputs depend on species only -> no source-row gradient needed

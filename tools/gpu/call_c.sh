@@ -5,7 +5,7 @@ for rep in 1 2; do
 timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_step']
-print('tree', round(d['ms_per_step'],3), ' '.join(f'{x}:{k[x]:.3f}' for x in ('radial_mlp_hidden_fwd','node_linear_fwd','node_linear_bwd','conv_fwd_fused[22d6a77ad5ac]','conv_bwd_fused[22d6a77ad5ac]') if x in k), 'kernels', d['config']['kernel_ms_per_step_rank0'], 'disp', d['config']['dispatches_per_step_rank0'])"
+print('tree', round(d['ms_per_step'],3), ' '.join(f'{x}:{k[x]:.3f}' for x in ('radial_mlp_hidden_fwd','node_linear_fwd','node_linear_bwd','gate_fwd','gate_bwd','row_bounds','conv_fwd_fused[22d6a77ad5ac]','conv_bwd_fused[22d6a77ad5ac]') if x in k), 'kernels', d['config']['kernel_ms_per_step_rank0'], 'disp', d['config']['dispatches_per_step_rank0'])"
 done
 timeout 300 python bench.py --no-cpu-baseline --steps 10 --warmup 3 --brick-proxy 8 2>/dev/null | python -c "
 import json,sys
