@@ -100,6 +100,12 @@ class Sampler:
             root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
             self._proc = subprocess.Popen([sys.executable, '-m', 'sevennet_amd.telemetry', '--watch', str(self.period), '--dev', str(self.dev)],
                                           cwd=root, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            import select
+            r, _, _ = select.select([self._proc.stdout], [], [], 20.0)   # a child stuck in rsmi_init must not hang the measurement
+            if not r:
+                self._proc.kill()
+                self._proc = None
+                return self
             first = self._proc.stdout.readline()          # 'ready' once the library is initialised (or 'unavailable')
             self._ok = first.strip() == 'ready'
         except Exception:  # noqa: BLE001
