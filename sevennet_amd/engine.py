@@ -617,378 +617,419 @@ class HipForceEngine:
         if self.needs_species_rows and g.species_rows is None:
             raise ValueError('graph was built without num_species but the model has a per-species self-connection')
         with torch.cuda.device(self.dev):
-            st = _stream()
-            N, NT, E = g.n_local, g.n_total, g.n_edges
-            nb, nsh = sp.n_basis, self.nsh
-            inter = {}
-            emb, sh, dsh = self._new(E, nb), self._new(E, nsh), self._new(E, nsh * 3)
-            with _Span(self, 'edge_embed_fwd'):
-                _lib.check(lib.snet_edge_embed_fwd(C.byref(self.edge_params), self.coeffs, _ptr(g.edge_vec), E,
-                                                   _ptr(emb), _ptr(sh), _ptr(dsh), st), 'snet_edge_embed_fwd')
-            # radial weights once per undirected pair (fused-MLP layers only: the unfused fallback keeps
-            # its per-edge hidden activations for the reverse pass)
-            pairs = g.w_row is not None and all(L.fused_mlp for L in self.layers)
-            w_row = g.w_row if pairs else None
-            if pairs:
-                emb_p = self._new(g.n_pairs, nb)
-                _lib.check(lib.snet_gather_rows(_ptr(emb), _ptr(g.pair_edge), _ptr(emb_p), g.n_pairs, nb, st),
-                           'snet_gather_rows')
-            # second stream: every layer's radial weights depend on the edge embedding only, so they are all
-            # enqueued now and the main stream waits for layer t's event right before its tensor product
-            side = None
-            w_ready = {}
-            any_fused = any(L.fused_fwd or L.fused_bwd for L in self.layers)
-            if E > 0:   # work lists of the fused reverse kernels (the topology's only device sync: built once per Graph)
-                for L in self.layers:
-                    if L.fused_bwd:
-                        g.tiles(L.tile_mode)
-            if self.overlap and E <= self.OVERLAP_MAX_EDGES and not any_fused and all(L.fused_mlp for L in self.layers):
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=self.dev)
-                side = self._side
-                main = torch.cuda.current_stream()
-                # every buffer the side stream touches is allocated on the MAIN stream and stays referenced until
-                # the main stream has waited for the side stream again: no record_stream, hence no deferred frees
-                # (with 10-GB blocks those made the caching allocator fall back to hipMalloc / hipFree)
-                rows_w = g.n_pairs if pairs else E
-                w_bufs = [self._new(rows_w, L_.spec.conv.weight_numel) for L_ in self.layers]
-                wn_max = max(L_.spec.conv.weight_numel for L_ in self.layers)
-                gw_bufs = [self._new(E * wn_max), self._new(E * wn_max)]
-                gw_done = [None, None]
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    for t_, L_ in enumerate(self.layers):
-                        with _Span(self, f'radial_mlp_fwd[wn={L_.spec.conv.weight_numel}]@side'):
-                            self._mlp_fwd(L_, emb_p if pairs else emb, rows_w, out=w_bufs[t_])
-                        ev = torch.cuda.Event()
-                        ev.record(side)
-                        w_ready[t_] = (w_bufs[t_], ev)
-            d0 = sp.embed.dim_out
-            x = None
-            if keep or self.h0_table is None:
-                x = self._new(NT, d0)  # ghost layer-0 features depend only on species (model_build.py:383-421)
-                _lib.check(lib.snet_embed_rows(_ptr(self.embed_table), _ptr(g.types), _ptr(x), NT, d0, st),
-                           'snet_embed_rows')
+            c = self._begin(g, halo, keep)            # edge embedding, radial-weight streams, hidden radial layers
+            x = self._forward_layers(c)                # interaction layers; what the reverse pass needs goes to c.saved
+            e_atom, energy, g_x = self._readout(c, x)  # atomic energies, their sum, dE/dx of the last layer's output
+            g_vec = self._reverse_layers(c, g_x)       # dE/d(edge vector), spherical and radial parts
+            return self._forces(c, g_vec, e_atom, energy, want_atomic_virial)
+
+    def _begin(self, g: Graph, halo, keep: bool):
+        """first phase of compute: edge embedding, one radial row per undirected pair, the side stream's radial weights (unfused
+        layers), the hidden radial layers of all fused layers; returns the evaluation's shared state"""
+        from types import SimpleNamespace
+        lib, sp = self.lib, self.spec
+        st = _stream()
+        N, NT, E = g.n_local, g.n_total, g.n_edges
+        nb, nsh = sp.n_basis, self.nsh
+        inter = {}
+        emb, sh, dsh = self._new(E, nb), self._new(E, nsh), self._new(E, nsh * 3)
+        with _Span(self, 'edge_embed_fwd'):
+            _lib.check(lib.snet_edge_embed_fwd(C.byref(self.edge_params), self.coeffs, _ptr(g.edge_vec), E,
+                                               _ptr(emb), _ptr(sh), _ptr(dsh), st), 'snet_edge_embed_fwd')
+        # radial weights once per undirected pair (fused-MLP layers only: the unfused fallback keeps
+        # its per-edge hidden activations for the reverse pass)
+        pairs = g.w_row is not None and all(L.fused_mlp for L in self.layers)
+        w_row = g.w_row if pairs else None
+        if pairs:
+            emb_p = self._new(g.n_pairs, nb)
+            _lib.check(lib.snet_gather_rows(_ptr(emb), _ptr(g.pair_edge), _ptr(emb_p), g.n_pairs, nb, st),
+                       'snet_gather_rows')
+        # second stream: every layer's radial weights depend on the edge embedding only, so they are all
+        # enqueued now and the main stream waits for layer t's event right before its tensor product
+        side = None
+        w_ready = {}
+        any_fused = any(L.fused_fwd or L.fused_bwd for L in self.layers)
+        if E > 0:   # work lists of the fused reverse kernels (the topology's only device sync: built once per Graph)
+            for L in self.layers:
+                if L.fused_bwd:
+                    g.tiles(L.tile_mode)
+        if self.overlap and E <= self.OVERLAP_MAX_EDGES and not any_fused and all(L.fused_mlp for L in self.layers):
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.dev)
+            side = self._side
+            main = torch.cuda.current_stream()
+            # every buffer the side stream touches is allocated on the MAIN stream and stays referenced until
+            # the main stream has waited for the side stream again: no record_stream, hence no deferred frees
+            # (with 10-GB blocks those made the caching allocator fall back to hipMalloc / hipFree)
+            rows_w = g.n_pairs if pairs else E
+            w_bufs = [self._new(rows_w, L_.spec.conv.weight_numel) for L_ in self.layers]
+            wn_max = max(L_.spec.conv.weight_numel for L_ in self.layers)
+            gw_bufs = [self._new(E * wn_max), self._new(E * wn_max)]
+            gw_done = [None, None]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for t_, L_ in enumerate(self.layers):
+                    with _Span(self, f'radial_mlp_fwd[wn={L_.spec.conv.weight_numel}]@side'):
+                        self._mlp_fwd(L_, emb_p if pairs else emb, rows_w, out=w_bufs[t_])
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    w_ready[t_] = (w_bufs[t_], ev)
+        d0 = sp.embed.dim_out
+        x = None
+        if keep or self.h0_table is None:
+            x = self._new(NT, d0)  # ghost layer-0 features depend only on species (model_build.py:383-421)
+            _lib.check(lib.snet_embed_rows(_ptr(self.embed_table), _ptr(g.types), _ptr(x), NT, d0, st),
+                       'snet_embed_rows')
+        if keep:
+            inter['edge_embedding'], inter['edge_attr'], inter['x_embed'] = emb, sh, x[:N]
+        saved = []
+        # interior / boundary split of the convolutions around the ghost exchange: needs the brick's interior-first row
+        # numbering, a halo with the split protocol, and edges (the reverse side walks a tile list)
+        split = bool(halo is not None and g.n_interior and hasattr(halo, 'forward_start') and hasattr(halo, 'reverse_start')
+                     and E > 0 and self.halo_split)
+        # hidden activations of every layer's radial MLP, one row per pair, in ONE launch: the layers share the edge embedding
+        # (five launches of a latency-bound kernel at brick sizes; the rows are kept for the reverse pass anyway)
+        h2_rows = g.n_pairs if pairs else E
+        h2_of = {t_: self._new(h2_rows, 64) for t_, L_ in enumerate(self.layers) if L_.fused_fwd or L_.fused_bwd}
+        with _Span(self, 'radial_mlp_hidden_fwd'):
+            ts = sorted(h2_of)
+            for i in range(0, len(ts), 8):
+                grp = ts[i:i + 8]
+                plans = (C.c_void_p * len(grp))(*[self.layers[t_].mlp_plan for t_ in grp])
+                outs = (C.c_void_p * len(grp))(*[h2_of[t_].data_ptr() for t_ in grp])
+                _lib.check(lib.snet_radial_mlp_hidden_fwd_layers(plans, len(grp), _ptr(emb_p if pairs else emb), h2_rows, outs, st),
+                           'snet_radial_mlp_hidden_fwd_layers')
+        return SimpleNamespace(g=g, halo=halo, keep=keep, st=st, N=N, NT=NT, E=E, nb=nb, nsh=nsh, inter=inter, emb=emb, sh=sh, dsh=dsh,
+                               pairs=pairs, w_row=w_row, emb_p=emb_p if pairs else None, side=side, w_ready=w_ready,
+                               gw_bufs=gw_bufs if side is not None else None, gw_done=gw_done if side is not None else None,
+                               x=x, saved=saved, split=split, h2_of=h2_of)
+
+    def _forward_layers(self, c):
+        """the interaction layers (interaction_blocks.py:41-76): SI1, ghost exchange, self-connection, convolution, SI2, gate"""
+        lib, g, halo, keep, st, inter = self.lib, c.g, c.halo, c.keep, c.st, c.inter
+        N, NT, E = c.N, c.NT, c.E
+        emb, sh, pairs, emb_p, w_row, side, w_ready = c.emb, c.sh, c.pairs, c.emb_p, c.w_row, c.side, c.w_ready
+        x, saved, split, h2_of = c.x, c.saved, c.split, c.h2_of
+        for t, L in enumerate(self.layers):
+            ls = L.spec
+            n_in = NT if t == 0 else N  # rows of x that are valid
+            with _Span(self, 'node_linear_fwd'):
+                h = self._new(NT, ls.si1.dim_out)
+                if t == 0 and self.h0_table is not None:   # species-only rows: fp64-evaluated table lookup
+                    _lib.check(lib.snet_embed_rows(_ptr(self.h0_table), _ptr(g.types), _ptr(h), NT, ls.si1.dim_out, st),
+                               'snet_embed_rows')
+                else:
+                    self._linear(L.si1, x, n_in, g, out=h)
+            # ghost rows of h travel while the self-connection and the radial MLP (which do not read
+            # them) run: hosts with a split exchange overlap the transfer with that work
+            pending = None
+            if t > 0 and halo is not None:
+                with _Span(self, 'halo_fwd'):
+                    if hasattr(halo, 'forward_start'):
+                        pending = halo.forward_start(h, N)
+                    else:
+                        halo.forward(h, N)
+            with _Span(self, 'node_linear_fwd'):
+                if t == 0 and self.h0_table is not None:
+                    sc = None
+                    if self.sc0_table is not None:
+                        sc = self._new(N, ls.gate.irreps_in.dim)
+                        _lib.check(lib.snet_embed_rows(_ptr(self.sc0_table), _ptr(g.types), _ptr(sc), N, ls.gate.irreps_in.dim,
+                                                       st), 'snet_embed_rows')
+                else:
+                    sc = self._linear(L.sc, x, N, g) if L.sc is not None else None
+            dmid = ls.conv.irreps_out.dim
+            m = self._new(N, dmid)
+            if E == 0:
+                m.zero_()
+            else:   # columns of pruned (unread) paths are never written by the tensor-product kernel: defined zeros
+                for off, ln in L.si2.zero_in:
+                    m[:, off:off + ln].zero_()
+            h2 = w = zs = None
+            rows_w = g.n_pairs if pairs else E
+            h2 = h2_of.pop(t, None)   # (computed before the layer loop)
+            if not (L.fused_fwd and L.fused_bwd):  # someone still reads w[rows, wn]
+                if side is not None:
+                    (w, ev), zs = w_ready.pop(t), None
+                    torch.cuda.current_stream().wait_event(ev)
+                else:
+                    with _Span(self, f'radial_mlp_fwd[wn={ls.conv.weight_numel}]'):
+                        # one weight row per undirected pair when the graph carries the pair map
+                        w, zs = self._mlp_fwd(L, emb_p, g.n_pairs) if pairs else self._mlp_fwd(L, emb, E)
+            def conv_rows(a, b):   # the forward convolution of destination rows [a, b): pointer offsets, same kernels
+                if b <= a:
+                    return
+                rp, mo = C.c_void_p(g.row_ptr.data_ptr() + 4 * a), C.c_void_p(m.data_ptr() + 4 * a * dmid)
+                if L.fused_fwd:
+                    with _Span(self, f'conv_fwd_fused[{ls.conv.tag}]'):
+                        _lib.check(lib.snet_conv_fwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(w_row), rp,
+                                                           _ptr(g.src), b - a, L.scale, mo, st), 'snet_conv_fwd_fused')
+                else:
+                    with _Span(self, f'conv_fwd[{ls.conv.tag}]'):
+                        _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(w_row), rp,
+                                                     _ptr(g.src), b - a, L.scale, mo, st), 'snet_conv_fwd')
+            # rows without a ghost source (bricks number them first) do not wait for the exchange
+            n_int = g.n_interior if (pending is not None and split) else 0
+            conv_rows(0, n_int)
+            if pending is not None:
+                with _Span(self, 'halo_fwd'):
+                    halo.forward_finish(pending)
+            conv_rows(n_int, N)
+            if L.fused_bwd:
+                w = None  # the reverse pass rebuilds its weight tiles from h2
+            with _Span(self, 'node_linear_fwd'):
+                # y = SI2(m) + self-connection: the linear map ACCUMULATES into the self-connection's rows (the gate kernel used to
+                # add them: one read of sc and one write of y per node and layer more); y is kept for the reverse pass
+                y = self._linear(L.si2, m, N, g) if sc is None else self._linear(L.si2, m, N, g, out=sc, accumulate=True)
+            xo = self._new(N, ls.gate.irreps_out.dim)
+            with _Span(self, 'gate_fwd'):
+                _lib.check(lib.snet_gate_fwd(_ptr(y), None, _ptr(xo), N, ls.gate.irreps_in.dim,
+                                             ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st), 'snet_gate_fwd')
+            saved.append((h, w, zs, y, h2))
             if keep:
-                inter['edge_embedding'], inter['edge_attr'], inter['x_embed'] = emb, sh, x[:N]
-            saved = []
-            # interior / boundary split of the convolutions around the ghost exchange: needs the brick's interior-first row
-            # numbering, a halo with the split protocol, and edges (the reverse side walks a tile list)
-            split = bool(halo is not None and g.n_interior and hasattr(halo, 'forward_start') and hasattr(halo, 'reverse_start')
-                         and E > 0 and self.halo_split)
-            # hidden activations of every layer's radial MLP, one row per pair, in ONE launch: the layers share the edge embedding
-            # (five launches of a latency-bound kernel at brick sizes; the rows are kept for the reverse pass anyway)
-            h2_rows = g.n_pairs if pairs else E
-            h2_of = {t_: self._new(h2_rows, 64) for t_, L_ in enumerate(self.layers) if L_.fused_fwd or L_.fused_bwd}
-            with _Span(self, 'radial_mlp_hidden_fwd'):
-                ts = sorted(h2_of)
+                inter[f'{t}_si1'], inter[f'{t}_conv'], inter[f'{t}_gate_in'], inter[f'{t}_x'] = h[:N], m, y, xo
+            x = xo
+        return x
+
+    def _readout(self, c, x):
+        """readout (plain, folded to one fp64 vector, or `readout_as_fcn`), rescale, energy sum; returns dE/dx beside them"""
+        lib, sp, g, st, N = self.lib, self.spec, c.g, c.st, c.N
+        e_atom = self._new(N)
+        energy = torch.empty(1, dtype=torch.float64, device=self.dev)
+        d_ro = sp.readout1.dim_in
+        if self.ro_fcn is not None:   # readout_as_fcn: x -> act(x W0) cst -> ... -> e, then its reverse (nn/linear.py:145-180)
+            F = self.ro_fcn
+            d, nl = F.dims, len(F.w)
+            zs, a = [], x
+            for i in range(nl):
+                z = self._new(N, d[i + 1])
+                self._gemm(a, F.w[i], z, N, 1, d[i], d[i + 1], d[i], 0, d[i + 1], 0)
+                if i + 1 < nl:
+                    a = self._new(N, d[i + 1])
+                    _lib.check(lib.snet_act_fwd(_ptr(z), _ptr(a), z.numel(), F.act, F.cst, st), 'snet_act_fwd')
+                    zs.append(z)
+            _lib.check(lib.snet_rescale_reduce(_ptr(z), _ptr(g.types), _ptr(self.scale), _ptr(self.shift),
+                                               self.n_scale, N, _ptr(e_atom), _ptr(energy), st), 'snet_rescale_reduce')
+            gz = self._new(N, 1)
+            if self.n_scale > 1:
+                _lib.check(lib.snet_embed_rows(_ptr(self.scale), _ptr(g.types), _ptr(gz), N, 1, st), 'snet_embed_rows')
+            else:
+                gz.fill_(self.scale0)
+            for i in range(nl - 1, -1, -1):
+                ga = self._new(N, d[i])
+                self._gemm(gz, F.wt[i], ga, N, 1, d[i + 1], d[i], d[i + 1], 0, d[i], 0)
+                if i > 0:
+                    _lib.check(lib.snet_act_bwd(_ptr(zs[i - 1]), _ptr(ga), _ptr(ga), ga.numel(), F.act, F.cst, st), 'snet_act_bwd')
+                gz = ga
+            g_x = gz
+        elif self.ro_v is not None:   # folded readout: fp64 dot product + rescale + energy sum in one pass
+            _lib.check(lib.snet_readout_energy(_ptr(x), N, d_ro, _ptr(self.ro_v), self.ro_c, _ptr(g.types), _ptr(self.scale),
+                                               _ptr(self.shift), self.n_scale, _ptr(e_atom), _ptr(energy), st), 'snet_readout_energy')
+            g_x = self._new(N, d_ro)
+            _lib.check(lib.snet_readout_grad(_ptr(self.ro_v), d_ro, _ptr(g.types), _ptr(self.scale), self.n_scale, N, _ptr(g_x),
+                                             st), 'snet_readout_grad')
+        else:
+            h1 = self._linear(self.ro1, x, N, g)
+            e_sc = self._linear(self.ro2, h1, N, g)
+            _lib.check(lib.snet_rescale_reduce(_ptr(e_sc), _ptr(g.types), _ptr(self.scale), _ptr(self.shift),
+                                               self.n_scale, N, _ptr(e_atom), _ptr(energy), st), 'snet_rescale_reduce')
+            # ---------------- reverse pass: dE/d(e_scaled) = scale[type]
+            g_e = self._new(N, 1)
+            if self.n_scale > 1:
+                _lib.check(lib.snet_embed_rows(_ptr(self.scale), _ptr(g.types), _ptr(g_e), N, 1, st), 'snet_embed_rows')
+            else:
+                g_e.fill_(self.scale0)
+            g_h1 = self._linear_T(self.ro2, g_e, N, g)
+            g_x = self._linear_T(self.ro1, g_h1, N, g)
+        return e_atom, energy, g_x
+
+    def _reverse_layers(self, c, g_x):
+        """reverse pass through the interaction layers and the edge embedding; returns g_vec[E, 3] = dE/d(edge vector)"""
+        lib, g, halo, st = self.lib, c.g, c.halo, c.st
+        N, NT, E, nb, nsh = c.N, c.NT, c.E, c.nb, c.nsh
+        emb, sh, dsh, w_row, side, gw_bufs, gw_done = c.emb, c.sh, c.dsh, c.w_row, c.side, c.gw_bufs, c.gw_done
+        saved, split = c.saved, c.split
+        sh_T = None   # spherical harmonics in source-grouped edge order (transposed scalar convolution)
+        g_vec = torch.zeros(E, 3, dtype=torch.float32, device=self.dev)  # spherical part, all layers
+        g_emb = torch.zeros(E, nb, dtype=torch.float32, device=self.dev)
+        # fp16 operands of the fused reverse kernels: row maxima of the source rows and of the incoming gradient bound every
+        # edge's g_w, from which the kernel derives that edge's power-of-two scale (no overflow possible).  The source-row
+        # bounds of ALL layers come from one launch here (the rows have been complete since the forward pass).
+        x_max_of = {}
+        if self.fused_terms == 4 and E > 0:
+            ts = [t_ for t_, L_ in enumerate(self.layers) if L_.fused_bwd]
+            for t_ in ts:
+                x_max_of[t_] = self._new(NT)
+            with _Span(self, 'row_bounds'):
                 for i in range(0, len(ts), 8):
                     grp = ts[i:i + 8]
-                    plans = (C.c_void_p * len(grp))(*[self.layers[t_].mlp_plan for t_ in grp])
-                    outs = (C.c_void_p * len(grp))(*[h2_of[t_].data_ptr() for t_ in grp])
-                    _lib.check(lib.snet_radial_mlp_hidden_fwd_layers(plans, len(grp), _ptr(emb_p if pairs else emb), h2_rows, outs, st),
-                               'snet_radial_mlp_hidden_fwd_layers')
-            for t, L in enumerate(self.layers):
-                ls = L.spec
-                n_in = NT if t == 0 else N  # rows of x that are valid
-                with _Span(self, 'node_linear_fwd'):
-                    h = self._new(NT, ls.si1.dim_out)
-                    if t == 0 and self.h0_table is not None:   # species-only rows: fp64-evaluated table lookup
-                        _lib.check(lib.snet_embed_rows(_ptr(self.h0_table), _ptr(g.types), _ptr(h), NT, ls.si1.dim_out, st),
-                                   'snet_embed_rows')
-                    else:
-                        self._linear(L.si1, x, n_in, g, out=h)
-                # ghost rows of h travel while the self-connection and the radial MLP (which do not read
-                # them) run: hosts with a split exchange overlap the transfer with that work
-                pending = None
-                if t > 0 and halo is not None:
-                    with _Span(self, 'halo_fwd'):
-                        if hasattr(halo, 'forward_start'):
-                            pending = halo.forward_start(h, N)
-                        else:
-                            halo.forward(h, N)
-                with _Span(self, 'node_linear_fwd'):
-                    if t == 0 and self.h0_table is not None:
-                        sc = None
-                        if self.sc0_table is not None:
-                            sc = self._new(N, ls.gate.irreps_in.dim)
-                            _lib.check(lib.snet_embed_rows(_ptr(self.sc0_table), _ptr(g.types), _ptr(sc), N, ls.gate.irreps_in.dim,
-                                                           st), 'snet_embed_rows')
-                    else:
-                        sc = self._linear(L.sc, x, N, g) if L.sc is not None else None
-                dmid = ls.conv.irreps_out.dim
-                m = self._new(N, dmid)
-                if E == 0:
-                    m.zero_()
-                else:   # columns of pruned (unread) paths are never written by the tensor-product kernel: defined zeros
-                    for off, ln in L.si2.zero_in:
-                        m[:, off:off + ln].zero_()
-                h2 = w = zs = None
-                rows_w = g.n_pairs if pairs else E
-                h2 = h2_of.pop(t, None)   # (computed before the layer loop)
-                if not (L.fused_fwd and L.fused_bwd):  # someone still reads w[rows, wn]
-                    if side is not None:
-                        (w, ev), zs = w_ready.pop(t), None
-                        torch.cuda.current_stream().wait_event(ev)
-                    else:
-                        with _Span(self, f'radial_mlp_fwd[wn={ls.conv.weight_numel}]'):
-                            # one weight row per undirected pair when the graph carries the pair map
-                            w, zs = self._mlp_fwd(L, emb_p, g.n_pairs) if pairs else self._mlp_fwd(L, emb, E)
-                def conv_rows(a, b):   # the forward convolution of destination rows [a, b): pointer offsets, same kernels
-                    if b <= a:
-                        return
-                    rp, mo = C.c_void_p(g.row_ptr.data_ptr() + 4 * a), C.c_void_p(m.data_ptr() + 4 * a * dmid)
-                    if L.fused_fwd:
-                        with _Span(self, f'conv_fwd_fused[{ls.conv.tag}]'):
-                            _lib.check(lib.snet_conv_fwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(h2), _ptr(w_row), rp,
-                                                               _ptr(g.src), b - a, L.scale, mo, st), 'snet_conv_fwd_fused')
-                    else:
-                        with _Span(self, f'conv_fwd[{ls.conv.tag}]'):
-                            _lib.check(lib.snet_conv_fwd(L.plan, _ptr(h), _ptr(sh), _ptr(w), _ptr(w_row), rp,
-                                                         _ptr(g.src), b - a, L.scale, mo, st), 'snet_conv_fwd')
-                # rows without a ghost source (bricks number them first) do not wait for the exchange
-                n_int = g.n_interior if (pending is not None and split) else 0
-                conv_rows(0, n_int)
-                if pending is not None:
-                    with _Span(self, 'halo_fwd'):
-                        halo.forward_finish(pending)
-                conv_rows(n_int, N)
-                if L.fused_bwd:
-                    w = None  # the reverse pass rebuilds its weight tiles from h2
-                with _Span(self, 'node_linear_fwd'):
-                    # y = SI2(m) + self-connection: the linear map ACCUMULATES into the self-connection's rows (the gate kernel used to
-                    # add them: one read of sc and one write of y per node and layer more); y is kept for the reverse pass
-                    y = self._linear(L.si2, m, N, g) if sc is None else self._linear(L.si2, m, N, g, out=sc, accumulate=True)
-                xo = self._new(N, ls.gate.irreps_out.dim)
-                with _Span(self, 'gate_fwd'):
-                    _lib.check(lib.snet_gate_fwd(_ptr(y), None, _ptr(xo), N, ls.gate.irreps_in.dim,
-                                                 ls.gate.irreps_out.dim, L.gate_segs, len(ls.gate.segs), st), 'snet_gate_fwd')
-                saved.append((h, w, zs, y, h2))
-                if keep:
-                    inter[f'{t}_si1'], inter[f'{t}_conv'], inter[f'{t}_gate_in'], inter[f'{t}_x'] = h[:N], m, y, xo
-                x = xo
-            e_atom = self._new(N)
-            energy = torch.empty(1, dtype=torch.float64, device=self.dev)
-            d_ro = sp.readout1.dim_in
-            if self.ro_fcn is not None:   # readout_as_fcn: x -> act(x W0) cst -> ... -> e, then its reverse (nn/linear.py:145-180)
-                F = self.ro_fcn
-                d, nl = F.dims, len(F.w)
-                zs, a = [], x
-                for i in range(nl):
-                    z = self._new(N, d[i + 1])
-                    self._gemm(a, F.w[i], z, N, 1, d[i], d[i + 1], d[i], 0, d[i + 1], 0)
-                    if i + 1 < nl:
-                        a = self._new(N, d[i + 1])
-                        _lib.check(lib.snet_act_fwd(_ptr(z), _ptr(a), z.numel(), F.act, F.cst, st), 'snet_act_fwd')
-                        zs.append(z)
-                _lib.check(lib.snet_rescale_reduce(_ptr(z), _ptr(g.types), _ptr(self.scale), _ptr(self.shift),
-                                                   self.n_scale, N, _ptr(e_atom), _ptr(energy), st), 'snet_rescale_reduce')
-                gz = self._new(N, 1)
-                if self.n_scale > 1:
-                    _lib.check(lib.snet_embed_rows(_ptr(self.scale), _ptr(g.types), _ptr(gz), N, 1, st), 'snet_embed_rows')
-                else:
-                    gz.fill_(self.scale0)
-                for i in range(nl - 1, -1, -1):
-                    ga = self._new(N, d[i])
-                    self._gemm(gz, F.wt[i], ga, N, 1, d[i + 1], d[i], d[i + 1], 0, d[i], 0)
-                    if i > 0:
-                        _lib.check(lib.snet_act_bwd(_ptr(zs[i - 1]), _ptr(ga), _ptr(ga), ga.numel(), F.act, F.cst, st), 'snet_act_bwd')
-                    gz = ga
-                g_x = gz
-            elif self.ro_v is not None:   # folded readout: fp64 dot product + rescale + energy sum in one pass
-                _lib.check(lib.snet_readout_energy(_ptr(x), N, d_ro, _ptr(self.ro_v), self.ro_c, _ptr(g.types), _ptr(self.scale),
-                                                   _ptr(self.shift), self.n_scale, _ptr(e_atom), _ptr(energy), st), 'snet_readout_energy')
-                g_x = self._new(N, d_ro)
-                _lib.check(lib.snet_readout_grad(_ptr(self.ro_v), d_ro, _ptr(g.types), _ptr(self.scale), self.n_scale, N, _ptr(g_x),
-                                                 st), 'snet_readout_grad')
-            else:
-                h1 = self._linear(self.ro1, x, N, g)
-                e_sc = self._linear(self.ro2, h1, N, g)
-                _lib.check(lib.snet_rescale_reduce(_ptr(e_sc), _ptr(g.types), _ptr(self.scale), _ptr(self.shift),
-                                                   self.n_scale, N, _ptr(e_atom), _ptr(energy), st), 'snet_rescale_reduce')
-                # ---------------- reverse pass: dE/d(e_scaled) = scale[type]
-                g_e = self._new(N, 1)
-                if self.n_scale > 1:
-                    _lib.check(lib.snet_embed_rows(_ptr(self.scale), _ptr(g.types), _ptr(g_e), N, 1, st), 'snet_embed_rows')
-                else:
-                    g_e.fill_(self.scale0)
-                g_h1 = self._linear_T(self.ro2, g_e, N, g)
-                g_x = self._linear_T(self.ro1, g_h1, N, g)
-            sh_T = None   # spherical harmonics in source-grouped edge order (transposed scalar convolution)
-            g_vec = torch.zeros(E, 3, dtype=torch.float32, device=self.dev)  # spherical part, all layers
-            g_emb = torch.zeros(E, nb, dtype=torch.float32, device=self.dev)
-            # fp16 operands of the fused reverse kernels: row maxima of the source rows and of the incoming gradient bound every
-            # edge's g_w, from which the kernel derives that edge's power-of-two scale (no overflow possible).  The source-row
-            # bounds of ALL layers come from one launch here (the rows have been complete since the forward pass).
-            x_max_of = {}
-            if self.fused_terms == 4 and E > 0:
-                ts = [t_ for t_, L_ in enumerate(self.layers) if L_.fused_bwd]
-                for t_ in ts:
-                    x_max_of[t_] = self._new(NT)
-                with _Span(self, 'row_bounds'):
-                    for i in range(0, len(ts), 8):
-                        grp = ts[i:i + 8]
-                        k = len(grp)
-                        _lib.check(lib.snet_row_absmax_multi((C.c_void_p * k)(*[saved[t_][0].data_ptr() for t_ in grp]), (C.c_int64 * k)(*[NT] * k),
-                                                             (C.c_int32 * k)(*[self.layers[t_].spec.si1.dim_out for t_ in grp]),
-                                                             (C.c_void_p * k)(*[x_max_of[t_].data_ptr() for t_ in grp]), k, st),
-                                   'snet_row_absmax_multi')
-            for t in range(len(self.layers) - 1, -1, -1):
-                L = self.layers[t]
-                ls = L.spec
-                h, w, zs, y, h2 = saved[t]
-                g_y = self._new(N, ls.gate.irreps_in.dim)
-                # fp16 operands of the fused reverse kernel: row bound of g_m = SI2^T g_y through the narrower g_y and SI2's
-                # largest row norm (Cauchy-Schwarz), taken while the gate's reverse pass has the row in registers
-                g_max = self._new(N) if (L.fused_bwd and self.fused_terms == 4 and E > 0) else None
-                with _Span(self, 'gate_bwd'):
-                    _lib.check(lib.snet_gate_bwd_norm(_ptr(y), _ptr(g_x), _ptr(g_y), N, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim,
-                                                      L.gate_segs, len(ls.gate.segs), L.si2.t_norm if g_max is not None else 0.0,
-                                                      _ptr(g_max), st), 'snet_gate_bwd_norm')
-                with _Span(self, 'node_linear_bwd'):
-                    g_m = self._linear_T(L.si2, g_y, N, g)
-                # layer 0: inputs depend on species only -> no source-row gradient needed
-                use_t = t > 0 and getattr(L, 'tplan', None) is not None and E > 0
-                g_xe = self._new(E, ls.si1.dim_out) if (t > 0 and not use_t) else None
-                g_w = g_h2 = None
-                # reverse split (t > 0, fused kernels): boundary tiles first -- they hold every edge with a ghost source --
-                # then the ghost rows of g_h, whose exchange starts at once; interior tiles, the local rows and sc^T run under it
-                rsplit = split and t > 0 and L.fused_bwd
-                pending = None
-                g_h = self._new(NT, ls.si1.dim_out) if t > 0 else None
+                    k = len(grp)
+                    _lib.check(lib.snet_row_absmax_multi((C.c_void_p * k)(*[saved[t_][0].data_ptr() for t_ in grp]), (C.c_int64 * k)(*[NT] * k),
+                                                         (C.c_int32 * k)(*[self.layers[t_].spec.si1.dim_out for t_ in grp]),
+                                                         (C.c_void_p * k)(*[x_max_of[t_].data_ptr() for t_ in grp]), k, st),
+                               'snet_row_absmax_multi')
+        for t in range(len(self.layers) - 1, -1, -1):
+            L = self.layers[t]
+            ls = L.spec
+            h, w, zs, y, h2 = saved[t]
+            g_y = self._new(N, ls.gate.irreps_in.dim)
+            # fp16 operands of the fused reverse kernel: row bound of g_m = SI2^T g_y through the narrower g_y and SI2's
+            # largest row norm (Cauchy-Schwarz), taken while the gate's reverse pass has the row in registers
+            g_max = self._new(N) if (L.fused_bwd and self.fused_terms == 4 and E > 0) else None
+            with _Span(self, 'gate_bwd'):
+                _lib.check(lib.snet_gate_bwd_norm(_ptr(y), _ptr(g_x), _ptr(g_y), N, ls.gate.irreps_in.dim, ls.gate.irreps_out.dim,
+                                                  L.gate_segs, len(ls.gate.segs), L.si2.t_norm if g_max is not None else 0.0,
+                                                  _ptr(g_max), st), 'snet_gate_bwd_norm')
+            with _Span(self, 'node_linear_bwd'):
+                g_m = self._linear_T(L.si2, g_y, N, g)
+            # layer 0: inputs depend on species only -> no source-row gradient needed
+            use_t = t > 0 and getattr(L, 'tplan', None) is not None and E > 0
+            g_xe = self._new(E, ls.si1.dim_out) if (t > 0 and not use_t) else None
+            g_w = g_h2 = None
+            # reverse split (t > 0, fused kernels): boundary tiles first -- they hold every edge with a ghost source --
+            # then the ghost rows of g_h, whose exchange starts at once; interior tiles, the local rows and sc^T run under it
+            rsplit = split and t > 0 and L.fused_bwd
+            pending = None
+            g_h = self._new(NT, ls.si1.dim_out) if t > 0 else None
+            if use_t:
+                src_t, w_row_t = g.by_source(lib, st)
+                if L.t_dead:
+                    g_h.zero_()
+                if sh_T is None:
+                    sh_T = self._new(E, nsh)
+                    _lib.check(lib.snet_gather_rows(_ptr(sh), _ptr(g.eperm), _ptr(sh_T), E, nsh, st), 'snet_gather_rows')
+
+            def gh_rows(a, b):
+                """source rows [a, b) of g_h: transposed scalar convolution over the edges grouped by source, or the segment
+                sum of the per-edge rows the reverse kernel wrote"""
+                if b <= a:
+                    return
+                cp, go = C.c_void_p(g.col_ptr.data_ptr() + 4 * a), C.c_void_p(g_h.data_ptr() + 4 * a * ls.si1.dim_out)
                 if use_t:
-                    src_t, w_row_t = g.by_source(lib, st)
-                    if L.t_dead:
-                        g_h.zero_()
-                    if sh_T is None:
-                        sh_T = self._new(E, nsh)
-                        _lib.check(lib.snet_gather_rows(_ptr(sh), _ptr(g.eperm), _ptr(sh_T), E, nsh, st), 'snet_gather_rows')
-
-                def gh_rows(a, b):
-                    """source rows [a, b) of g_h: transposed scalar convolution over the edges grouped by source, or the segment
-                    sum of the per-edge rows the reverse kernel wrote"""
-                    if b <= a:
-                        return
-                    cp, go = C.c_void_p(g.col_ptr.data_ptr() + 4 * a), C.c_void_p(g_h.data_ptr() + 4 * a * ls.si1.dim_out)
-                    if use_t:
-                        with _Span(self, f'conv_bwd_node[transposed {ls.conv.tag}]'):
-                            _lib.check(lib.snet_conv_fwd_fused(L.tplan, _ptr(g_m), _ptr(sh_T), _ptr(h2), _ptr(w_row_t), cp, _ptr(src_t),
-                                                               b - a, L.scale, go, st), 'snet_conv_fwd_fused')
-                        return
-                    with _Span(self, 'conv_bwd_node[segment_sum]'):
-                        if L.fused_bwd:   # the fused kernel's g_xe rows: chunk order undone while summing
-                            _lib.check(lib.snet_segment_sum_rows_chunked(_ptr(g_xe), cp, _ptr(g.eperm), b - a, ls.si1.dim_out,
-                                                                         _ptr(L.gxe_chunks), go, st), 'snet_segment_sum_rows_chunked')
-                        else:
-                            _lib.check(lib.snet_segment_sum_rows(_ptr(g_xe), cp, _ptr(g.eperm), b - a, ls.si1.dim_out, go, st),
-                                       'snet_segment_sum_rows')
-
-                if L.fused_bwd:
-                    g_h2 = None if L.mlp_tail else self._new(E, 64)
-                    x_max = x_max_of.pop(t, None)   # (computed before the layer loop)
-
-                    def bwd_tiles(tp_, tn_, nt_):
-                        if nt_ <= 0:
-                            return
-                        with _Span(self, f'conv_bwd_fused[{ls.conv.tag}]'):
-                            _lib.check(lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(w_row),
-                                                               _ptr(g.row_ptr), _ptr(g.src), _ptr(tp_), _ptr(tn_), nt_, L.scale,
-                                                               _ptr(g_m), _ptr(g_xe), _ptr(g_h2),
-                                                               _ptr(emb) if L.mlp_tail else None, _ptr(g_emb) if L.mlp_tail else None,
-                                                               _ptr(g_vec), _ptr(x_max), _ptr(g_max), st),
-                                       'snet_conv_bwd_fused')
-                    if rsplit:
-                        (tpi, tni, nti), (tpb, tnb, ntb) = g.tiles_split(L.tile_mode)
-                        if use_t:                  # g_h does not depend on the reverse kernel: ghost rows straight away
-                            gh_rows(N, NT)
-                        else:
-                            bwd_tiles(tpb, tnb, ntb)
-                            gh_rows(N, NT)
-                        with _Span(self, 'halo_rev'):
-                            pending = halo.reverse_start(g_h, N)
-                        if use_t:
-                            bwd_tiles(*g.tiles(L.tile_mode))
-                        else:
-                            bwd_tiles(tpi, tni, nti)
-                        gh_rows(0, N)
-                    elif E > 0:
-                        bwd_tiles(*g.tiles(L.tile_mode))
-                else:
-                    if side is not None:  # double-buffered: the MLP reverse of layer t+2 may still be reading this one
-                        if gw_done[t & 1] is not None:
-                            torch.cuda.current_stream().wait_event(gw_done[t & 1])
-                        g_w = gw_bufs[t & 1][:E * ls.conv.weight_numel].view(E, ls.conv.weight_numel)
+                    with _Span(self, f'conv_bwd_node[transposed {ls.conv.tag}]'):
+                        _lib.check(lib.snet_conv_fwd_fused(L.tplan, _ptr(g_m), _ptr(sh_T), _ptr(h2), _ptr(w_row_t), cp, _ptr(src_t),
+                                                           b - a, L.scale, go, st), 'snet_conv_fwd_fused')
+                    return
+                with _Span(self, 'conv_bwd_node[segment_sum]'):
+                    if L.fused_bwd:   # the fused kernel's g_xe rows: chunk order undone while summing
+                        _lib.check(lib.snet_segment_sum_rows_chunked(_ptr(g_xe), cp, _ptr(g.eperm), b - a, ls.si1.dim_out,
+                                                                     _ptr(L.gxe_chunks), go, st), 'snet_segment_sum_rows_chunked')
                     else:
-                        g_w = self._new(E, ls.conv.weight_numel)
-                    with _Span(self, f'conv_bwd_edge[{ls.conv.tag}]'):
-                        _lib.check(lib.snet_conv_bwd_edge_vec(L.plan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(w), _ptr(w_row),
-                                                              _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(g_m), _ptr(g_w),
-                                                              _ptr(g_xe), _ptr(g_vec), st), 'snet_conv_bwd_edge_vec')
-                # the source-row gradient goes first so that its ghost rows can travel to their owners while
-                # the radial MLP's reverse pass (independent of them) runs
-                if t > 0 and not rsplit:
-                    gh_rows(0, NT)
-                    if halo is not None:
-                        with _Span(self, 'halo_rev'):
-                            if hasattr(halo, 'reverse_start'):
-                                pending = halo.reverse_start(g_h, N)
-                            else:
-                                halo.reverse(g_h, N)
-                del g_xe
-                if L.fused_bwd and L.mlp_tail:
-                    pass
-                elif L.fused_bwd:
-                    with _Span(self, 'radial_mlp_hidden_bwd'):
-                        _lib.check(lib.snet_radial_mlp_hidden_bwd(L.mlp_plan, _ptr(emb), _ptr(g_h2), E, _ptr(g_emb), st),
-                                   'snet_radial_mlp_hidden_bwd')
-                elif side is not None:  # g_w is complete on the main stream; its consumer runs beside what follows
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]@side'):
-                            self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
-                        gw_done[t & 1] = torch.cuda.Event()
-                        gw_done[t & 1].record(side)
-                else:
-                    with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]'):
-                        self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
-                del g_w, g_h2
-                if t == 0:
-                    break
-                # g_x = sc^T g_y + SI1^T g_h: the self-connection's share does not need the ghost gradients, so it runs
-                # while they travel (reverse_start above put the exchange on the halo's stream)
-                with _Span(self, 'node_linear_bwd'):
-                    g_x = self._linear_T(L.sc, g_y, N, g) if L.sc is not None else None
-                if pending is not None:
+                        _lib.check(lib.snet_segment_sum_rows(_ptr(g_xe), cp, _ptr(g.eperm), b - a, ls.si1.dim_out, go, st),
+                                   'snet_segment_sum_rows')
+
+            if L.fused_bwd:
+                g_h2 = None if L.mlp_tail else self._new(E, 64)
+                x_max = x_max_of.pop(t, None)   # (computed before the layer loop)
+
+                def bwd_tiles(tp_, tn_, nt_):
+                    if nt_ <= 0:
+                        return
+                    with _Span(self, f'conv_bwd_fused[{ls.conv.tag}]'):
+                        _lib.check(lib.snet_conv_bwd_fused(L.fplan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(h2), _ptr(w_row),
+                                                           _ptr(g.row_ptr), _ptr(g.src), _ptr(tp_), _ptr(tn_), nt_, L.scale,
+                                                           _ptr(g_m), _ptr(g_xe), _ptr(g_h2),
+                                                           _ptr(emb) if L.mlp_tail else None, _ptr(g_emb) if L.mlp_tail else None,
+                                                           _ptr(g_vec), _ptr(x_max), _ptr(g_max), st),
+                                   'snet_conv_bwd_fused')
+                if rsplit:
+                    (tpi, tni, nti), (tpb, tnb, ntb) = g.tiles_split(L.tile_mode)
+                    if use_t:                  # g_h does not depend on the reverse kernel: ghost rows straight away
+                        gh_rows(N, NT)
+                    else:
+                        bwd_tiles(tpb, tnb, ntb)
+                        gh_rows(N, NT)
                     with _Span(self, 'halo_rev'):
-                        halo.reverse_finish(pending, g_h)
-                with _Span(self, 'node_linear_bwd'):
-                    g_x = self._linear_T(L.si1, g_h, N, g, out=g_x, accumulate=g_x is not None)
-                saved[t] = None
-            if side is not None:
-                torch.cuda.current_stream().wait_stream(side)
-            _lib.check(lib.snet_edge_embed_bwd(C.byref(self.edge_params), self.coeffs, _ptr(g.edge_vec), E, _ptr(g_emb),
-                                               None, _ptr(g_vec), 1, st), 'snet_edge_embed_bwd')
-            forces = self._new(NT, 3)
-            vir_atom = self._new(NT, 6) if want_atomic_virial else None
-            virial = torch.empty(6, dtype=torch.float64, device=self.dev)
-            _lib.check(lib.snet_edge_force(_ptr(g_vec), _ptr(g.edge_vec), _ptr(g.row_ptr), _ptr(g.col_ptr),
-                                           _ptr(g.eperm), NT, E, _ptr(forces), _ptr(vir_atom), _ptr(virial), st),
-                       'snet_edge_force')
-            if halo is not None:  # fold ghost-atom force (and atomic virial) contributions into their owners: ONE exchange
-                with _Span(self, 'halo_rev'):
-                    if vir_atom is None:
-                        halo.reverse(forces, N)
+                        pending = halo.reverse_start(g_h, N)
+                    if use_t:
+                        bwd_tiles(*g.tiles(L.tile_mode))
                     else:
-                        fv = torch.cat([forces, vir_atom], 1).contiguous()
-                        halo.reverse(fv, N)
-                        forces, vir_atom = fv[:, :3].contiguous(), fv[:, 3:].contiguous()
-            if g.order is not None:  # report dE/dr in the caller's edge order
-                tmp = torch.empty_like(g_vec)
-                tmp[g.order] = g_vec
-                g_vec = tmp
-            out = dict(energy=energy, atomic_energy=e_atom, dE_dr=g_vec, forces=forces[:N], virial=virial)
-            if vir_atom is not None:
-                out['atomic_virial'] = vir_atom[:N]
-            if keep:
-                out['inter'] = inter
-            return out
+                        bwd_tiles(tpi, tni, nti)
+                    gh_rows(0, N)
+                elif E > 0:
+                    bwd_tiles(*g.tiles(L.tile_mode))
+            else:
+                if side is not None:  # double-buffered: the MLP reverse of layer t+2 may still be reading this one
+                    if gw_done[t & 1] is not None:
+                        torch.cuda.current_stream().wait_event(gw_done[t & 1])
+                    g_w = gw_bufs[t & 1][:E * ls.conv.weight_numel].view(E, ls.conv.weight_numel)
+                else:
+                    g_w = self._new(E, ls.conv.weight_numel)
+                with _Span(self, f'conv_bwd_edge[{ls.conv.tag}]'):
+                    _lib.check(lib.snet_conv_bwd_edge_vec(L.plan, _ptr(h), _ptr(sh), _ptr(dsh), _ptr(w), _ptr(w_row),
+                                                          _ptr(g.row_ptr), _ptr(g.src), N, L.scale, _ptr(g_m), _ptr(g_w),
+                                                          _ptr(g_xe), _ptr(g_vec), st), 'snet_conv_bwd_edge_vec')
+            # the source-row gradient goes first so that its ghost rows can travel to their owners while
+            # the radial MLP's reverse pass (independent of them) runs
+            if t > 0 and not rsplit:
+                gh_rows(0, NT)
+                if halo is not None:
+                    with _Span(self, 'halo_rev'):
+                        if hasattr(halo, 'reverse_start'):
+                            pending = halo.reverse_start(g_h, N)
+                        else:
+                            halo.reverse(g_h, N)
+            del g_xe
+            if L.fused_bwd and L.mlp_tail:
+                pass
+            elif L.fused_bwd:
+                with _Span(self, 'radial_mlp_hidden_bwd'):
+                    _lib.check(lib.snet_radial_mlp_hidden_bwd(L.mlp_plan, _ptr(emb), _ptr(g_h2), E, _ptr(g_emb), st),
+                               'snet_radial_mlp_hidden_bwd')
+            elif side is not None:  # g_w is complete on the main stream; its consumer runs beside what follows
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]@side'):
+                        self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
+                    gw_done[t & 1] = torch.cuda.Event()
+                    gw_done[t & 1].record(side)
+            else:
+                with _Span(self, f'radial_mlp_bwd[wn={ls.conv.weight_numel}]'):
+                    self._mlp_bwd(L, emb, zs, g_w, g_emb, E)
+            del g_w, g_h2
+            if t == 0:
+                break
+            # g_x = sc^T g_y + SI1^T g_h: the self-connection's share does not need the ghost gradients, so it runs
+            # while they travel (reverse_start above put the exchange on the halo's stream)
+            with _Span(self, 'node_linear_bwd'):
+                g_x = self._linear_T(L.sc, g_y, N, g) if L.sc is not None else None
+            if pending is not None:
+                with _Span(self, 'halo_rev'):
+                    halo.reverse_finish(pending, g_h)
+            with _Span(self, 'node_linear_bwd'):
+                g_x = self._linear_T(L.si1, g_h, N, g, out=g_x, accumulate=g_x is not None)
+            saved[t] = None
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        _lib.check(lib.snet_edge_embed_bwd(C.byref(self.edge_params), self.coeffs, _ptr(g.edge_vec), E, _ptr(g_emb),
+                                           None, _ptr(g_vec), 1, st), 'snet_edge_embed_bwd')
+        return g_vec
+
+    def _forces(self, c, g_vec, e_atom, energy, want_atomic_virial: bool):
+        """forces / virial from the edge gradients (force_output.py:171-230), ghost contributions folded into their owners"""
+        lib, g, halo, st, N, NT, E = self.lib, c.g, c.halo, c.st, c.N, c.NT, c.E
+        keep, inter = c.keep, c.inter
+        forces = self._new(NT, 3)
+        vir_atom = self._new(NT, 6) if want_atomic_virial else None
+        virial = torch.empty(6, dtype=torch.float64, device=self.dev)
+        _lib.check(lib.snet_edge_force(_ptr(g_vec), _ptr(g.edge_vec), _ptr(g.row_ptr), _ptr(g.col_ptr),
+                                       _ptr(g.eperm), NT, E, _ptr(forces), _ptr(vir_atom), _ptr(virial), st),
+                   'snet_edge_force')
+        if halo is not None:  # fold ghost-atom force (and atomic virial) contributions into their owners: ONE exchange
+            with _Span(self, 'halo_rev'):
+                if vir_atom is None:
+                    halo.reverse(forces, N)
+                else:
+                    fv = torch.cat([forces, vir_atom], 1).contiguous()
+                    halo.reverse(fv, N)
+                    forces, vir_atom = fv[:, :3].contiguous(), fv[:, 3:].contiguous()
+        if g.order is not None:  # report dE/dr in the caller's edge order
+            tmp = torch.empty_like(g_vec)
+            tmp[g.order] = g_vec
+            g_vec = tmp
+        out = dict(energy=energy, atomic_energy=e_atom, dE_dr=g_vec, forces=forces[:N], virial=virial)
+        if vir_atom is not None:
+            out['atomic_virial'] = vir_atom[:N]
+        if keep:
+            out['inter'] = inter
+        return out
