@@ -236,3 +236,14 @@ def test_generator_functions_stay_reviewable():
     tree = ast.parse(inspect.getsource(codegen_fused))
     long = [(n.name, n.end_lineno - n.lineno + 1) for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.end_lineno - n.lineno + 1 > 300]
     assert long == []
+
+
+def test_engine_functions_stay_reviewable():
+    """the Python host's evaluation is a sequence of phase methods (compute was one 385-line function through round 6): nothing in
+    engine.py over 200 lines"""
+    import ast
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'sevennet_amd', 'engine.py')
+    tree = ast.parse(open(path).read())
+    long = [(n.name, n.end_lineno - n.lineno + 1) for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.end_lineno - n.lineno + 1 > 200]
+    assert long == []
