@@ -1201,3 +1201,59 @@ def test_amorphous_supercell_at_config4_size():
     f_ref, e_ref = ref['forces'].numpy(), ref['atomic_energy'].numpy()
     assert np.abs(F - f_ref[None]).max() < 1e-4, np.abs(F - f_ref[None]).max()
     _energy_fp32_class(float(out['energy'].cpu()) / n_big, Ea, ref, n_u)
+
+
+@pytest.mark.gpu
+def test_symmetries_at_the_benchmark_size():
+    """BASELINE config 3's workload itself (SevenNet-0 shape, 97 336 atoms, the cell bench.py times) through the properties an
+    E(3)-equivariant, permutation- and translation-invariant potential has at ANY size (what the reference's model guarantees by
+    construction, nn/convolution.py:118-141 + force_output.py:171-230): the total force vanishes; a rigid rotation of cell and positions
+    leaves the energy, rotates the forces and conjugates the virial; a translation and a relabelling of the atoms change nothing.
+    Each transformed system gets its own GPU neighbor list (a rotated cubic cell is a general triclinic one for the list builder) and its
+    own edge order, so the comparison also crosses different summation orders: forces within twice the single-evaluation bar (1e-4 eV/A
+    at max|F| = 8 eV/A, scaled to this system's max|F|), energy within 5e-7 and virial within 1e-6 of their magnitudes (the fp64 sums of
+    fp32 terms move by 1e-8 relative between orders)."""
+    from sevennet_amd.engine import HipForceEngine
+    from sevennet_amd.model_spec import sevennet_0_config
+    from sevennet_amd.neighbor import diamond_cubic
+    from sevennet_amd.neighbor_gpu import build_graph_gpu
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = sevennet_0_config()
+    eng = HipForceEngine(cfg, random_state_dict(cfg, seed=0), device='cuda:0')
+    pos, cell = diamond_cubic(5.431, (23,) * 3, 0.05, 2)
+    cell = np.asarray(cell, np.float64)
+    n = len(pos)
+    assert n == 97336
+    types = np.zeros(n, np.int64)
+
+    def evaluate(p, c):
+        g = build_graph_gpu(types, p, c, cfg['cutoff'], device='cuda:0')
+        out = eng.compute(g)
+        torch.cuda.synchronize()
+        v = out['virial'].cpu().numpy()          # xx yy zz xy yz zx (include/snet_hip.h)
+        V = np.array([[v[0], v[3], v[5]], [v[3], v[1], v[4]], [v[5], v[4], v[2]]])
+        return g.n_edges, float(out['energy'].cpu()), out['forces'].cpu().numpy().astype(np.float64), V
+
+    ne0, e0, f0, v0 = evaluate(pos, cell)
+    fmax, vmax = np.abs(f0).max(), np.abs(v0).max()
+    # measured on an MI355X: rotation |dE| 1.2e-5 eV of 1 759 eV, |dF| 3.6e-7 eV/A at max|F| = 0.083, |dV| 9.6e-5 of 4 460 eV;
+    # relabelling + translation 4.3e-5 eV, 8.9e-8 eV/A, 1.0e-5 eV
+    f_tol, e_tol, v_tol = 2 * 1e-4 * fmax / 8.0, 5e-7 * abs(e0), 1e-6 * vmax
+    assert np.abs(f0.sum(0)).max() < 1e-3 * max(1.0, fmax)                      # Newton's third law over 2.7 M edges
+    # rigid rotation (proper, random): rows of `cell` are lattice vectors
+    q, r = np.linalg.qr(np.random.default_rng(3).normal(size=(3, 3)))
+    R = q * np.sign(np.diag(r))
+    if np.linalg.det(R) < 0:
+        R[:, 0] = -R[:, 0]
+    ne1, e1, f1, v1 = evaluate(pos @ R.T, cell @ R.T)
+    assert ne1 == ne0
+    assert abs(e1 - e0) <= e_tol, (e1 - e0, e_tol)
+    assert np.abs(f1 - f0 @ R.T).max() <= f_tol, (np.abs(f1 - f0 @ R.T).max(), f_tol)
+    assert np.abs(v1 - R @ v0 @ R.T).max() <= v_tol, (np.abs(v1 - R @ v0 @ R.T).max(), v_tol)
+    # translation (atoms leave the cell on one side: the list builder wraps them) and relabelling
+    perm = np.random.default_rng(4).permutation(n)
+    ne2, e2, f2, v2 = evaluate((pos + np.array([1.234, -7.5, 40.1]))[perm], cell)
+    assert ne2 == ne0
+    assert abs(e2 - e0) <= e_tol, (e2 - e0, e_tol)
+    assert np.abs(f2 - f0[perm]).max() <= f_tol, (np.abs(f2 - f0[perm]).max(), f_tol)
+    assert np.abs(v2 - v0).max() <= v_tol, (np.abs(v2 - v0).max(), v_tol)
