@@ -1204,8 +1204,10 @@ def test_amorphous_supercell_at_config4_size():
 
 
 @pytest.mark.gpu
-def test_symmetries_at_the_benchmark_size():
-    """BASELINE config 3's workload itself (SevenNet-0 shape, 97 336 atoms, the cell bench.py times) through the properties an
+@pytest.mark.parametrize('model', ['sevennet_0', 'sevennet_l3i5'])
+def test_symmetries_at_the_benchmark_size(model):
+    """BASELINE config 3's and config 4's workloads themselves (SevenNet-0 shape, 97 336 atoms; l3i5 shape -- lmax 3, odd-parity
+    paths --, 54 872-atom "amorphous" cell: the cells bench.py times) through the properties an
     E(3)-equivariant, permutation- and translation-invariant potential has at ANY size (what the reference's model guarantees by
     construction, nn/convolution.py:118-141 + force_output.py:171-230): the total force vanishes; a rigid rotation of cell and positions
     leaves the energy, rotates the forces and conjugates the virial; a translation and a relabelling of the atoms change nothing.
@@ -1214,16 +1216,20 @@ def test_symmetries_at_the_benchmark_size():
     at max|F| = 8 eV/A, scaled to this system's max|F|), energy within 5e-7 and virial within 1e-6 of their magnitudes (the fp64 sums of
     fp32 terms move by 1e-8 relative between orders)."""
     from sevennet_amd.engine import HipForceEngine
-    from sevennet_amd.model_spec import sevennet_0_config
-    from sevennet_amd.neighbor import diamond_cubic
+    from sevennet_amd.neighbor import amorphous_cell, diamond_cubic
     from sevennet_amd.neighbor_gpu import build_graph_gpu
+    from sevennet_amd.shapes import sevennet_0_config, sevennet_l3i5_config
     from sevennet_amd.synthetic import random_state_dict
-    cfg = sevennet_0_config()
+    if model == 'sevennet_0':
+        cfg = sevennet_0_config()
+        pos, cell = diamond_cubic(5.431, (23,) * 3, 0.05, 2)
+    else:
+        cfg = sevennet_l3i5_config()
+        pos, cell = amorphous_cell(5.431, (19,) * 3, 0.35, 3, 1.8)
     eng = HipForceEngine(cfg, random_state_dict(cfg, seed=0), device='cuda:0')
-    pos, cell = diamond_cubic(5.431, (23,) * 3, 0.05, 2)
     cell = np.asarray(cell, np.float64)
     n = len(pos)
-    assert n == 97336
+    assert n == {'sevennet_0': 97336, 'sevennet_l3i5': 54872}[model]
     types = np.zeros(n, np.int64)
 
     def evaluate(p, c):
@@ -1236,7 +1242,7 @@ def test_symmetries_at_the_benchmark_size():
 
     ne0, e0, f0, v0 = evaluate(pos, cell)
     fmax, vmax = np.abs(f0).max(), np.abs(v0).max()
-    # measured on an MI355X: rotation |dE| 1.2e-5 eV of 1 759 eV, |dF| 3.6e-7 eV/A at max|F| = 0.083, |dV| 9.6e-5 of 4 460 eV;
+    # measured on an MI355X (SevenNet-0 shape): rotation |dE| 1.2e-5 eV of 1 759 eV, |dF| 3.6e-7 eV/A at max|F| = 0.083, |dV| 9.6e-5 of 4 460 eV;
     # relabelling + translation 4.3e-5 eV, 8.9e-8 eV/A, 1.0e-5 eV
     f_tol, e_tol, v_tol = 2 * 1e-4 * fmax / 8.0, 5e-7 * abs(e0), 1e-6 * vmax
     assert np.abs(f0.sum(0)).max() < 1e-3 * max(1.0, fmax)                      # Newton's third law over 2.7 M edges
@@ -1257,3 +1263,5 @@ def test_symmetries_at_the_benchmark_size():
     assert abs(e2 - e0) <= e_tol, (e2 - e0, e_tol)
     assert np.abs(f2 - f0[perm]).max() <= f_tol, (np.abs(f2 - f0[perm]).max(), f_tol)
     assert np.abs(v2 - v0).max() <= v_tol, (np.abs(v2 - v0).max(), v_tol)
+    # (no inversion test: the released SevenNet shapes are built with is_parity = False -- every irrep even, paths such as 1 x 1 -> 1
+    # present --, i.e. they are SO(3)- but not O(3)-equivariant by construction; measured here, forces change by 1.5 % under inversion)
