@@ -1204,10 +1204,26 @@ def test_amorphous_supercell_at_config4_size():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('model', ['sevennet_0', 'sevennet_l3i5'])
+def _benchmark_workload(model):
+    """(cfg, pos, cell, types, modal) of bench.py's workload for `model` (SURVEY.md 8(d) configs 3, 4 and config 5's per-GPU share)"""
+    from bench import model_config, species_of
+    from sevennet_amd.neighbor import amorphous_cell, diamond_cubic
+    cfg = model_config(model)
+    if model == 'sevennet_l3i5':
+        pos, cell = amorphous_cell(5.431, (19,) * 3, 0.35, 3, 1.8)
+    elif model == 'sevennet_mf_ompa':
+        pos, cell = diamond_cubic(5.431, (15,) * 3, 0.1, 4)
+    else:
+        pos, cell = diamond_cubic(5.431, (23,) * 3, 0.05, 2)
+    assert len(pos) == {'sevennet_0': 97336, 'sevennet_l3i5': 54872, 'sevennet_mf_ompa': 27000}[model]
+    return cfg, pos, np.asarray(cell, np.float64), species_of(cfg, len(pos)), ('mpa' if cfg.get('use_modality') else None)
+
+
+@pytest.mark.parametrize('model', ['sevennet_0', 'sevennet_l3i5', 'sevennet_mf_ompa'])
 def test_symmetries_at_the_benchmark_size(model):
-    """BASELINE config 3's and config 4's workloads themselves (SevenNet-0 shape, 97 336 atoms; l3i5 shape -- lmax 3, odd-parity
-    paths --, 54 872-atom "amorphous" cell: the cells bench.py times) through the properties an
+    """BASELINE config 3's, config 4's and config 5's (per-GPU share) workloads themselves (SevenNet-0 shape, 97 336 atoms; l3i5 shape
+    -- lmax 3 --, 54 872-atom "amorphous" cell; MF-ompa shape -- 119 species, 4 of them present, fidelity channel, cutoff 6 A --, 27 000
+    atoms: the cells bench.py times) through the properties an
     E(3)-equivariant, permutation- and translation-invariant potential has at ANY size (what the reference's model guarantees by
     construction, nn/convolution.py:118-141 + force_output.py:171-230): the total force vanishes; a rigid rotation of cell and positions
     leaves the energy, rotates the forces and conjugates the virial; a translation and a relabelling of the atoms change nothing.
@@ -1216,24 +1232,15 @@ def test_symmetries_at_the_benchmark_size(model):
     at max|F| = 8 eV/A, scaled to this system's max|F|), energy within 5e-7 and virial within 1e-6 of their magnitudes (the fp64 sums of
     fp32 terms move by 1e-8 relative between orders)."""
     from sevennet_amd.engine import HipForceEngine
-    from sevennet_amd.neighbor import amorphous_cell, diamond_cubic
     from sevennet_amd.neighbor_gpu import build_graph_gpu
-    from sevennet_amd.shapes import sevennet_0_config, sevennet_l3i5_config
     from sevennet_amd.synthetic import random_state_dict
-    if model == 'sevennet_0':
-        cfg = sevennet_0_config()
-        pos, cell = diamond_cubic(5.431, (23,) * 3, 0.05, 2)
-    else:
-        cfg = sevennet_l3i5_config()
-        pos, cell = amorphous_cell(5.431, (19,) * 3, 0.35, 3, 1.8)
-    eng = HipForceEngine(cfg, random_state_dict(cfg, seed=0), device='cuda:0')
-    cell = np.asarray(cell, np.float64)
+    cfg, pos, cell, types, modal = _benchmark_workload(model)
+    eng = HipForceEngine(cfg, random_state_dict(cfg, seed=0), device='cuda:0', modal=modal)
     n = len(pos)
-    assert n == {'sevennet_0': 97336, 'sevennet_l3i5': 54872}[model]
-    types = np.zeros(n, np.int64)
+    ns = eng.spec.num_species if eng.needs_species_rows else 0
 
-    def evaluate(p, c):
-        g = build_graph_gpu(types, p, c, cfg['cutoff'], device='cuda:0')
+    def evaluate(p, c, ty=types):
+        g = build_graph_gpu(ty, p, c, cfg['cutoff'], device='cuda:0', num_species=ns)
         out = eng.compute(g)
         torch.cuda.synchronize()
         v = out['virial'].cpu().numpy()          # xx yy zz xy yz zx (include/snet_hip.h)
@@ -1258,7 +1265,7 @@ def test_symmetries_at_the_benchmark_size(model):
     assert np.abs(v1 - R @ v0 @ R.T).max() <= v_tol, (np.abs(v1 - R @ v0 @ R.T).max(), v_tol)
     # translation (atoms leave the cell on one side: the list builder wraps them) and relabelling
     perm = np.random.default_rng(4).permutation(n)
-    ne2, e2, f2, v2 = evaluate((pos + np.array([1.234, -7.5, 40.1]))[perm], cell)
+    ne2, e2, f2, v2 = evaluate((pos + np.array([1.234, -7.5, 40.1]))[perm], cell, types[perm])
     assert ne2 == ne0
     assert abs(e2 - e0) <= e_tol, (e2 - e0, e_tol)
     assert np.abs(f2 - f0[perm]).max() <= f_tol, (np.abs(f2 - f0[perm]).max(), f_tol)
@@ -1268,29 +1275,21 @@ def test_symmetries_at_the_benchmark_size(model):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('model', ['sevennet_0', 'sevennet_l3i5'])
+@pytest.mark.parametrize('model', ['sevennet_0', 'sevennet_l3i5', 'sevennet_mf_ompa'])
 def test_forces_are_the_gradient_of_the_energy_at_the_benchmark_size(model):
     """the benchmark cells (97 336 / 54 872 atoms) through the defining property of a force (force_output.py:171-230: F = -dE/dr by
     autograd in the reference, a hand-scheduled reverse pass here): a central difference of the total energy along a collective
     displacement d (every atom along its own force, |d_i| <= 1) reproduces -sum_i F_i . d_i.  A wrong sign, a missing path of the
     reverse pass or a mis-folded periodic image shows at the 1e-1 level; truncation (h = 2e-3 A) and fp32 rounding at a few 1e-5."""
     from sevennet_amd.engine import HipForceEngine
-    from sevennet_amd.neighbor import amorphous_cell, diamond_cubic
     from sevennet_amd.neighbor_gpu import build_graph_gpu
-    from sevennet_amd.shapes import sevennet_0_config, sevennet_l3i5_config
     from sevennet_amd.synthetic import random_state_dict
-    if model == 'sevennet_0':
-        cfg = sevennet_0_config()
-        pos, cell = diamond_cubic(5.431, (23,) * 3, 0.05, 2)
-    else:
-        cfg = sevennet_l3i5_config()
-        pos, cell = amorphous_cell(5.431, (19,) * 3, 0.35, 3, 1.8)
-    eng = HipForceEngine(cfg, random_state_dict(cfg, seed=0), device='cuda:0')
-    cell = np.asarray(cell, np.float64)
-    types = np.zeros(len(pos), np.int64)
+    cfg, pos, cell, types, modal = _benchmark_workload(model)
+    eng = HipForceEngine(cfg, random_state_dict(cfg, seed=0), device='cuda:0', modal=modal)
+    ns = eng.spec.num_species if eng.needs_species_rows else 0
 
     def evaluate(p):
-        out = eng.compute(build_graph_gpu(types, p, cell, cfg['cutoff'], device='cuda:0'))
+        out = eng.compute(build_graph_gpu(types, p, cell, cfg['cutoff'], device='cuda:0', num_species=ns))
         torch.cuda.synchronize()
         return float(out['energy'].cpu()), out['forces'].cpu().numpy().astype(np.float64)
 
