@@ -315,3 +315,53 @@ def test_md_host_isolated_atoms_no_edges():
     ref = oracle_model(cfg, sd).forward(np.array([2, 0]), np.zeros((2, 0), np.int64), np.zeros((0, 3)))
     assert np.abs(out['eatom'] - ref['atomic_energy'].numpy()).max() < 1e-5
     assert abs(out['energy'] - float(ref['energy'])) < 1e-5
+
+
+def test_md_host_at_the_benchmark_size_matches_the_engine():
+    """The LAMMPS-facing host at BASELINE config 3's size: one process holding the whole 97 336-atom cell the way LAMMPS presents it
+    (owned atoms + 54 k periodic ghost images carrying their owners' tags, a FULL neighbor list with a 1-A skin: 5.2 M slots for 2.7 M
+    edges inside the cutoff) through snet_md_compute == the engine on the GPU-built periodic graph of the same positions -- energy,
+    per-atom energies, forces, LAMMPS-order virial --, and again after the atoms moved inside the skin with the list declared unchanged
+    (pair_e3gnn.cpp:74-289 runs exactly this every MD step; reference analogue tests/lammps_tests/test_lammps.py:201-220)."""
+    from sevennet_amd.engine import HipForceEngine
+    from sevennet_amd.model_spec import sevennet_0_config
+    from sevennet_amd.neighbor import diamond_cubic
+    from sevennet_amd.neighbor_gpu import build_graph_gpu
+    from sevennet_amd.synthetic import random_state_dict
+    cfg = sevennet_0_config()
+    sd = random_state_dict(cfg, seed=0)
+    pos, cell = diamond_cubic(5.431, (23,) * 3, 0.05, 2)
+    n, rc = len(pos), cfg['cutoff'] + SKIN
+    L = np.diag(cell)
+    xs, tags, shifts = [pos], [np.arange(1, n + 1)], [np.zeros((n, 3))]
+    for s in np.ndindex(3, 3, 3):
+        sh = (np.array(s) - 1) * L
+        if not sh.any():
+            continue
+        img = pos + sh
+        sel = np.all((img > -rc) & (img < L + rc), axis=1)
+        xs.append(img[sel]); tags.append(np.nonzero(sel)[0] + 1); shifts.append(np.broadcast_to(sh, (int(sel.sum()), 3)))
+    x, tag, shift = np.concatenate(xs), np.concatenate(tags), np.concatenate(shifts)
+    nb = cKDTree(x).query_ball_point(x[:n], rc, workers=-1)
+    rows = [np.asarray([j for j in r if j != i], np.int32) for i, r in enumerate(nb)]
+    ty_all = np.zeros(len(x), np.int64)
+    host = MdHost(cfg, sd)
+    eng = HipForceEngine(cfg, sd, device='cuda:0')
+
+    def check(p, unchanged):
+        out = host.compute(p[tag - 1] + shift, tag, n, rows, ty_all, vflag_atom=0, unchanged=unchanged)
+        g = build_graph_gpu(np.zeros(n, np.int64), p, cell, cfg['cutoff'], device='cuda:0')
+        ref = eng.compute(g)
+        torch.cuda.synchronize()
+        assert out['n_nodes'] == n and out['n_edges'] == g.n_edges
+        e_ref, f_ref = float(ref['energy'].cpu()), ref['forces'].cpu().numpy().astype(np.float64)
+        assert abs(out['energy'] - e_ref) <= 1e-7 * abs(e_ref), (out['energy'], e_ref)
+        assert np.abs(out['f'][:n] - f_ref).max() <= 5e-6 * np.abs(f_ref).max(), np.abs(out['f'][:n] - f_ref).max()
+        assert np.abs(out['f'][n:]).max() == 0.0
+        assert np.abs(out['eatom'][:n] - ref['atomic_energy'].cpu().numpy()).max() <= 1e-6
+        v = ref['virial'].cpu().numpy()[[0, 1, 2, 3, 5, 4]]      # model xx yy zz xy yz zx -> LAMMPS xx yy zz xy xz yz
+        assert np.abs(out['virial'] - v).max() <= 1e-6 * np.abs(v).max()
+
+    check(pos, False)
+    moved = pos + np.random.default_rng(8).uniform(-0.2, 0.2, pos.shape)    # inside half the skin: the list stays valid
+    check(moved, True)
