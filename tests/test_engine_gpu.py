@@ -1349,3 +1349,14 @@ def test_eight_bricks_of_the_benchmark_cell_equal_the_single_graph():
     # the ghost gradients are added in another order than the single graph's segment sum)
     assert abs(e_tot - e_ref) < 1e-8 * abs(e_ref), (e_tot, e_ref)
     assert np.abs(F - fr).max() <= 5e-6 * np.abs(fr).max(), (np.abs(F - fr).max(), np.abs(fr).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model', ['sevennet_0', 'sevennet_l3i5', 'sevennet_mf_ompa'])
+def test_gpu_neighbor_list_of_the_benchmark_cells_equals_the_host_list(model):
+    """f1 at BASELINE's sizes, index-exact: the device cell list of each benchmark cell (97 336 atoms / 2.73 M edges; the 54 872-atom
+    amorphous cell with its ragged degrees; 27 000 atoms at MF-ompa's 6-A cutoff) is the host KD-tree list (train/dataload.py:32-129
+    restated) as a multiset of (center, source, periodic image), rows sorted by center, edge vectors to fp32 rounding."""
+    cfg, pos, cell, _, _ = _benchmark_workload(model)
+    g = _same_edges(pos, cell, [True] * 3, cfg['cutoff'])
+    assert g.n_edges > 20 * len(pos)
