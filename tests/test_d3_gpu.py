@@ -182,3 +182,46 @@ def test_reference_pair_d3_binding_failures_are_not_silent():
     e1, f1, s1 = _reference_calculate(lib, NACL['numbers'], NACL['positions'], NACL['cell'], NACL['pbc'])
     e2, f2, s2 = _reference_calculate(lib, NACL['numbers'], NACL['positions'], NACL['cell'], NACL['pbc'])
     assert e1 == e2 and np.array_equal(f1, f2) and abs(e1 - NACL_REF['energy']) < RTOL * abs(NACL_REF['energy'])
+
+
+@pytest.mark.parametrize('damp', ['damp_bj', 'damp_zero'])
+def test_d3_forces_and_stress_are_derivatives_of_the_energy_at_1000_atoms(damp):
+    """f4 through size-independent properties (the reference's kernels carry no such test; its known answers are 2 .. 96 atoms): a
+    1 000-atom two-species cell at the DEFAULT cutoffs (vdw 9000, cn 1600 bohr^2: ~25 k pairs per atom, several periodic images of the
+    cell), fp64 kernels: central differences of the energy along a collective displacement reproduce -sum F.d, along a symmetric strain
+    reproduce V sigma:eps (pair_d3_for_ase.cu:1420-1780 accumulates both in the same pair loop), a rigid rotation leaves the energy and
+    rotates forces and stress."""
+    from sevennet_amd.d3 import D3Engine
+    from sevennet_amd.neighbor import diamond_cubic
+    pos, cell = diamond_cubic(5.431, (5, 5, 5), 0.08, 3)
+    cell = np.asarray(cell, np.float64)
+    z = np.where(np.arange(len(pos)) % 2 == 0, 14, 8).tolist()
+    eng = D3Engine(damp, 'pbe', 9000.0, 1600.0)
+    ev = lambda p, c: eng.compute(z, p, c, [True] * 3)   # noqa: E731
+    a = ev(pos, cell)
+    f, s, vol = a['forces'], a['stress'], abs(np.linalg.det(cell))
+    assert np.abs(f.sum(0)).max() < 1e-9 * np.abs(f).max() * len(pos)
+    d = f / np.abs(f).max()
+    h = 1e-4
+    lhs = (ev(pos + h * d, cell)['energy'] - ev(pos - h * d, cell)['energy']) / (2 * h)
+    # (D3 cuts pair and coordination-number sums off SHARPLY at the two radii, as the reference does: the ~300 pairs that cross the 50-A
+    # shell between the two displaced configurations each leave e_pair / 2h in the difference quotient -- 4.5e-6 relative measured)
+    assert abs(lhs + (f * d).sum()) <= 2e-5 * abs((f * d).sum()), (lhs, -(f * d).sum())
+    eps = np.array([[0.3, 0.1, -0.2], [0.1, -0.5, 0.4], [-0.2, 0.4, 0.7]]) * 1e-4     # symmetric strain
+    def strained(sign):   # noqa: E306
+        m = np.eye(3) + sign * eps
+        return ev(pos @ m, cell @ m)['energy']
+    lhs = (strained(+1) - strained(-1)) / 2
+    rhs = vol * (s * eps).sum()
+    # (under a strain every pair distance moves in proportion to r: the count of pairs crossing the sharp cutoff grows with the strain
+    # itself, so their share of the difference quotient does not vanish with it -- 2.1e-4 relative measured; the analytic stress, like the
+    # reference's, has no surface term)
+    assert abs(lhs - rhs) <= 1e-3 * abs(rhs) + 3e-6, (lhs, rhs)   # (the surface term is 1.3e-6 / 1.7e-6 eV for this strain, both dampings)
+    q, r = np.linalg.qr(np.random.default_rng(5).normal(size=(3, 3)))
+    R = q * np.sign(np.diag(r))
+    if np.linalg.det(R) < 0:
+        R[:, 0] = -R[:, 0]
+    b = ev(pos @ R.T, cell @ R.T)
+    assert abs(b['energy'] - a['energy']) <= 1e-10 * abs(a['energy'])
+    assert np.abs(b['forces'] - f @ R.T).max() <= 1e-9 * np.abs(f).max()
+    assert np.abs(b['stress'] - R @ s @ R.T).max() <= 1e-9 * np.abs(s).max()
