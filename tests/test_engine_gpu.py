@@ -1288,20 +1288,28 @@ def test_forces_are_the_gradient_of_the_energy_at_the_benchmark_size(model):
     eng = HipForceEngine(cfg, random_state_dict(cfg, seed=0), device='cuda:0', modal=modal)
     ns = eng.spec.num_species if eng.needs_species_rows else 0
 
-    def evaluate(p):
-        out = eng.compute(build_graph_gpu(types, p, cell, cfg['cutoff'], device='cuda:0', num_species=ns))
+    def evaluate(p, c=cell):
+        out = eng.compute(build_graph_gpu(types, p, c, cfg['cutoff'], device='cuda:0', num_species=ns))
         torch.cuda.synchronize()
-        return float(out['energy'].cpu()), out['forces'].cpu().numpy().astype(np.float64)
+        v = out['virial'].cpu().numpy()          # xx yy zz xy yz zx = -sum r (x) dE/dr (include/snet_hip.h)
+        return float(out['energy'].cpu()), out['forces'].cpu().numpy().astype(np.float64), \
+            np.array([[v[0], v[3], v[5]], [v[3], v[1], v[4]], [v[5], v[4], v[2]]])
 
-    e0, f0 = evaluate(pos)
+    e0, f0, v0 = evaluate(pos)
     d = f0 / np.abs(f0).max()
     h = 2e-3
-    ep, _ = evaluate(pos + h * d)
-    em, _ = evaluate(pos - h * d)
+    ep = evaluate(pos + h * d)[0]
+    em = evaluate(pos - h * d)[0]
     lhs, rhs = (ep - em) / (2 * h), -(f0 * d).sum()
     assert abs(rhs) > 1.0 and abs(ep - em) > 1e3 * 1e-8 * abs(e0)          # the signal is far above the rounding of the (fp64) energy sum
     # measured on an MI355X: relative mismatch 3.6e-5 (SevenNet-0: dE = -3.76 eV of -1 759 eV), 1.3e-5 (l3i5: -3.41 eV of 90 375 eV)
     assert abs(lhs - rhs) <= 2e-4 * abs(rhs), (lhs, rhs, ep - em, e0)
+    # ... and the virial is the strain derivative: dE/d(eps) = -virial : eps for a symmetric strain of cell and positions
+    # (force_output.py:218-230 forms the stress from it; pair_e3gnn.cpp:254-270 hands it to LAMMPS)
+    eps = np.array([[0.3, 0.1, -0.2], [0.1, -0.5, 0.4], [-0.2, 0.4, 0.7]]) * 2e-4
+    es = [evaluate(pos @ (np.eye(3) + sg * eps), cell @ (np.eye(3) + sg * eps))[0] for sg in (+1, -1)]
+    lhs, rhs = (es[0] - es[1]) / 2, -(v0 * eps).sum()
+    assert abs(lhs - rhs) <= 1e-3 * abs(rhs) + 1e-7 * abs(e0), (lhs, rhs, e0)
 
 
 @pytest.mark.gpu
